@@ -1,0 +1,71 @@
+"""ctypes binding of libaten_amd.so (include/aten_amd.h).
+
+The HIP library is the product: there is no CPU fallback and no CPU checker is reachable from here.
+If the shared object is missing or no GPU is present the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+from . import build
+
+_lib = None
+
+K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sample", "gather"]
+
+SYMBOLS = [
+    "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera",
+    "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset",
+    "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
+    "atn_assemble_tiles", "atn_download_film", "atn_get_stats", "atn_get_kernel_times",
+    "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples",
+    "atn_material_table", "atn_compact", "atn_sizeof_scene_desc", "atn_sizeof_destination",
+    "atn_abi_version",
+]
+
+
+class Destination(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("maxDepth", C.c_int32),
+                ("russianRouletteDepth", C.c_int32), ("sample", C.c_int32), ("frame", C.c_uint32),
+                ("progressive", C.c_int32), ("break_on_terminate", C.c_int32),
+                ("count_stats", C.c_int32), ("profile", C.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = build.HIP_LIB
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "aten_amd: %s is missing. Build it with `python -m aten_amd.build hip` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % path)
+        l = C.CDLL(path)
+        vp = C.c_void_p
+        l.atn_create.argtypes = [C.POINTER(vp), C.c_int]
+        l.atn_destroy.argtypes = [vp]; l.atn_destroy.restype = None
+        l.atn_last_error.argtypes = [vp]; l.atn_last_error.restype = C.c_char_p
+        l.atn_upload_scene.argtypes = [vp, vp]
+        l.atn_update_camera.argtypes = [vp, vp]
+        l.atn_init_sampler.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+        l.atn_set_random.argtypes = [vp, vp, C.c_uint32]
+        l.atn_set_screen_shard.argtypes = [vp, C.c_int32, C.c_int32]
+        l.atn_render.argtypes = [vp, C.POINTER(Destination), vp]
+        l.atn_reset.argtypes = [vp]
+        l.atn_film_device.argtypes = [vp]; l.atn_film_device.restype = vp
+        l.atn_tile_device.argtypes = [vp]; l.atn_tile_device.restype = vp
+        l.atn_tile_slots.argtypes = [vp]; l.atn_tile_slots.restype = C.c_uint32
+        l.atn_stream.argtypes = [vp]; l.atn_stream.restype = vp
+        l.atn_synchronize.argtypes = [vp]
+        l.atn_assemble_tiles.argtypes = [vp, vp, C.c_int32, vp]
+        l.atn_download_film.argtypes = [vp, vp]
+        l.atn_get_stats.argtypes = [vp, vp]
+        l.atn_get_kernel_times.argtypes = [vp, vp, vp]
+        l.atn_reset_kernel_times.argtypes = [vp]
+        l.atn_generate_paths.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, vp]
+        l.atn_trace_closest.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, vp, vp]
+        l.atn_cmj_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
+        l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+        l.atn_compact.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+        for n in ("atn_sizeof_scene_desc", "atn_sizeof_destination", "atn_abi_version"):
+            getattr(l, n).restype = C.c_uint32
+        _lib = l
+    return _lib

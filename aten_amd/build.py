@@ -1,0 +1,74 @@
+"""Build recipes for the native pieces (in-tree, explicit compiler calls).
+
+  libaten_amd_scene.so : host-only BVH builder (g++)
+  libaten_amd.so       : HIP kernels + C-ABI for gfx950 (hipcc)
+  oracle/liboracle.so  : CPU oracle -- test infrastructure, built by `make -C oracle`
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "aten_amd")
+CSRC = os.path.join(PKG, "csrc")
+
+HOST_LIB = os.path.join(PKG, "libaten_amd_scene.so")
+HIP_LIB = os.path.join(PKG, "libaten_amd.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+
+# -ffp-contract=off: the parity contract is per-operation IEEE fp32 rounding.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+             "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+             "-Wno-unused-result"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _walk(d, exts):
+    out = []
+    for r, _, fs in os.walk(d):
+        for f in fs:
+            if f.endswith(exts):
+                out.append(os.path.join(r, f))
+    return out
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_host(force=False):
+    srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp")]
+    deps = srcs + _walk(os.path.join(ROOT, "include"), (".h",))
+    if force or not _newer(HOST_LIB, deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", HOST_LIB] + srcs)
+    return HOST_LIB
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, "aten_amd.hip")]
+    deps = _walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",))
+    if force or not _newer(HIP_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", HIP_LIB] + srcs)
+    return HIP_LIB
+
+
+def build_oracle(force=False):
+    d = os.path.join(ROOT, "oracle")
+    deps = _walk(d, (".cpp", ".h")) + _walk(os.path.join(ROOT, "include"), (".h",))
+    if force or not _newer(ORACLE_LIB, deps):
+        _run(["make", "-C", d, "-B"])
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["host", "hip", "oracle"]
+    for w in what:
+        {"host": build_host, "hip": build_hip, "oracle": build_oracle}[w](force=True)

@@ -1,0 +1,553 @@
+// libaten_amd.so: host-side renderer object + C-ABI (include/aten_amd.h) over the HIP kernels.
+//
+// atn::PathTracing mirrors the public surface of the reference's GPU seam --
+// idaten::Renderer / idaten::PathTracing (src/libidaten/kernel/renderer.h:17-179,
+// src/libidaten/kernel/pathtracing.cpp:23-153): UpdateSceneData, updateCamera, render, reset --
+// with the CPU renderer's semantics (frame passed in, CMJ seeded once per sample).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/aten_amd.h"
+#include "device/kernels.hpp"
+#include "host/scene_upload.hpp"
+
+namespace atn {
+
+#define ATN_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) { return fail(ATN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t resize(size_t count)
+    {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t s)
+    {
+        hipError_t e = resize(v.size() ? v.size() : 1);
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+class PathTracing {
+public:
+    std::string last_error;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // scene (HBM-resident after UpdateSceneData)
+    DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels;
+    DevBuf<atn_triangle_param> tris;
+    DevBuf<atn_object_param> objects;
+    DevBuf<DevMaterial> materials;
+    DevBuf<atn_light_param> lights;
+    DevBuf<DevTexture> textures;
+    DevScene scene{};
+    bool has_scene = false, has_camera = false;
+    atn_camera_param camera{};
+
+    // sampler
+    DevBuf<uint32_t> seeds;
+    uint32_t n_seeds = 0;
+
+    // path state
+    DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
+    DevBuf<uint4> smp;
+    DevBuf<int2> isect2;
+    DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
+    DevBuf<unsigned long long> stats;
+    int32_t film_w = 0, film_h = 0;
+    int32_t rank = 0, world = 1;
+    uint32_t n_slots = 0;
+    int32_t counters_depth = 0;
+
+    // profiling
+    float k_ms[ATN_K_COUNT] = {};
+    uint32_t k_launches[ATN_K_COUNT] = {};
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int kind; size_t e0, e1; };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
+    uint64_t host_stats[8] = {};
+
+    int fail(int code, const std::string& msg) { last_error = msg; return code; }
+
+    int init(int device_ordinal)
+    {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) return fail(ATN_ERR_NO_DEVICE, "no HIP device available (libaten_amd has no CPU fallback)");
+        if (device_ordinal < 0 || device_ordinal >= n) return fail(ATN_ERR_INVALID_ARG, "device ordinal out of range");
+        device = device_ordinal;
+        ATN_HIP(hipSetDevice(device));
+        ATN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return ATN_OK;
+    }
+
+    ~PathTracing()
+    {
+        for (auto& e : ev_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    // ≙ idaten::Renderer::UpdateSceneData, src/libidaten/kernel/renderer.cpp:12-131
+    int UpdateSceneData(const atn_scene_desc* s)
+    {
+        ATN_HIP(hipSetDevice(device));
+        HostSceneImage img;
+        std::string err;
+        if (!build_host_image(img, s, err)) return fail(ATN_ERR_UNSUPPORTED, err);
+        ATN_HIP(nodes.upload(img.nodes, stream));
+        ATN_HIP(tris.upload(img.tris, stream));
+        ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));
+        ATN_HIP(vtx_nml.upload(img.vtx_nml, stream));
+        ATN_HIP(objects.upload(img.objects, stream));
+        ATN_HIP(matrices.upload(img.matrices, stream));
+        ATN_HIP(materials.upload(img.materials, stream));
+        ATN_HIP(lights.upload(img.lights, stream));
+        ATN_HIP(texels.upload(img.texels, stream));
+        ATN_HIP(textures.upload(img.textures, stream));
+        ATN_HIP(hipStreamSynchronize(stream));      // `img` is pageable host memory
+        scene = img.params;
+        scene.nodes = nodes.p; scene.tris = tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
+        scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p;
+        scene.lights = lights.p; scene.texels = texels.p; scene.textures = textures.p;
+        has_scene = true;
+        return ATN_OK;
+    }
+
+    // ≙ idaten::Renderer::updateCamera, renderer.cpp:202-205
+    int updateCamera(const atn_camera_param* c)
+    {
+        if (!c) return fail(ATN_ERR_INVALID_ARG, "null camera");
+        camera = *c;
+        has_camera = true;
+        return ATN_OK;
+    }
+
+    int setRandom(const uint32_t* v, uint32_t n)
+    {
+        if (!v || n == 0) return fail(ATN_ERR_INVALID_ARG, "empty seed array");
+        ATN_HIP(hipSetDevice(device));
+        ATN_HIP(seeds.resize(n));
+        ATN_HIP(hipMemcpyAsync(seeds.p, v, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        ATN_HIP(hipStreamSynchronize(stream));
+        n_seeds = n;
+        return ATN_OK;
+    }
+
+    // ≙ aten::initSampler, src/libaten/sampler/sampler.cpp:8-18
+    int initSampler(int32_t w, int32_t h, int32_t seed)
+    {
+        if (w <= 0 || h <= 0) return fail(ATN_ERR_INVALID_ARG, "bad sampler size");
+        std::vector<uint32_t> v((size_t)w * h);
+        std::mt19937 src(seed);
+        for (auto& x : v) x = (uint32_t)src();
+        return setRandom(v.data(), (uint32_t)v.size());
+    }
+
+    int ensure_frame(int32_t w, int32_t h, int32_t max_depth)
+    {
+        const int32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+        const uint32_t n_tiles = (uint32_t)tx * ty;
+        const uint32_t tiles_per_rank = (n_tiles + world - 1) / world;
+        const uint32_t slots = tiles_per_rank * 64;
+        if (w != film_w || h != film_h || slots != n_slots) {
+            ATN_HIP(ray_o.resize(slots)); ATN_HIP(ray_d.resize(slots)); ATN_HIP(thr.resize(slots));
+            ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots)); ATN_HIP(isect2.resize(slots));
+            ATN_HIP(sh_o.resize(slots)); ATN_HIP(sh_d.resize(slots)); ATN_HIP(sh_c.resize(slots));
+            ATN_HIP(accum.resize(slots)); ATN_HIP(smp.resize(slots)); ATN_HIP(done.resize(slots));
+            ATN_HIP(queue0.resize(slots)); ATN_HIP(queue1.resize(slots)); ATN_HIP(shadow_q.resize(slots));
+            ATN_HIP(tile_out.resize(slots));
+            ATN_HIP(film.resize((size_t)w * h));
+            ATN_HIP(hipMemsetAsync(film.p, 0, (size_t)w * h * sizeof(float4), stream));
+            film_w = w; film_h = h; n_slots = slots;
+        }
+        if (max_depth + 2 > counters_depth) {
+            ATN_HIP(counters.resize((size_t)2 * (max_depth + 2)));
+            counters_depth = max_depth + 2;
+        }
+        if (!stats.p) {
+            ATN_HIP(stats.resize(8));
+            ATN_HIP(hipMemsetAsync(stats.p, 0, 64, stream));
+        }
+        return ATN_OK;
+    }
+
+    PathBuffers buffers(bool count)
+    {
+        PathBuffers pb{};
+        pb.ray_o = ray_o.p; pb.ray_d = ray_d.p; pb.thr = thr.p; pb.contrib = contrib.p; pb.smp = smp.p;
+        pb.isect = isect.p; pb.isect2 = isect2.p; pb.sh_o = sh_o.p; pb.sh_d = sh_d.p; pb.sh_c = sh_c.p;
+        pb.accum = accum.p; pb.done = done.p; pb.queue[0] = queue0.p; pb.queue[1] = queue1.p;
+        pb.shadow_q = shadow_q.p; pb.q_count = counters.p; pb.sh_count = counters.p + counters_depth;
+        pb.stats = count ? stats.p : nullptr;
+        return pb;
+    }
+
+    FrameParams frame_params(const atn_destination& d)
+    {
+        FrameParams fp{};
+        fp.width = d.width; fp.height = d.height; fp.n_slots = (int32_t)n_slots;
+        fp.tiles_x = (d.width + 7) / 8; fp.tiles_y = (d.height + 7) / 8;
+        fp.rank = rank; fp.world = world;
+        fp.max_depth = d.maxDepth;
+        fp.rr_depth = d.russianRouletteDepth;
+        if (fp.rr_depth > fp.max_depth) fp.rr_depth = fp.max_depth - 1;    // pathtracing.cpp:282-284
+        fp.sample = 0; fp.frame = d.frame; fp.n_seeds = n_seeds;
+        fp.break_on_terminate = d.break_on_terminate; fp.progressive = d.progressive;
+        return fp;
+    }
+
+    // launch geometry: enough waves to fill 256 CUs several times over; grid-stride loops do the rest
+    static uint32_t grid_for(uint32_t n, uint32_t cap_blocks = 256u * 16u)
+    {
+        uint32_t b = (n + 255u) / 256u;
+        if (b == 0) b = 1;
+        return b < cap_blocks ? b : cap_blocks;
+    }
+
+    void prof_begin(bool on, int kind)
+    {
+        if (!on) return;
+        if (ev_used + 2 > ev_pool.size()) {
+            for (int i = 0; i < 64; i++) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+        }
+        spans.push_back(Span{ kind, ev_used, ev_used + 1 });
+        (void)hipEventRecord(ev_pool[ev_used], stream);
+    }
+    void prof_end(bool on)
+    {
+        if (!on) return;
+        (void)hipEventRecord(ev_pool[ev_used + 1], stream);
+        ev_used += 2;
+    }
+    void prof_collect()
+    {
+        for (const Span& s : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev_pool[s.e0], ev_pool[s.e1]) == hipSuccess) { k_ms[s.kind] += ms; k_launches[s.kind]++; }
+        }
+        spans.clear();
+        ev_used = 0;
+    }
+
+    // ≙ idaten::PathTracing::render + OnRender (src/libidaten/kernel/pathtracing.cpp:49-153), loop
+    // structure of aten::PathTracing::OnRender/radiance (src/libaten/renderer/pathtracing/pathtracing.cpp:22-89,269-366)
+    int render(const atn_destination* d, atn_vec4* out_host)
+    {
+        if (!d) return fail(ATN_ERR_INVALID_ARG, "null destination");
+        if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+        if (!has_camera) return fail(ATN_ERR_INVALID_ARG, "atn_update_camera has not been called");
+        if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
+        if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
+        ATN_HIP(hipSetDevice(device));
+        int rc = ensure_frame(d->width, d->height, d->maxDepth);
+        if (rc) return rc;
+        const bool count = d->count_stats != 0, prof = d->profile != 0;
+        PathBuffers pb = buffers(count);
+        FrameParams fp = frame_params(*d);
+        if (count) ATN_HIP(hipMemsetAsync(stats.p, 0, 64, stream));
+
+        const uint32_t g_slots = grid_for(n_slots);
+        const uint32_t g_all = (n_slots + 255u) / 256u;
+        for (int32_t s = 0; s < d->sample; s++) {
+            fp.sample = s;
+            ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)2 * counters_depth * 4, stream));
+            prof_begin(prof, ATN_K_GEN);
+            hipLaunchKernelGGL(k_gen_path, dim3(g_slots), dim3(256), 0, stream, pb, fp, camera, (const uint32_t*)seeds.p);
+            prof_end(prof);
+            for (int32_t b = 0; b < d->maxDepth; b++) {
+                prof_begin(prof, ATN_K_TRACE_CLOSEST);
+                if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g_slots), dim3(256), 0, stream, pb, scene, b);
+                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g_slots), dim3(256), 0, stream, pb, scene, b);
+                prof_end(prof);
+                prof_begin(prof, ATN_K_SHADE);
+                hipLaunchKernelGGL(k_shade, dim3(g_slots), dim3(256), 0, stream, pb, scene, fp, camera, b);
+                prof_end(prof);
+                prof_begin(prof, ATN_K_TRACE_SHADOW);
+                if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(g_slots), dim3(256), 0, stream, pb, scene, b);
+                else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(g_slots), dim3(256), 0, stream, pb, scene, b);
+                prof_end(prof);
+            }
+            prof_begin(prof, ATN_K_ACCUM);
+            hipLaunchKernelGGL(k_accumulate_sample, dim3(g_all), dim3(256), 0, stream, pb, fp);
+            prof_end(prof);
+        }
+        prof_begin(prof, ATN_K_GATHER);
+        hipLaunchKernelGGL(k_gather, dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
+        prof_end(prof);
+        ATN_HIP(hipGetLastError());
+
+        if (count) {
+            ATN_HIP(hipMemcpyAsync(host_stats, stats.p, 64, hipMemcpyDeviceToHost, stream));
+        }
+        if (out_host) {
+            ATN_HIP(hipMemcpyAsync(out_host, film.p, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        }
+        if (out_host || count) ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;      // profiling spans are resolved lazily in kernel_times() (no sync in the frame loop)
+    }
+
+    // ≙ idaten::Renderer::reset, renderer.h:40-43
+    int reset()
+    {
+        if (film.p) {
+            ATN_HIP(hipSetDevice(device));
+            ATN_HIP(hipMemsetAsync(film.p, 0, film.n * sizeof(float4), stream));
+        }
+        return ATN_OK;
+    }
+};
+
+} // namespace atn
+
+struct atn_ctx { atn::PathTracing r; };
+
+using atn::PathTracing;
+
+#define CTX_OR_FAIL(ctx) do { if (!(ctx)) return ATN_ERR_INVALID_ARG; } while (0)
+#define C_HIP(r, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (r).fail(ATN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" {
+
+int atn_create(atn_ctx** out, int device_ordinal)
+{
+    if (!out) return ATN_ERR_INVALID_ARG;
+    *out = nullptr;
+    atn_ctx* c = new (std::nothrow) atn_ctx();
+    if (!c) return ATN_ERR_OUT_OF_MEMORY;
+    int rc = c->r.init(device_ordinal);
+    if (rc != ATN_OK) {
+        std::fprintf(stderr, "atn_create: %s\n", c->r.last_error.c_str());
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return ATN_OK;
+}
+
+void atn_destroy(atn_ctx* ctx) { delete ctx; }
+
+const char* atn_last_error(atn_ctx* ctx) { return ctx ? ctx->r.last_error.c_str() : "null context"; }
+
+int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene)
+{
+    CTX_OR_FAIL(ctx);
+    if (!scene) return ctx->r.fail(ATN_ERR_INVALID_ARG, "null scene");
+    return ctx->r.UpdateSceneData(scene);
+}
+
+int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAIL(ctx); return ctx->r.updateCamera(camera); }
+int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_OR_FAIL(ctx); return ctx->r.initSampler(w, h, seed); }
+int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_OR_FAIL(ctx); return ctx->r.setRandom(seeds, n); }
+
+int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
+{
+    CTX_OR_FAIL(ctx);
+    if (world <= 0 || rank < 0 || rank >= world) return ctx->r.fail(ATN_ERR_INVALID_ARG, "bad screen shard");
+    ctx->r.rank = rank; ctx->r.world = world;
+    return ATN_OK;
+}
+
+int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return ctx->r.render(dst, out_host); }
+int atn_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.reset(); }
+
+void* atn_film_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.film.p : nullptr; }
+void* atn_tile_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.tile_out.p : nullptr; }
+uint32_t atn_tile_slots(atn_ctx* ctx) { return ctx ? ctx->r.n_slots : 0; }
+void* atn_stream(atn_ctx* ctx) { return ctx ? (void*)ctx->r.stream : nullptr; }
+
+int atn_synchronize(atn_ctx* ctx)
+{
+    CTX_OR_FAIL(ctx);
+    C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
+    return ATN_OK;
+}
+
+int atn_assemble_tiles(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!gathered_dev || world <= 0 || r.film_w <= 0) return r.fail(ATN_ERR_INVALID_ARG, "atn_assemble_tiles: nothing rendered yet");
+    float4* dst = film_dev_out ? (float4*)film_dev_out : r.film.p;
+    const uint32_t total = (uint32_t)world * r.n_slots;
+    hipLaunchKernelGGL(atn::k_assemble_tiles, dim3((total + 255) / 256), dim3(256), 0, r.stream,
+                       (const float4*)gathered_dev, dst, r.film_w, r.film_h, (r.film_w + 7) / 8, (r.film_h + 7) / 8,
+                       world, (int32_t)r.n_slots);
+    C_HIP(r, hipGetLastError());
+    return ATN_OK;
+}
+
+int atn_download_film(atn_ctx* ctx, atn_vec4* out_host)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!out_host || !r.film.p) return r.fail(ATN_ERR_INVALID_ARG, "atn_download_film: nothing rendered yet");
+    C_HIP(r, hipMemcpyAsync(out_host, r.film.p, (size_t)r.film_w * r.film_h * sizeof(float4), hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
+int atn_get_stats(atn_ctx* ctx, uint64_t out[8])
+{
+    CTX_OR_FAIL(ctx);
+    for (int i = 0; i < 8; i++) out[i] = ctx->r.host_stats[i];
+    return ATN_OK;
+}
+
+int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT])
+{
+    CTX_OR_FAIL(ctx);
+    C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
+    ctx->r.prof_collect();
+    for (int i = 0; i < ATN_K_COUNT; i++) { ms[i] = ctx->r.k_ms[i]; launches[i] = ctx->r.k_launches[i]; }
+    return ATN_OK;
+}
+
+int atn_reset_kernel_times(atn_ctx* ctx)
+{
+    CTX_OR_FAIL(ctx);
+    C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
+    ctx->r.prof_collect();
+    for (int i = 0; i < ATN_K_COUNT; i++) { ctx->r.k_ms[i] = 0; ctx->r.k_launches[i] = 0; }
+    return ATN_OK;
+}
+
+// ---------------------------------------------------------------- stage entry points
+int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t sample, uint32_t frame, atn_ray* out_host)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!r.has_camera || r.n_seeds == 0 || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "atn_generate_paths: camera / sampler / output missing");
+    C_HIP(r, hipSetDevice(r.device));
+    const int32_t sr = r.rank, sw = r.world;
+    r.rank = 0; r.world = 1;
+    int rc = r.ensure_frame(width, height, 1);
+    if (rc) { r.rank = sr; r.world = sw; return rc; }
+    atn_destination d{}; d.width = width; d.height = height; d.maxDepth = 1; d.russianRouletteDepth = 1; d.sample = 1; d.frame = frame;
+    atn::FrameParams fp = r.frame_params(d);
+    fp.sample = sample;
+    atn::PathBuffers pb = r.buffers(false);
+    atn::DevBuf<atn_ray> out;
+    C_HIP(r, out.resize((size_t)width * height));
+    C_HIP(r, hipMemsetAsync(r.counters.p, 0, (size_t)2 * r.counters_depth * 4, r.stream));
+    if (sample > 0) C_HIP(r, hipMemsetAsync(r.done.p, 0, (size_t)r.n_slots * 4, r.stream));
+    hipLaunchKernelGGL(atn::k_gen_path, dim3(PathTracing::grid_for(r.n_slots)), dim3(256), 0, r.stream, pb, fp, r.camera, (const uint32_t*)r.seeds.p);
+    hipLaunchKernelGGL(atn::k_export_rays, dim3((r.n_slots + 255) / 256), dim3(256), 0, r.stream, pb, fp, out.p);
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, (size_t)width * height * sizeof(atn_ray), hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    r.rank = sr; r.world = sw;
+    r.film_w = 0; r.film_h = 0;     // force re-validation of frame buffers for the caller's shard
+    return ATN_OK;
+}
+
+int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float t_min, float t_max,
+                      atn_intersection* out_host, uint64_t* stats_out)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    if (!rays_host || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "null rays / output");
+    if (n == 0) { if (stats_out) { stats_out[0] = stats_out[1] = 0; } return ATN_OK; }
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<atn_ray> rays; atn::DevBuf<atn_intersection> out; atn::DevBuf<unsigned long long> st;
+    C_HIP(r, rays.resize(n)); C_HIP(r, out.resize(n)); C_HIP(r, st.resize(8));
+    C_HIP(r, hipMemcpyAsync(rays.p, rays_host, (size_t)n * sizeof(atn_ray), hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemsetAsync(st.p, 0, 64, r.stream));
+    if (stats_out) hipLaunchKernelGGL(atn::k_trace_batch<true>, dim3((n + 255) / 256), dim3(256), 0, r.stream, r.scene, (const atn_ray*)rays.p, n, t_min, t_max, out.p, st.p);
+    else hipLaunchKernelGGL(atn::k_trace_batch<false>, dim3((n + 255) / 256), dim3(256), 0, r.stream, r.scene, (const atn_ray*)rays.p, n, t_min, t_max, out.p, st.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, (size_t)n * sizeof(atn_intersection), hipMemcpyDeviceToHost, r.stream));
+    unsigned long long hs[8] = {};
+    C_HIP(r, hipMemcpyAsync(hs, st.p, 64, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    if (stats_out) { stats_out[0] = hs[3]; stats_out[1] = hs[4]; }
+    return ATN_OK;
+}
+
+int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t scramble, int32_t n, float* out_host)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (n <= 0 || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "bad sample count");
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<float> out;
+    C_HIP(r, out.resize(n));
+    hipLaunchKernelGGL(atn::k_cmj_samples, dim3(1), dim3(64), 0, r.stream, index, dimension, scramble, n, out.p);
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
+int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
+                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                       float* out_sample, float* out_eval)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    if (mtrl_id < 0 || mtrl_id >= r.scene.n_materials || n == 0) return r.fail(ATN_ERR_INVALID_ARG, "bad material id / count");
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<float> dn, dw, duv, ds, de; atn::DevBuf<uint32_t> di, dsc;
+    C_HIP(r, dn.resize(3 * (size_t)n)); C_HIP(r, dw.resize(3 * (size_t)n)); C_HIP(r, duv.resize(2 * (size_t)n));
+    C_HIP(r, ds.resize(7 * (size_t)n)); C_HIP(r, de.resize(5 * (size_t)n)); C_HIP(r, di.resize(n)); C_HIP(r, dsc.resize(n));
+    C_HIP(r, hipMemcpyAsync(dn.p, nrm, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(dw.p, wi, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(duv.p, uv, 8 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(di.p, index, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(dsc.p, scramble, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    hipLaunchKernelGGL(atn::k_material_table, dim3((n + 63) / 64), dim3(64), 0, r.stream, r.scene, mtrl_id, n,
+                       (const float*)dn.p, (const float*)dw.p, (const uint32_t*)di.p, (const uint32_t*)dsc.p, (const float*)duv.p, ds.p, de.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_sample, ds.p, 28 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipMemcpyAsync(out_eval, de.p, 20 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
+int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* out_idx_host, uint32_t* out_count)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!flags_host || !out_idx_host || !out_count) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
+    *out_count = 0;
+    if (n == 0) return ATN_OK;
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<int32_t> f, o; atn::DevBuf<uint32_t> c;
+    C_HIP(r, f.resize(n)); C_HIP(r, o.resize(n)); C_HIP(r, c.resize(1));
+    C_HIP(r, hipMemcpyAsync(f.p, flags_host, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    hipLaunchKernelGGL(atn::k_compact_stable, dim3(1), dim3(64), 0, r.stream, (const int32_t*)f.p, n, o.p, c.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_count, c.p, 4, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    if (*out_count) {
+        C_HIP(r, hipMemcpyAsync(out_idx_host, o.p, 4 * (size_t)(*out_count), hipMemcpyDeviceToHost, r.stream));
+        C_HIP(r, hipStreamSynchronize(r.stream));
+    }
+    return ATN_OK;
+}
+
+uint32_t atn_sizeof_scene_desc(void) { return (uint32_t)sizeof(atn_scene_desc); }
+uint32_t atn_sizeof_destination(void) { return (uint32_t)sizeof(atn_destination); }
+uint32_t atn_abi_version(void) { return 1; }
+
+} // extern "C"

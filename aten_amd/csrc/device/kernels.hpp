@@ -1,0 +1,528 @@
+// Wavefront path-tracing kernels.  One launch sequence per sample:
+//
+//   gen_path -> [ trace_closest -> shade (+ miss) -> trace_shadow ] x maxDepth -> accumulate_sample
+//   ... -> gather (film write)
+//
+// Path state lives in SoA float4 arrays indexed by the LOCAL path slot (one slot per pixel this
+// GPU owns); queues hold slot indices of live paths and are filled with wave64 ballot + mbcnt
+// prefix + one atomicAdd per wave (no scan kernels: the reference's StreamCompaction.cu needs
+// ~6 launches per bounce, src/libidaten/kernel/StreamCompaction.cu:175-316).
+//
+// Semantics are those of the CPU path aten::PathTracing (renderer/pathtracing/pathtracing.cpp:22-236,
+// 269-366 and pathtracing_impl.h) -- NOT of the CUDA backend, which re-seeds CMJ per bounce.
+#pragma once
+#include "shading.hpp"
+
+namespace atn {
+
+constexpr uint32_t F_TERMINATED = 1u, F_SINGULAR = 2u, F_HIT = 4u;
+
+struct PathBuffers {
+    float4* ray_o;      // org.xyz, pdfb
+    float4* ray_d;      // dir.xyz, flags (bit pattern)
+    float4* thr;        // throughput.xyz, -
+    float4* contrib;    // contrib.xyz, -
+    uint4* smp;         // cmj idx, dim, scramble ; global pixel index
+    float4* isect;      // t, a, b, triangle id (bit pattern)
+    int2* isect2;       // instance object id, TLAS mesh id
+    float4* sh_o;       // shadow org.xyz, distToLight
+    float4* sh_d;       // shadow dir.xyz, target light id (bit pattern)
+    float4* sh_c;       // lightcontrib.xyz, -
+    float4* accum;      // sum of valid sample contribs.xyz, count
+    uint32_t* done;     // pixel stopped sampling (pathtracing.cpp:350-352)
+    uint32_t* queue[2]; // live path slots, ping-pong per bounce
+    uint32_t* shadow_q; // slots with an active shadow ray this bounce
+    uint32_t* q_count;  // [maxDepth + 1] live count entering bounce b
+    uint32_t* sh_count; // [maxDepth]
+    unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
+};
+
+struct FrameParams {
+    int32_t width, height;
+    int32_t n_slots;            // local path slots (n_local_tiles * 64)
+    int32_t tiles_x, tiles_y;
+    int32_t rank, world;        // screen-space shard: tile t belongs to rank t % world
+    int32_t max_depth, rr_depth;
+    int32_t sample;
+    uint32_t frame;
+    uint32_t n_seeds;
+    int32_t break_on_terminate;
+    int32_t progressive;
+};
+
+// slot -> pixel.  Slots are grouped in 8x8 pixel tiles (one tile per wave64): a wave's primary
+// rays stay spatially coherent and a tile is the multi-GPU sharding unit.
+ATN_DEV bool slot_to_pixel(const FrameParams& fp, uint32_t slot, int32_t& x, int32_t& y)
+{
+    const uint32_t local_tile = slot >> 6;
+    const uint32_t in_tile = slot & 63u;
+    const uint32_t tile = local_tile * (uint32_t)fp.world + (uint32_t)fp.rank;
+    if (tile >= (uint32_t)(fp.tiles_x * fp.tiles_y)) return false;
+    const int32_t tx = (int32_t)(tile % (uint32_t)fp.tiles_x), ty = (int32_t)(tile / (uint32_t)fp.tiles_x);
+    x = tx * 8 + (int32_t)(in_tile & 7u);
+    y = ty * 8 + (int32_t)(in_tile >> 3);
+    return x < fp.width && y < fp.height;
+}
+
+// Wave-aggregated append.  Must be reached by every lane of the wave (predicated).
+ATN_DEV void queue_push(uint32_t* q, uint32_t* counter, bool pred, uint32_t value)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) q[base + prefix] = value;
+}
+
+ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
+{
+    // wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (__lane_id() == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// PinholeCamera::sample, camera/pinhole.cpp:97-118
+ATN_DEV void pinhole_sample(const atn_camera_param& cam, float s, float t, f3& org, f3& dir)
+{
+    s = 2.0F * s - 1.0F;
+    t = 2.0F * t - 1.0F;
+    const f3 cu = mk3(cam.u[0], cam.u[1], cam.u[2]), cv = mk3(cam.v[0], cam.v[1], cam.v[2]);
+    const f3 center = mk3(cam.center[0], cam.center[1], cam.center[2]);
+    const f3 origin = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    f3 pos_on_lens = s * cu + t * cv;
+    pos_on_lens = pos_on_lens + center;
+    dir = normalize(pos_on_lens - origin);
+    org = origin;
+}
+
+// GeneratePath, renderer/pathtracing/pathtracing_impl.h:65-110
+__global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp, atn_camera_param cam,
+                                                   const uint32_t* __restrict__ seeds)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < (uint32_t)fp.n_slots; base += stride) {
+        const uint32_t slot = base + (threadIdx.x & 63u);
+        int32_t ix = 0, iy = 0;
+        bool valid = slot < (uint32_t)fp.n_slots && slot_to_pixel(fp, slot, ix, iy);
+        if (valid && fp.sample > 0) valid = pb.done[slot] == 0;
+        if (valid) {
+            const uint32_t idx = (uint32_t)(iy * fp.width + ix);
+            const uint32_t rnd = seeds[idx % fp.n_seeds];
+            const uint32_t fs = fp.frame + (uint32_t)fp.sample;
+            const uint32_t scramble = rnd * 0x1fe3434fu * ((fs + 133u * rnd) / 256u);
+            Cmj smp; smp.idx = fs % 256u; smp.dim = 0; smp.scramble = scramble;
+            const float r1 = cmj_next(smp);
+            const float r2 = cmj_next(smp);
+            const float s = ((float)ix + r1) / (float)cam.width;
+            const float t = ((float)iy + r2) / (float)cam.height;
+            f3 org, dir;
+            pinhole_sample(cam, s, t, org, dir);
+            pb.ray_o[slot] = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
+            pb.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(0u));     // flags cleared
+            pb.thr[slot] = make_float4(1.0F, 1.0F, 1.0F, 0.0F);
+            pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+            pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, idx);
+            if (fp.sample == 0) { pb.accum[slot] = make_float4(0, 0, 0, 0); pb.done[slot] = 0; }
+        }
+        queue_push(pb.queue[0], &pb.q_count[0], valid, slot);
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_closest(PathBuffers pb, DevScene sc, int32_t bounce)
+{
+    const uint32_t count = pb.q_count[bounce];
+    const uint32_t* __restrict__ q = pb.queue[bounce & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    uint32_t nrays = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const uint32_t slot = q[j];
+        const float4 ro = pb.ray_o[slot], rd = pb.ray_d[slot];
+        Hit h;
+        traverse_closest<COUNT>(h, sc, mk3(ro), mk3(rd), kEps, kInf, &tc);
+        pb.isect[slot] = make_float4(h.t, h.a, h.b, __int_as_float(h.tri));
+        pb.isect2[slot] = make_int2(h.objid, h.meshid);
+        nrays++;
+    }
+    if (COUNT) {
+        wave_add_stat(&pb.stats[0], nrays);
+        wave_add_stat(&pb.stats[3], tc.nodes);
+        wave_add_stat(&pb.stats[4], tc.tris);
+    }
+}
+
+// PathTracing::shade (pathtracing.cpp:91-236) + ShadeMiss (pathtracing_impl.h:112-176) for one path.
+// Returns updated flags; fills the next ray and the shadow ray.
+__global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce)
+{
+    const uint32_t count = pb.q_count[bounce];
+    const uint32_t* __restrict__ q = pb.queue[bounce & 1];
+    uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t nhits = 0;
+
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += stride) {
+        const uint32_t j = base + (threadIdx.x & 63u);
+        const bool valid = j < count;
+        bool push_next = false, push_shadow = false;
+        uint32_t slot = 0;
+
+        if (valid) {
+            slot = q[j];
+            const float4 ro4 = pb.ray_o[slot], rd4 = pb.ray_d[slot];
+            const f3 ray_org = mk3(ro4), ray_dir = mk3(rd4);
+            float pdfb = ro4.w;
+            uint32_t flags = __float_as_uint(rd4.w);
+            const float4 is4 = pb.isect[slot];
+            const int2 is2 = pb.isect2[slot];
+            f3 throughput = mk3(pb.thr[slot]);
+            f3 contrib = mk3(pb.contrib[slot]);
+            uint4 s4 = pb.smp[slot];
+            Cmj smp; smp.idx = s4.x; smp.dim = s4.y; smp.scramble = s4.z;
+
+            flags &= ~F_HIT;
+            const bool is_hit = is2.x >= 0;
+
+            if (!is_hit) {
+                // ---------------- ShadeMiss
+                if (!(flags & F_TERMINATED)) {
+                    f3 dir = ray_dir;
+                    if (bounce == 0) {
+                        const int32_t ix = (int32_t)(s4.w % (uint32_t)fp.width), iy = (int32_t)(s4.w / (uint32_t)fp.width);
+                        const float s = (float)ix / (float)fp.width;
+                        const float t = (float)iy / (float)fp.height;
+                        f3 o;
+                        pinhole_sample(cam, s, t, o, dir);
+                    }
+                    const float4 emit = background_sample(sc, dir);
+                    float misW = 1.0f;
+                    if (!(bounce == 0 || (bounce == 1 && (flags & F_SINGULAR)))) {
+                        // ImageBasedLight::samplePdf, light/ibl.h:46-58
+                        float pdfLight = luminance(emit.x, emit.y, emit.z) / sc.avgIllum;
+                        pdfLight /= (2.0f * kPi);
+                        misW = pdfb / (pdfLight + pdfb);
+                    }
+                    f3 c = 1.0F * mk3(mul4(misW, emit)) + mk3(0.0F);   // ApplyAlphaBlend (transmission 1, throughput 0)
+                    c = c * throughput;
+                    contrib = contrib + c;
+                    flags |= F_TERMINATED;
+                }
+            }
+            else {
+                flags |= F_HIT;
+                nhits++;
+                // ---------------- shade
+                const int32_t tri_id = __float_as_int(is4.w);
+                HitRec rec;
+                evaluate_hit(rec, sc, is2.x, tri_id, is4.y, is4.z);
+                const atn_triangle_param tp = sc.tris[tri_id];
+                const int32_t mtrlid = tp.mtrlid;
+
+                const bool isBackfacing = dot(rec.normal, -ray_dir) < 0.0F;
+                f3 orienting_normal = rec.normal;
+
+                DevMaterial m;
+                if (mtrlid >= 0) m = sc.materials[mtrlid];
+                else {  // FillMaterial fallback, material_impl.h:253-259
+                    m.baseColor = make_float4(1, 1, 1, 1); m.type = ATN_MTRL_DIFFUSE; m.attrib = 0; m.id = 0;
+                    m.albedoMap = m.normalMap = m.roughnessMap = -1; m.ior = 1.0F; m.roughness = 0.5F;
+                    m.subsurface = m.metallic = m.specular = m.specularTint = 0.5F;
+                    m.sheen = m.sheenTint = m.clearcoat = m.clearcoatGloss = 0.5F;
+                }
+                float4 albedo4 = sample_texture(sc, m.albedoMap, rec.u, rec.v, m.baseColor);
+                albedo4 = add4(mul4(1.0F, albedo4), make_float4(0, 0, 0, 0));
+                const f3 albedo = mk3(albedo4);
+
+                bool shaded_out = false;
+                // HitTeminatedMaterial -> HitImplicitLight, pathtracing_impl.h:395-509
+                if (m.type == ATN_MTRL_EMISSIVE && (m.attrib & ATN_MTRL_ATTR_EMISSIVE) && !isBackfacing) {
+                    const atn_object_param* obj = &sc.objects[is2.x];
+                    const atn_light_param lp = sc.lights[obj->light_id];
+                    const f3 light_color = area_light_color(lp, rec.area);
+                    float weight = 1.0f;
+                    if (bounce > 0) {
+                        const float cosLight = dot(rec.normal, -ray_dir);
+                        const f3 dv = rec.p - ray_org;
+                        const float dist2 = dot(dv, dv);
+                        if (cosLight >= 0) {
+                            float pdfLight = 1 / rec.area;
+                            pdfLight = (pdfLight * dist2) / cosLight;
+                            weight = pdfb / (pdfb + pdfLight);
+                        }
+                    }
+                    contrib = contrib + (throughput * weight) * light_color;
+                    flags |= F_TERMINATED;
+                    shaded_out = true;
+                }
+
+                if (!shaded_out) {
+                    if (!(m.attrib & ATN_MTRL_ATTR_TRANSLUCENT) && isBackfacing) orienting_normal = -orienting_normal;
+                    orienting_normal = apply_normal_map(sc, m.normalMap, orienting_normal, rec.u, rec.v);
+
+                    // ---- FillShadowRay / SampleLight, pathtracing_impl.h:178-264
+                    const bool invalid_mtrl = (m.attrib & (ATN_MTRL_ATTR_SINGULAR | ATN_MTRL_ATTR_TRANSLUCENT)) != 0;
+                    bool shadow_active = false;
+                    if (sc.n_lights > 0 && !invalid_mtrl) {
+                        int32_t li = (int32_t)(cmj_next(smp) * (float)sc.n_lights);
+                        li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
+                        const float lightSelectPdf = 1.0f / (float)sc.n_lights;
+                        const atn_light_param lp = sc.lights[li];
+                        LightSample ls;
+                        sample_light(ls, lp, sc, rec.p, orienting_normal, smp);
+                        const f3 dirToLight = normalize(ls.dir);
+                        const float distToLight = length(ls.pos - rec.p);
+                        const f3 so = ray_offset(rec.p, orienting_normal);
+                        f3 radiance;
+                        f3 lightcontrib = mk3(0.0F);
+                        if (radiance_nee(radiance, sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls)) {
+                            lightcontrib = (throughput * radiance) * albedo;
+                            shadow_active = true;
+                        }
+                        pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
+                        pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, __int_as_float(li));
+                        pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, 0.0F);
+                    }
+
+                    // ---- ComputeRussianProbability, pathtracing_impl.h:680-698
+                    float russian_prob = 1.0f;
+                    if (bounce > fp.rr_depth) {
+                        if (dot(throughput, throughput) > 0) {
+                            russian_prob = max3(throughput);
+                            const float p = cmj_next(smp);
+                            if (p >= russian_prob) flags |= F_TERMINATED; else flags &= ~F_TERMINATED;
+                        }
+                    }
+
+                    // ---- sampleMaterial + PrepareForNextBounce, pathtracing_impl.h:700-743
+                    MtrlSample ms;
+                    sample_material(ms, sc, m, orienting_normal, ray_dir, smp, rec.u, rec.v);
+                    const f3 next_dir = normalize(ms.dir);
+                    const f3 ray_along_normal = dot(orienting_normal, next_dir) >= 0.0f ? orienting_normal : -orienting_normal;
+                    const float c = dot(ray_along_normal, next_dir);
+                    if (ms.pdf > 0 && c > 0) {
+                        throughput = throughput * ((((albedo * ms.bsdf) * c) / ms.pdf));
+                        throughput = throughput / russian_prob;
+                    }
+                    else {
+                        flags |= F_TERMINATED;
+                    }
+                    if (!(flags & F_TERMINATED)) {
+                        pdfb = ms.pdf;
+                        flags = (m.attrib & ATN_MTRL_ATTR_SINGULAR) ? (flags | F_SINGULAR) : (flags & ~F_SINGULAR);
+                        const f3 no = ray_offset(rec.p, ray_along_normal);
+                        const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
+                        pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
+                        pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
+                        push_next = (bounce + 1 < fp.max_depth);
+                    }
+                    // HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
+                    push_shadow = shadow_active && !(flags & F_TERMINATED);
+                }
+            }
+            if (!push_next) {
+                // path ends here (terminated, or depth exhausted): keep flags for the sample epilogue
+                const float4 d = pb.ray_d[slot];
+                pb.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(flags));
+            }
+            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0F);
+            pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
+            pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, s4.w);
+        }
+        queue_push(qn, &pb.q_count[bounce + 1], push_next, slot);
+        queue_push(pb.shadow_q, &pb.sh_count[bounce], push_shadow, slot);
+    }
+    if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
+}
+
+// HitShadowRay -> HitTestToTargetLight -> scene::hitLight
+// (pathtracing_impl.h:266-393, scene/scene.h:64-134): closest hit toward the light, visible iff
+// the hit object IS the light object (or nothing is hit / infinite / singular rules).
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
+{
+    const uint32_t count = pb.sh_count[bounce];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    uint32_t nrays = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const uint32_t slot = pb.shadow_q[j];
+        const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
+        const float distToLight = so.w;
+        const int32_t li = __float_as_int(sd.w);
+        const atn_light_param lp = sc.lights[li];
+        const f3 dir = normalize(mk3(sd));      // aten::ray(org, dir) constructor re-normalises (pathtracing_impl.h:380)
+        Hit h;
+        const bool isHit = traverse_closest<COUNT>(h, sc, mk3(so), dir, kEps, distToLight - kEps, &tc);
+        const int32_t lightobj = (lp.type == ATN_LIGHT_AREA && lp.arealight_objid >= 0) ? lp.arealight_objid : -1;
+        const int32_t hitobj = isHit ? h.objid : lightobj;
+        bool visible;
+        if (hitobj == lightobj) visible = true;
+        else if (lp.attrib & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
+        else if (lp.attrib & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
+        else visible = false;
+        if (visible) {
+            const float4 c = pb.contrib[slot];
+            const float4 lc = pb.sh_c[slot];
+            pb.contrib[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
+        }
+        nrays++;
+    }
+    if (COUNT) {
+        wave_add_stat(&pb.stats[1], nrays);
+        wave_add_stat(&pb.stats[5], tc.nodes);
+        wave_add_stat(&pb.stats[6], tc.tris);
+    }
+}
+
+// Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,
+// accumulate, stop sampling this pixel once its path terminated.
+__global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, FrameParams fp)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.n_slots) return;
+    int32_t x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    if (fp.sample > 0 && pb.done[slot]) return;
+    const float4 c = pb.contrib[slot];
+    const bool invalid = isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z)
+        || c.x < 0 || c.y < 0 || c.z < 0;                     // Renderer::isInvalidColor, renderer.h:58-68
+    if (invalid) return;
+    float4 a = pb.accum[slot];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0F;
+    pb.accum[slot] = a;
+    const uint32_t flags = __float_as_uint(pb.ray_d[slot].w);
+    if (fp.break_on_terminate && (flags & F_TERMINATED)) pb.done[slot] = 1;
+}
+
+// col / cnt -> Film::put / FilmProgressive::put (renderer/film.cpp:33-45,61-71).
+// film: full-frame vec4[w*h] (row 0 = bottom); tile_out: this GPU's pixels in slot order
+// (the buffer that is all-gathered over RCCL when the screen is sharded).
+__global__ void __launch_bounds__(256) k_gather(PathBuffers pb, FrameParams fp, float4* film, float4* tile_out)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.n_slots) return;
+    int32_t x, y;
+    float4 out = make_float4(0, 0, 0, 0);
+    if (slot_to_pixel(fp, slot, x, y)) {
+        const float4 a = pb.accum[slot];
+        const float cnt = a.w;      // (float)cnt of an integer counter
+        const float4 v = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
+        const uint32_t idx = (uint32_t)(y * fp.width + x);
+        if (fp.progressive) {
+            const float4 cur = film[idx];
+            const float n = (float)((int32_t)cur.w);
+            const float d = n + 1;
+            out = make_float4((n * cur.x + v.x) / d, (n * cur.y + v.y) / d, (n * cur.z + v.z) / d, n + 1);
+        }
+        else {
+            out = v;
+        }
+        film[idx] = out;
+    }
+    if (tile_out) tile_out[slot] = out;
+}
+
+// Scatter all-gathered tile buffers (rank-major, each n_slots_per_rank float4) into a full frame.
+__global__ void __launch_bounds__(256) k_assemble_tiles(const float4* __restrict__ gathered, float4* film,
+                                                        int32_t width, int32_t height, int32_t tiles_x, int32_t tiles_y,
+                                                        int32_t world, int32_t slots_per_rank)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (uint32_t)(world * slots_per_rank)) return;
+    FrameParams fp{};
+    fp.width = width; fp.height = height; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+    fp.world = world; fp.rank = (int32_t)(g / (uint32_t)slots_per_rank);
+    const uint32_t slot = g % (uint32_t)slots_per_rank;
+    int32_t x, y;
+    if (slot_to_pixel(fp, slot, x, y)) film[y * width + x] = gathered[g];
+}
+
+// ---- stage kernels used by the parity tests through the C-ABI --------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_batch(DevScene sc, const atn_ray* __restrict__ rays, uint32_t n,
+                                                     float t_min, float t_max, atn_intersection* out,
+                                                     unsigned long long* stats)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    if (i < n) {
+        const atn_ray r = rays[i];
+        Hit h;
+        traverse_closest<COUNT>(h, sc, mk3(r.org[0], r.org[1], r.org[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), t_min, t_max, &tc);
+        atn_intersection o;
+        o.t = h.t; o.objid = h.objid; o.tri_id = h.tri; o.a = h.a; o.b = h.b; o.isVoxel = 0;
+        o.mtrlid = -1; o.meshid = -1;
+        if (h.objid >= 0) {
+            const atn_triangle_param tp = sc.tris[h.tri];
+            o.mtrlid = tp.mtrlid;
+            o.meshid = tp.mesh_id < 0 ? h.meshid : tp.mesh_id;     // threaded_bvh_traverser.h:206-209
+        }
+        out[i] = o;
+    }
+    if (COUNT) { wave_add_stat(&stats[3], tc.nodes); wave_add_stat(&stats[4], tc.tris); }
+}
+
+__global__ void __launch_bounds__(256) k_export_rays(PathBuffers pb, FrameParams fp, atn_ray* out)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.n_slots) return;
+    int32_t x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    const float4 o = pb.ray_o[slot], d = pb.ray_d[slot];
+    atn_ray r; r.org[0] = o.x; r.org[1] = o.y; r.org[2] = o.z; r.dir[0] = d.x; r.dir[1] = d.y; r.dir[2] = d.z;
+    out[y * fp.width + x] = r;
+}
+
+__global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim, uint32_t scramble, int n, float* out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Cmj s; s.idx = index; s.dim = dim; s.scramble = scramble;
+        for (int i = 0; i < n; i++) out[i] = cmj_next(s);
+    }
+}
+
+// BSDF table: for case i sample at (n, wi) with sampler (index, dim 0, scramble), then re-evaluate pdf/bsdf at the sampled dir
+__global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
+                                                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                                                       float* out_sample, float* out_eval)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial m = sc.materials[mtrl_id];
+    Cmj s; s.idx = index[i]; s.dim = 0; s.scramble = scramble[i];
+    const f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    const f3 WI = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    MtrlSample ms;
+    sample_material(ms, sc, m, N, WI, s, uv[2 * i], uv[2 * i + 1]);
+    float* o = out_sample + 7 * i;
+    o[0] = ms.dir.x; o[1] = ms.dir.y; o[2] = ms.dir.z; o[3] = ms.bsdf.x; o[4] = ms.bsdf.y; o[5] = ms.bsdf.z; o[6] = ms.pdf;
+    const float p = material_pdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+    const MtrlSample ev = material_bsdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+    float* e = out_eval + 5 * i;
+    e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
+}
+
+// Stable compaction of indices whose flag > 0 (the contract of idaten::StreamCompaction::compact,
+// src/libidaten/kernel/StreamCompaction.cu:175-316) for ONE wave-sized or larger array, done with
+// the same ballot/mbcnt primitive as queue_push but made order-preserving by a serial block loop.
+// Only used by the compaction known-answer test; the renderer's queues need no ordering.
+__global__ void __launch_bounds__(64) k_compact_stable(const int32_t* __restrict__ flags, uint32_t n, int32_t* out_idx, uint32_t* out_count)
+{
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + threadIdx.x;
+        const bool pred = i < n && flags[i] > 0;
+        const unsigned long long mask = __ballot(pred);
+        const uint32_t prefix = __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+        if (pred) out_idx[total + prefix] = (int32_t)i;
+        total += (uint32_t)__popcll(mask);
+    }
+    if (threadIdx.x == 0) *out_count = total;
+}
+
+} // namespace atn

@@ -1,0 +1,76 @@
+// Device-resident scene: what the kernels read.  Built once by Renderer::UpdateSceneData from
+// the caller's flat arrays (include/aten_layout.h); see DESIGN.md "data layout in HBM".
+#pragma once
+#include "vec.hpp"
+#include "../../../include/aten_layout.h"
+
+namespace atn {
+
+// One 48-byte record per BVH node, all node lists concatenated into a single array with ABSOLUTE
+// indices, each list re-laid-out in walk (pre-)order so that an inner node's hit link is always
+// index + 1.  The walk order -- and therefore every hit/miss decision -- is exactly the
+// reference's (threaded_bvh_traverser.h:98-304); only the storage differs:
+//
+//   q0.w = tag:  -1 inner | >= 0 triangle leaf (value = triangle id) | -2 TLAS leaf with nested
+//                tree | -3 TLAS leaf without one (sphere: never tested)
+//   inner    : q0 = {boxmin.xyz, -1}        q1 = {boxmax.xyz, miss}
+//   tri leaf : q0 = {v0.xyz, triid}         q1 = {e1.xyz, next}      q2 = {e2.xyz, 0}
+//              (v0, e1 = v1 - v0, e2 = v2 - v0 of the leaf's triangle: the three dependent
+//               gathers node -> TriangleParameter -> 3 vertices become one 48-byte read;
+//               e1/e2 are the same IEEE subtractions intersectTriangle performs, done at upload)
+//   TLAS leaf: q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), blas_root, -2}
+//              q1 = {meshid, top_hit, top_miss, 0}     (ints stored as bit patterns)
+struct DevNodes {
+    const float4* q;
+};
+
+constexpr float kTagInner = -1.0F;
+constexpr float kTagTlasNested = -2.0F;
+constexpr float kTagTlasDead = -3.0F;
+
+// MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
+struct DevMaterial {
+    float4 baseColor;
+    int32_t type;
+    uint32_t attrib;
+    int32_t id;
+    int32_t albedoMap;
+    int32_t normalMap;
+    int32_t roughnessMap;
+    float ior, roughness;
+    float subsurface, metallic, specular, specularTint;
+    float sheen, sheenTint, clearcoat, clearcoatGloss;
+};
+static_assert(sizeof(DevMaterial) == 80, "DevMaterial");
+
+struct DevTexture {
+    uint32_t offset;    // first texel in `texels`
+    int32_t width, height;
+    int32_t _pad;
+};
+
+struct DevScene {
+    const float4* nodes;                // DevNodes records, 3 float4 per node
+    const atn_triangle_param* tris;     // 32 B each (ids / needNormal / mtrlid / mesh_id)
+    const float4* vtx_pos;              // (pos.xyz, u)
+    const float4* vtx_nml;              // (nml.xyz, v)
+    const atn_object_param* objects;
+    const float4* matrices;             // 4 rows per mat4
+    const DevMaterial* materials;
+    const atn_light_param* lights;
+    const float4* texels;
+    const DevTexture* textures;
+    int32_t n_lights;
+    int32_t n_textures;
+    int32_t n_materials;
+    float bvh_hit_min;
+    // background (scene_rendering_config.bg)
+    float bg_color[3];
+    int32_t envmap_tex_idx;
+    float avgIllum;
+    float multiplyer;
+    int32_t enable_env_map;
+    float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
+};
+
+} // namespace atn

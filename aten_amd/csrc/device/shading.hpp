@@ -1,0 +1,590 @@
+// Hit evaluation, textures, BSDFs (Lambert / specular / GGX / Disney), lights and NEE: the device
+// side of aten's shared "impl" headers.  Each function cites the reference file:line
+// (relative to /root/reference/src/libaten) whose arithmetic it reproduces operation by operation.
+#pragma once
+#include "cmj.hpp"
+#include "scene_dev.hpp"
+#include "traverse.hpp"
+
+namespace atn {
+
+struct HitRec { f3 p; float area; f3 normal; float u, v; };
+struct MtrlSample { f3 dir; f3 bsdf; float pdf; };
+
+ATN_DEV m4 load_m4(const DevScene& sc, int32_t elem) // element index of a mat4
+{
+    m4 m;
+    m.r0 = sc.matrices[4 * elem + 0]; m.r1 = sc.matrices[4 * elem + 1];
+    m.r2 = sc.matrices[4 * elem + 2]; m.r3 = sc.matrices[4 * elem + 3];
+    return m;
+}
+
+// evaluate_hit_result (geometry/EvaluateHitResult.h:10-72) -> PolygonObject::evaluate_hit_result
+// (geometry/PolygonObject.h:37-72) -> triangle::EvaluateHitResult (geometry/triangle.h:69-120)
+ATN_DEV void evaluate_hit(HitRec& rec, const DevScene& sc, int32_t objid, int32_t tri_id, float a, float b)
+{
+    const atn_object_param* obj = &sc.objects[objid];
+    const bool is_inst = obj->type == ATN_OBJ_INSTANCE;
+    const atn_object_param* real_obj = is_inst ? &sc.objects[obj->object_id] : obj;
+    const int32_t mtx_id = is_inst ? obj->mtx_id : -1;
+    m4 L2W = m4_identity();
+    if (mtx_id >= 0) L2W = load_m4(sc, mtx_id);
+
+    const atn_triangle_param tri = sc.tris[tri_id];
+    const float4 p0 = sc.vtx_pos[tri.idx[0]], p1 = sc.vtx_pos[tri.idx[1]], p2 = sc.vtx_pos[tri.idx[2]];
+    const float4 n0 = sc.vtx_nml[tri.idx[0]], n1 = sc.vtx_nml[tri.idx[1]], n2 = sc.vtx_nml[tri.idx[2]];
+    const float c = 1 - a - b;
+
+    float4 P = add4(add4(mul4(c, p0), mul4(a, p1)), mul4(b, p2));
+    float4 N = add4(add4(mul4(c, n0), mul4(a, n1)), mul4(b, n2));
+    rec.p = mk3(P);
+    rec.normal = mk3(N);
+    rec.u = (c * p0.w + a * p1.w) + b * p2.w;
+    rec.v = (c * n0.w + a * n1.w) + b * n2.w;
+    if (tri.needNormal > 0) {
+        float4 e01 = sub4(p1, p0), e02 = sub4(p2, p0);
+        e01.w = 0.0F; e02.w = 0.0F;
+        rec.normal = mk3(normalize4(cross4(e01, e02)));
+    }
+    // PolygonObject: whole-object area scaled by the instance's edge-length ratio
+    {
+        const f3 q0 = mk3(p0), q1 = mk3(p1);
+        const float orignalLen = length(q1 - q0);
+        const f3 s0 = m4_apply_w1(L2W, q0), s1 = m4_apply_w1(L2W, q1);
+        const float scaledLen = length(s1 - s0);
+        float ratio = scaledLen / orignalLen;
+        ratio = ratio * ratio;
+        rec.area = real_obj->area * ratio;
+    }
+    rec.p = m4_apply(L2W, rec.p);
+    rec.normal = normalize(m4_applyXYZ(L2W, rec.normal));
+}
+
+// texture::at (image/texture.cpp:64-75, image/texture.h:197-208): point sample, wrap-repeat
+ATN_DEV int32_t wrap_repeat(int32_t value, int32_t wrap_size)
+{
+    if (wrap_size <= 0) return 0;
+    if (value > wrap_size) { int32_t n = value / wrap_size; value -= n * wrap_size; }
+    else if (value < 0) { int32_t n = abs(value / wrap_size); value += (n + 1) * wrap_size; }
+    return value;
+}
+ATN_DEV float4 sample_texture(const DevScene& sc, int32_t texid, float u, float v, const float4& def)
+{
+    if (texid < 0 || texid >= sc.n_textures) return def;
+    const DevTexture t = sc.textures[texid];
+    const int32_t iu = (int32_t)(u * (float)(t.width - 1));
+    const int32_t iv = (int32_t)(v * (float)(t.height - 1));
+    const int32_t x = wrap_repeat(iu, t.width - 1);
+    const int32_t y = wrap_repeat(iv, t.height - 1);
+    return sc.texels[t.offset + (uint32_t)(y * t.width + x)];
+}
+
+// applyNormalMap, material/sample_texture.h:62-87
+ATN_DEV f3 apply_normal_map(const DevScene& sc, int32_t normalMap, const f3& orgNml, float u, float v)
+{
+    if (normalMap >= 0) {
+        f3 nml = mk3(sample_texture(sc, normalMap, u, v, make_float4(0, 0, 0, 0)));
+        nml = 2.0F * nml - mk3(1.0F);
+        nml = normalize(nml);
+        const f3 n = normalize(orgNml);
+        f3 t, b;
+        tangent_coordinate(n, t, b);
+        f3 r = (nml.z * n + nml.x * t) + nml.y * b;
+        return normalize(r);
+    }
+    return normalize(orgNml);
+}
+
+// ------------------------------------------------------------------ material helpers
+ATN_DEV float schlick_f0_cos(float f0, float costheta)         // material/material.h:500-509
+{
+    const float c = sclamp(1 - costheta, 0.0F, 1.0F);
+    const float c5 = (((c * c) * c) * c) * c;
+    return f0 + (1.0F - f0) * c5;
+}
+ATN_DEV float schlick_fresnel(float ni, float nt, const f3& w, const f3& n)    // material.h:466-498
+{
+    float costheta = dot(w, n);
+    if (costheta < 0) { float t = ni; ni = nt; nt = t; costheta = -costheta; }
+    float f0 = (ni - nt) / (ni + nt);
+    f0 = f0 * f0;
+    return schlick_f0_cos(f0, costheta);
+}
+ATN_DEV f3 reflect_vector(const f3& wi, const f3& n)            // material.h:517-524
+{
+    const f3 wo = wi - (2 * dot(wi, n)) * n;
+    return normalize(wo);
+}
+
+// Diffuse, material/diffuse.h:86-137
+ATN_DEV float diffuse_pdf(const f3& n, const f3& wo) { return fabsf(dot(n, wo)) / kPi; }
+ATN_DEV f3 diffuse_dir(const f3& n, float r1, float r2)
+{
+    const float costheta = sqrtf(1 - r1);
+    const float sintheta = sqrtf(r1);
+    const float phi = kPi2 * r2;
+    const float cosphi = cosf(phi);
+    const float sinphi = sinf(phi);
+    f3 t, b;
+    tangent_coordinate(n, t, b);
+    const f3 dir = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + n * costheta;
+    return normalize(dir);
+}
+ATN_DEV f3 diffuse_brdf() { return mk3(1.0F) / kPi; }
+
+// GGX, material/ggx.cpp:107-274
+ATN_DEV float ggx_D(const f3& m, const f3& n, float roughness)
+{
+    const float a2 = roughness * roughness;
+    const float costheta = fabsf(dot(m, n));
+    const float cos2 = costheta * costheta;
+    const float denom = (a2 - 1) * cos2 + 1.0f;
+    const float denom2 = denom * denom;
+    return denom > 0 ? a2 / (kPi * denom2) : 0.0F;
+}
+ATN_DEV float ggx_lambda(float roughness, const f3& w, const f3& n)
+{
+    const float cos_theta = fabsf(dot(w, n));
+    const float cos2 = cos_theta * cos_theta;
+    const float sin2 = 1.0f - cos2;
+    const float tan2 = sin2 / cos2;
+    const float a2 = 1.0f / ((roughness * roughness) * tan2);
+    return (-1.0f + sqrtf(1.0f + 1.0f / a2)) / 2.0f;
+}
+ATN_DEV float ggx_G2(float roughness, const f3& view, const f3& light, const f3& n)
+{
+    const float lwi = ggx_lambda(roughness, view, n);
+    const float lwo = ggx_lambda(roughness, light, n);
+    return 1.0f / ((1.0f + lwi) + lwo);
+}
+ATN_DEV float ggx_pdf_h(float roughness, const f3& n, const f3& m, const f3& wo)
+{
+    const float D = ggx_D(m, n, roughness);
+    const float costheta = fabsf(dot(m, n));
+    const float denom = 4 * fabsf(dot(wo, m));
+    return denom > 0 ? (D * costheta) / denom : 0.0F;
+}
+ATN_DEV float ggx_pdf(float roughness, const f3& n, const f3& wi, const f3& wo)
+{
+    const f3 wh = normalize((-wi) + wo);
+    return ggx_pdf_h(roughness, n, wh, wo);
+}
+ATN_DEV f3 ggx_sample_m(float roughness, const f3& n, float r1, float r2)
+{
+    float theta = atanf(roughness * sqrtf(r1 / (1 - r1)));
+    theta = ((theta >= 0) ? theta : (theta + 2 * kPi));
+    const float phi = (2 * kPi) * r2;
+    const float costheta = cosf(theta);
+    const float sintheta = sinf(theta);
+    const float cosphi = cosf(phi);
+    const float sinphi = sinf(phi);
+    f3 t, b;
+    tangent_coordinate(n, t, b);
+    const f3 m = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + n * costheta;
+    return normalize(m);
+}
+ATN_DEV f3 ggx_dir(float r1, float r2, float roughness, const f3& wi, const f3& n)
+{
+    return reflect_vector(wi, ggx_sample_m(roughness, n, r1, r2));
+}
+ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo)
+{
+    const f3 V = -wi, L = wo;
+    const f3 H = normalize(L + V);
+    const float NL = fabsf(dot(N, L));
+    const float NV = fabsf(dot(N, V));
+    const float D = ggx_D(H, N, roughness);
+    const float G = ggx_G2(roughness, V, L, N);
+    const float F = schlick_fresnel(1.0F, ior, L, H);
+    const float denom = (4 * NL) * NV;
+    const float bsdf = denom > kEps ? ((F * G) * D) / denom : 0.0f;
+    return mk3(bsdf);
+}
+ATN_DEV float ggx_roughness(const DevScene& sc, const DevMaterial& m, float u, float v)
+{
+    return sample_texture(sc, m.roughnessMap, u, v, make_float4(m.roughness, m.roughness, m.roughness, m.roughness)).x;
+}
+
+// Disney, material/disney_brdf.cpp:38-555
+ATN_DEV f3 dis_ctint(const f3& base)
+{
+    const float Y = dot(base, mk3(0.3F, 0.6F, 0.1F));
+    return Y > 0 ? base / Y : mk3(1.0F);
+}
+ATN_DEV float dis_schlick(float u)
+{
+    const float m = sclamp(1.0F - u, 0.0F, 1.0F);
+    const float m2 = m * m;
+    return (m2 * m2) * m;
+}
+ATN_DEV f3 dis_diffuse_brdf(const f3& base, float roughness, float subsurface, const f3& V, const f3& L, const f3& N)
+{
+    const f3 H = normalize(V + L);
+    const float LdotH = dot(L, H);
+    const float NdotV = dot(V, N);
+    const float NdotL = dot(L, N);
+    const float FV = dis_schlick(dot(V, N));
+    const float FL = dis_schlick(dot(L, N));
+    const float Fd90 = 0.5F + ((2 * LdotH) * LdotH) * roughness;
+    float fd = mixf(1.0F, Fd90, FL) * mixf(1.0F, Fd90, FV);
+    const float Fss90 = (LdotH * LdotH) * roughness;
+    const float Fss = mixf(1.0F, Fss90, FL) * mixf(1.0F, Fss90, FV);
+    const float ss = 1.25F * (Fss * (1.0F / (NdotL + NdotV) - 0.5F) + 0.5F);
+    fd = mixf(fd, ss, subsurface);
+    return (base / kPi) * fd;
+}
+ATN_DEV f3 dis_sheen_brdf(const f3& base, float sheen, float sheen_tint, const f3& V, const f3& L)
+{
+    const f3 H = normalize(V + L);
+    const f3 Csheen = mix3(mk3(1.0F), dis_ctint(base), sheen_tint);
+    const float FH = dis_schlick(dot(L, H));
+    return (sheen * Csheen) * FH;
+}
+ATN_DEV float dis_gtr1(float a, float NdotH)
+{
+    if (a >= 1) return 1 / kPi;
+    const float a2 = a * a;
+    const float t = 1.0F + ((a2 - 1.0F) * NdotH) * NdotH;
+    return (a2 - 1) / ((kPi * logf(a2)) * t);
+}
+ATN_DEV f3 dis_clearcoat_brdf(float clearcoat, const f3& V, const f3& L)
+{
+    const f3 H = normalize(V + L);
+    const float FH = dis_schlick(fabsf(dot(L, H)));
+    const float F = mixf(0.04F, 1.0F, FH);
+    return mk3((0.25F * clearcoat) * F);
+}
+ATN_DEV float dis_clearcoat_pdf(float gloss_or_rough, const f3& V, const f3& L, const f3& N)
+{
+    const f3 H = normalize(V + L);
+    const float NdotH = dot(N, H);
+    const float a = mixf(0.1F, 0.001F, gloss_or_rough);
+    const float D = dis_gtr1(a, NdotH);
+    const float costheta = fabsf(dot(H, N));
+    const float denom = 4 * fabsf(dot(L, H));
+    return denom > 0 ? (D * costheta) / denom : 0.0F;
+}
+ATN_DEV f3 dis_specular_brdf(const f3& base, float roughness, float metallic, float specular, float specular_tint,
+                             const f3& V, const f3& L, const f3& N)
+{
+    const f3 H = normalize(V + L);
+    const f3 Cspec = mix3(mk3(1.0F), dis_ctint(base), specular_tint);
+    const f3 F_s0 = mix3((0.08F * specular) * Cspec, base, metallic);
+    const f3 F = mix3(F_s0, mk3(1.0F), dot(L, H));
+    const float D = ggx_D(H, N, roughness);
+    const float G = ggx_G2(roughness, V, L, N);
+    const float NdotL = fabsf(dot(N, L));
+    const float NdotV = fabsf(dot(N, V));
+    const float denom = (4 * NdotV) * NdotL;
+    return denom > 0 ? ((F * D) * G) / denom : mk3(0.0F);
+}
+ATN_DEV float dis_specular_pdf(float roughness, const f3& V, const f3& L, const f3& N)
+{
+    const f3 H = normalize(V + L);
+    return ggx_pdf_h(roughness, N, H, L);
+}
+ATN_DEV void dis_weights(float w[4], const f3& base, float metalic, float sheen, float specular, float clearcoat)
+{
+    const float lum = luminance(base.x, base.y, base.z);
+    w[0] = lum * (1 - metalic);
+    w[1] = sheen * (1 - metalic);
+    w[2] = mixf(specular, 1.0F, metalic);
+    w[3] = 0.25F * clearcoat;
+    float norm = 0.0F;
+    norm += w[0]; norm += w[1]; norm += w[2]; norm += w[3];
+    if (norm > 0) { w[0] /= norm; w[1] /= norm; w[2] /= norm; w[3] /= norm; }
+}
+// evaluate every lobe whose weight is > 0 at (V, wo) and add weight * pdf (disney_brdf.cpp:404-433,527-550)
+ATN_DEV void dis_eval_rest(const DevMaterial& m, const f3& base, const float w[4], const f3& V, const f3& wo, const f3& N,
+                           f3& d, f3& sh, f3& sp, f3& cc, float& p, bool weight_first)
+{
+    if (w[0] > 0.0F) {
+        d = dis_diffuse_brdf(base, m.roughness, m.subsurface, V, wo, N);
+        const float prob = diffuse_pdf(N, wo);
+        p += weight_first ? w[0] * prob : prob * w[0];
+    }
+    if (w[1] > 0.0F) {
+        sh = dis_sheen_brdf(base, m.sheen, m.sheenTint, V, wo);
+        const float prob = 1 / kPi;
+        p += weight_first ? w[1] * prob : prob * w[1];
+    }
+    if (w[2] > 0.0F) {
+        sp = dis_specular_brdf(base, m.roughness, m.metallic, m.specular, m.specularTint, V, wo, N);
+        const float prob = dis_specular_pdf(m.roughness, V, wo, N);
+        p += weight_first ? w[2] * prob : prob * w[2];
+    }
+    if (w[3] > 0.0F) {
+        cc = dis_clearcoat_brdf(m.clearcoat, V, wo);
+        const float prob = dis_clearcoat_pdf(m.roughness, V, wo, N);   // reference quirk: roughness, not gloss (:431,517,548)
+        p += weight_first ? w[3] * prob : prob * w[3];
+    }
+}
+ATN_DEV float disney_pdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)   // :347-378
+{
+    float w[4];
+    const f3 base = mk3(m.baseColor);
+    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const f3 V = -wi;
+    float p = 0.0F;
+    p += w[0] * diffuse_pdf(n, wo);
+    p += w[1] * (1 / kPi);
+    p += w[2] * dis_specular_pdf(m.roughness, V, wo, n);
+    p += w[3] * dis_clearcoat_pdf(m.clearcoatGloss, V, wo, n);
+    return p;
+}
+ATN_DEV MtrlSample disney_bsdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)   // :380-441
+{
+    float w[4];
+    const f3 base = mk3(m.baseColor);
+    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const f3 V = -wi;
+    f3 d = mk3(0.0F), sh = mk3(0.0F), sp = mk3(0.0F), cc = mk3(0.0F);
+    float p = 0.0F;
+    dis_eval_rest(m, base, w, V, wo, n, d, sh, sp, cc, p, false);
+    MtrlSample r;
+    r.bsdf = ((1 - m.metallic) * (d + sh) + sp) + cc;
+    r.pdf = p;
+    r.dir = wo;
+    return r;
+}
+ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp)  // :443-555
+{
+    const float r1 = cmj_next(smp), r2 = cmj_next(smp), r3 = cmj_next(smp);
+    float w[4];
+    const f3 base = mk3(m.baseColor);
+    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const float c0 = w[0], c1 = c0 + w[1], c2 = c1 + w[2];
+    const f3 V = -wi, N = n;
+    f3 wo; float p = 0;
+    f3 d = mk3(0.0F), sh = mk3(0.0F), sp = mk3(0.0F), cc = mk3(0.0F);
+    if (r3 < c0) {
+        wo = diffuse_dir(N, r1, r2);
+        d = dis_diffuse_brdf(base, m.roughness, m.subsurface, V, wo, N);
+        p = diffuse_pdf(N, wo);
+        p *= w[0]; w[0] = 0.0F;
+    }
+    else if (r3 < c1) {
+        wo = diffuse_dir(N, r1, r2);
+        sh = dis_sheen_brdf(base, m.sheen, m.sheenTint, V, wo);
+        p = 1 / kPi;
+        p *= w[1]; w[1] = 0.0F;
+    }
+    else if (r3 < c2) {
+        wo = ggx_dir(r1, r2, m.roughness, -V, N);
+        sp = dis_specular_brdf(base, m.roughness, m.metallic, m.specular, m.specularTint, V, wo, N);
+        p = dis_specular_pdf(m.roughness, V, wo, N);
+        p *= w[2]; w[2] = 0.0F;
+    }
+    else {
+        const float a = mixf(0.1F, 0.001F, m.clearcoatGloss);
+        wo = reflect_vector(-V, ggx_sample_m(a, N, r1, r2));
+        cc = dis_clearcoat_brdf(m.clearcoat, V, wo);
+        p = dis_clearcoat_pdf(m.roughness, V, wo, N);
+        p *= w[3]; w[3] = 0.0F;
+    }
+    dis_eval_rest(m, base, w, V, wo, N, d, sh, sp, cc, p, true);
+    res.pdf = p;
+    res.bsdf = ((1 - m.metallic) * (d + sh) + sp) + cc;
+    res.dir = wo;
+}
+
+// material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
+ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
+                             const f3& wi, Cmj& smp, float u, float v)
+{
+    switch (m.type) {
+    case ATN_MTRL_SPECULAR: {
+        r.dir = reflect_vector(wi, normal);
+        r.pdf = 1.0F;
+        const float c = dot(normal, r.dir);
+        r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c);
+        break;
+    }
+    case ATN_MTRL_GGX: {
+        const float rough = ggx_roughness(sc, m, u, v);
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        r.dir = ggx_dir(r1, r2, rough, wi, normal);
+        r.pdf = ggx_pdf(rough, normal, wi, r.dir);
+        r.bsdf = ggx_brdf(rough, m.ior, normal, wi, r.dir);
+        break;
+    }
+    case ATN_MTRL_DISNEY:
+        disney_sample(r, m, normal, wi, smp);
+        break;
+    default: {  // Diffuse, Emissive (emissive.h:70-83) and the reference's fallback
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        r.dir = diffuse_dir(normal, r1, r2);
+        r.pdf = diffuse_pdf(normal, r.dir);
+        r.bsdf = diffuse_brdf();
+        break;
+    }
+    }
+}
+ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v)
+{
+    switch (m.type) {
+    case ATN_MTRL_SPECULAR: return 1.0F;
+    case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
+    case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
+    default: return diffuse_pdf(normal, wo);
+    }
+}
+ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v)
+{
+    MtrlSample r; r.pdf = 0.0F; r.dir = wo; r.bsdf = mk3(0.0F);
+    switch (m.type) {
+    case ATN_MTRL_SPECULAR: { const float c = dot(normal, wo); r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c); break; }
+    case ATN_MTRL_GGX: r.bsdf = ggx_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
+    case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
+    default: r.bsdf = diffuse_brdf(); break;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------ background / lights
+ATN_DEV void direction_to_uv(const f3& dir, float& u, float& v)    // renderer/background.h:88-127
+{
+    const float temp = atan2f(dir.x, dir.z);
+    const float r = length(dir);
+    const float phi = (temp >= 0) ? temp : (temp + 2 * kPi);
+    const float theta = acosf(dir.y / r);
+    u = phi / (2 * kPi);
+    v = 1 - theta / kPi;
+}
+ATN_DEV float4 background_sample(const DevScene& sc, const f3& dir)   // background.h:34-62
+{
+    if (sc.envmap_tex_idx < 0 || !sc.enable_env_map) {
+        return make_float4(sc.bg_color[0], sc.bg_color[1], sc.bg_color[2], 0.0F);
+    }
+    float u, v;
+    direction_to_uv(dir, u, v);
+    const float4 c = sample_texture(sc, sc.envmap_tex_idx, u, v, make_float4(1, 1, 1, 1));
+    return mul4(sc.multiplyer, c);
+}
+
+struct LightSample { f3 pos, dir, nml, color; float dist, pdf; uint32_t attrib; };
+
+ATN_DEV f3 area_light_color(const atn_light_param& p, float area)   // light/arealight.h:58-63
+{
+    const float lum = (p.scale * p.intensity) / area;
+    return mk3(p.light_color[0], p.light_color[1], p.light_color[2]) * lum;
+}
+
+// Light::sample (light/light_impl.h:12-43) and the per-type samplers it dispatches to
+ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const DevScene& sc, const f3& org, const f3& nml, Cmj& smp)
+{
+    res.pdf = 0.0F; res.dist = 0.0F; res.color = mk3(0.0F);
+    res.pos = org; res.dir = mk3(0.0F, 1.0F, 0.0F); res.nml = mk3(0.0F, 1.0F, 0.0F);
+    const f3 lpos = mk3(lp.pos.x, lp.pos.y, lp.pos.z);
+    const f3 lcol = mk3(lp.light_color[0], lp.light_color[1], lp.light_color[2]);
+    switch (lp.type) {
+    case ATN_LIGHT_AREA: {      // AreaLight::sample, arealight.h:65-143 (polygon lights)
+        if (lp.arealight_objid < 0) break;
+        const atn_object_param* obj = &sc.objects[lp.arealight_objid];
+        const atn_object_param* real_obj = obj->type == ATN_OBJ_INSTANCE ? &sc.objects[obj->object_id] : obj;
+        if (real_obj->type != ATN_OBJ_POLYGONS) break;
+        // PolygonObject::SamplePosAndNormal (PolygonObject.h:113-156) + triangle::SamplePosAndNormal (triangle.h:122-162)
+        const float r = cmj_next(smp);
+        uint32_t tri_idx = (uint32_t)((float)real_obj->triangle_num * r);
+        tri_idx += (uint32_t)real_obj->triangle_id;
+        const float r0 = cmj_next(smp), r1 = cmj_next(smp);
+        const float a = sqrtf(r0) * (1.0F - r1);
+        const float b = sqrtf(r0) * r1;
+        HitRec rec;
+        evaluate_hit(rec, sc, lp.arealight_objid, (int32_t)tri_idx, a, b);
+        res.pos = rec.p;
+        res.pdf = 1 / rec.area;
+        res.dir = rec.p - org;
+        res.dist = length(res.dir);
+        res.dir = normalize(res.dir);
+        res.nml = rec.normal;
+        res.color = area_light_color(lp, rec.area);
+        break;
+    }
+    case ATN_LIGHT_IBL: {       // ImageBasedLight::sample, light/ibl.h:71-133
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        res.dir = diffuse_dir(nml, r1, r2);
+        float u, v;
+        direction_to_uv(res.dir, u, v);
+        res.pos = org + sc.ibl_scene_radius * res.dir;
+        res.nml = -normalize(res.dir);
+        res.pdf = 1.0f / (2.0f * kPi);
+        res.dist = 1.0F;
+        const float4 lum = sample_texture(sc, lp.envmapidx, u, v, make_float4(1, 1, 1, 1));
+        res.color = mk3(mul4(lp.scale, lum));
+        break;
+    }
+    case ATN_LIGHT_POINT: {     // light/pointlight.h:40-58
+        res.pdf = 1.0f;
+        res.dir = lpos - org;
+        res.dist = length(res.dir);
+        res.dir = normalize(res.dir);
+        res.pos = lpos;
+        res.nml = normalize(-res.dir);
+        const float dist2 = sqr(res.dist);
+        res.color = ((lcol * lp.scale) * lp.intensity) / dist2;
+        break;
+    }
+    case ATN_LIGHT_SPOT: {      // light/spotlight.h:58-92
+        const f3 ldir = mk3(lp.dir.x, lp.dir.y, lp.dir.z);
+        res.pdf = 1.0f;
+        res.pos = lpos;
+        res.nml = ldir;
+        res.dir = lpos - org;
+        res.dist = length(res.dir);
+        res.dir = normalize(res.dir);
+        const float rho = dot(ldir, -res.dir);
+        const float cosHalfInner = cosf(lp.innerAngle * 0.5F);
+        const float cosHalfOuter = cosf(lp.outerAngle * 0.5F);
+        if (rho > cosHalfOuter) {
+            float att = (rho - cosHalfOuter) / (cosHalfInner - cosHalfOuter);
+            att = sclamp(att, 0.0f, 1.0f);
+            const float dist2 = sqr(res.dist);
+            res.color = (((lp.scale * lcol) * att) * lp.intensity) / dist2;
+        }
+        else {
+            res.pdf = 0.0f;
+            res.color = mk3(0.0F);
+        }
+        break;
+    }
+    case ATN_LIGHT_DIRECTION: { // light/directionallight.h:40-63
+        res.pdf = 1.0f;
+        const float4 nd = normalize4(make_float4(lp.dir.x, lp.dir.y, lp.dir.z, lp.dir.w));
+        res.dir = mk3(-nd.x, -nd.y, -nd.z);
+        res.nml = mk3(nd);
+        res.pos = org + (100000.0F * 0.5F) * res.dir;
+        res.color = (lcol * lp.scale) * lp.intensity;
+        res.dist = 1.0F;
+        break;
+    }
+    default: break;
+    }
+    res.attrib = lp.attrib;
+}
+
+// ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
+ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
+                          float hu, float hv, float light_select_prob, const LightSample& ls)
+{
+    const float cosShadow = dot(nml, ls.dir);
+    float path_pdf = material_pdf(sc, m, nml, wi, ls.dir, hu, hv);
+    const MtrlSample ev = material_bsdf(sc, m, nml, wi, ls.dir, hu, hv);
+    if (ev.pdf > 0) path_pdf = ev.pdf;
+    const float cosLight = dot(ls.nml, -ls.dir);
+    float dist2 = sqr(ls.dist);
+    const bool isInfinite = (ls.attrib & ATN_LIGHT_ATTR_INFINITE) != 0;
+    const bool is_singular = (ls.attrib & ATN_LIGHT_ATTR_SINGULAR) != 0;
+    dist2 = (isInfinite || is_singular) ? 1.0F : dist2;
+    if (cosShadow >= 0 && cosLight >= 0 && dist2 > 0 && path_pdf > 0.0F && ls.pdf > 0.0F) {
+        if (!isInfinite) path_pdf = (path_pdf * cosLight) / dist2;
+        const float f = ls.pdf * light_select_prob;
+        const float misW = is_singular ? 1.0f : f / (f + path_pdf);
+        const float G = isInfinite ? cosShadow * cosLight : (cosShadow * cosLight) / dist2;
+        out = ((((misW * ev.bsdf) * ls.color) * G) / ls.pdf) / light_select_prob;
+        return true;
+    }
+    return false;
+}
+
+} // namespace atn

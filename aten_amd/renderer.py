@@ -1,0 +1,149 @@
+"""Host-side handle over the C-ABI, named after the reference's GPU seam.
+
+`PathTracing` exposes the calls an aten application makes on idaten::PathTracing
+(src/libidaten/kernel/renderer.h:35-111, src/libidaten/kernel/pathtracing.cpp:23-153):
+UpdateSceneData, updateCamera, render, reset -- every one a thin forward into libaten_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import layout as L
+from ._lib import Destination, K_NAMES, lib
+
+
+class AtenAmdError(RuntimeError):
+    pass
+
+
+class PathTracing:
+    def __init__(self, device=0):
+        self._l = lib()
+        self._ctx = C.c_void_p()
+        rc = self._l.atn_create(C.byref(self._ctx), device)
+        if rc != 0:
+            raise AtenAmdError("atn_create failed (%d): no usable HIP device; libaten_amd has no CPU fallback" % rc)
+        if self._l.atn_sizeof_scene_desc() != C.sizeof(L.SceneDesc):
+            raise AtenAmdError("atn_scene_desc ABI mismatch")
+        if self._l.atn_sizeof_destination() != C.sizeof(Destination):
+            raise AtenAmdError("atn_destination ABI mismatch")
+        self.width = self.height = 0
+
+    def close(self):
+        if self._ctx:
+            self._l.atn_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AtenAmdError("%s (status %d)" % (self._l.atn_last_error(self._ctx).decode(), rc))
+
+    # ---- the reference's renderer surface
+    def UpdateSceneData(self, scene):
+        self._check(self._l.atn_upload_scene(self._ctx, C.cast(scene.ref(), C.c_void_p)))
+
+    def updateCamera(self, cam):
+        self._check(self._l.atn_update_camera(self._ctx, cam.ctypes.data))
+
+    def initSampler(self, width, height, seed=0):
+        self._check(self._l.atn_init_sampler(self._ctx, width, height, seed))
+
+    def setRandom(self, seeds):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        self._check(self._l.atn_set_random(self._ctx, seeds.ctypes.data, len(seeds)))
+
+    def setScreenShard(self, rank, world):
+        self._check(self._l.atn_set_screen_shard(self._ctx, rank, world))
+
+    def render(self, width, height, max_depth=5, rr_depth=3, spp=1, frame=0, progressive=True,
+               break_on_terminate=True, download=True, count_stats=False, profile=False):
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, int(progressive),
+                        int(break_on_terminate), int(count_stats), int(profile))
+        out = np.empty((height, width, 4), np.float32) if download else None
+        self._check(self._l.atn_render(self._ctx, C.byref(d), out.ctypes.data if download else None))
+        self.width, self.height = width, height
+        return out
+
+    def reset(self):
+        self._check(self._l.atn_reset(self._ctx))
+
+    # ---- results / instrumentation
+    def synchronize(self):
+        self._check(self._l.atn_synchronize(self._ctx))
+
+    def film_device_ptr(self):
+        return self._l.atn_film_device(self._ctx)
+
+    def tile_device_ptr(self):
+        return self._l.atn_tile_device(self._ctx)
+
+    def tile_slots(self):
+        return int(self._l.atn_tile_slots(self._ctx))
+
+    def stream_ptr(self):
+        return self._l.atn_stream(self._ctx)
+
+    def assemble_tiles(self, gathered_dev_ptr, world, out_dev_ptr=None):
+        self._check(self._l.atn_assemble_tiles(self._ctx, gathered_dev_ptr, world, out_dev_ptr))
+
+    def download_film(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._l.atn_download_film(self._ctx, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = np.zeros(8, np.uint64)
+        self._check(self._l.atn_get_stats(self._ctx, s.ctypes.data))
+        return dict(closest_rays=int(s[0]), shadow_rays=int(s[1]), hits=int(s[2]),
+                    closest_nodes=int(s[3]), closest_tris=int(s[4]), shadow_nodes=int(s[5]), shadow_tris=int(s[6]))
+
+    def kernel_times(self):
+        ms = np.zeros(6, np.float32); n = np.zeros(6, np.uint32)
+        self._check(self._l.atn_get_kernel_times(self._ctx, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def reset_kernel_times(self):
+        self._check(self._l.atn_reset_kernel_times(self._ctx))
+
+    # ---- stage entry points (parity tests)
+    def generate_paths(self, width, height, sample=0, frame=0):
+        rays = np.zeros(width * height, L.RAY)
+        self._check(self._l.atn_generate_paths(self._ctx, width, height, sample, frame, rays.ctypes.data))
+        return rays
+
+    def trace_closest(self, rays, t_min=1e-9, t_max=float(np.finfo(np.float32).max), stats=False):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), L.INTERSECTION)
+        st = np.zeros(2, np.uint64)
+        self._check(self._l.atn_trace_closest(self._ctx, rays.ctypes.data, len(rays), t_min, t_max,
+                                              out.ctypes.data, st.ctypes.data if stats else None))
+        return (out, st) if stats else out
+
+    def cmj_samples(self, index, dimension, scramble, n):
+        out = np.zeros(n, np.float32)
+        self._check(self._l.atn_cmj_samples(self._ctx, index, dimension, scramble, n, out.ctypes.data))
+        return out
+
+    def material_table(self, mtrl_id, nrm, wi, index, scramble, uv):
+        n = len(nrm)
+        nrm = np.ascontiguousarray(nrm, np.float32); wi = np.ascontiguousarray(wi, np.float32)
+        index = np.ascontiguousarray(index, np.uint32); scramble = np.ascontiguousarray(scramble, np.uint32)
+        uv = np.ascontiguousarray(uv, np.float32)
+        s = np.zeros((n, 7), np.float32); e = np.zeros((n, 5), np.float32)
+        self._check(self._l.atn_material_table(self._ctx, mtrl_id, n, nrm.ctypes.data, wi.ctypes.data,
+                                               index.ctypes.data, scramble.ctypes.data, uv.ctypes.data,
+                                               s.ctypes.data, e.ctypes.data))
+        return s, e
+
+    def compact(self, flags):
+        flags = np.ascontiguousarray(flags, np.int32)
+        out = np.zeros(max(1, len(flags)), np.int32)
+        cnt = C.c_uint32()
+        self._check(self._l.atn_compact(self._ctx, flags.ctypes.data, len(flags), out.ctypes.data, C.byref(cnt)))
+        return out[:cnt.value]

@@ -1,0 +1,474 @@
+"""Host scene assembly: what aten::context + ObjLoader + AcceleratedScene<sbvh>::build do,
+producing the flat arrays of include/aten_layout.h.
+
+Reference behaviour followed (paths relative to /root/reference/src):
+  * vertex / triangle registration order ........ libatenscene/ObjLoader.cpp:95-461
+  * triangle area, object area, ids ............. libaten/geometry/triangle.cpp:108-134,
+                                                  TriangleGroupMesh.cpp:10-35, PolygonObject.cpp:14-55
+  * object array = creation order, instances are entries too
+                                                  libaten/scene/host_scene_context.cpp:258-263
+  * every instance owns an (L2W, W2L) matrix pair  libaten/geometry/instance.h:253-269
+  * light_id on both instance and real object .... host_scene_context.cpp:398-427
+  * texture storage (flipped, *1/255, a=1) ....... libaten/image/image.cpp:40-88, image/texture.h:93-102
+  * .sbvh import ................................. libaten/accelerator/sbvh.cpp:1345-1436,109-128
+
+BVH topology comes from our own builder (aten_amd/csrc/host/bvh_builder.cpp) unless a
+reference-built .sbvh is imported.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from .. import layout as L
+from .._hostlib import hostlib
+from . import obj_loader
+
+F32 = np.float32
+
+
+def _length3(x, y, z):
+    return np.sqrt((x * x + y * y) + z * z, dtype=F32)
+
+
+class FlatScene:
+    """Owns the numpy arrays behind an atn_scene_desc."""
+
+    def __init__(self):
+        self.desc = L.SceneDesc()
+        self.keep = []
+        self.names = {}
+
+    def ref(self):
+        return C.byref(self.desc)
+
+
+class SceneBuilder:
+    def __init__(self):
+        self.pos = []           # (x,y,z,u)
+        self.nml = []           # (x,y,z,v)
+        self.tris = []          # dict rows
+        self.materials = []     # (name, np record)
+        self.textures = []      # (name, array[h,w,4])
+        self.objects = []       # dict: type, ...
+        self.matrices = []      # 4x4 f32
+        self.lights = []
+        self.blas = {}          # polygon object id -> node array (or None = build)
+        self.mesh_counter = 0
+        self.config = L.SceneRenderingConfig()
+        self.config.bvh_hit_min = -1.0
+        self.config.epsilon_bias = 1e-3
+        self.config.bg.envmap_tex_idx = -1
+        self.config.bg.avgIllum = 1.0
+        self.config.bg.multiplyer = 1.0
+        self.config.bg.enable_env_map = 1
+
+    # ---------------------------------------------------------------- materials / textures
+    def add_material(self, name, mtype, base_color, albedo_map=-1, normal_map=-1, roughness_map=-1, **std):
+        m = np.zeros((), L.MATERIAL_PARAM)
+        bc = list(base_color)
+        m["baseColor"] = (bc + [0.0])[:4] if len(bc) == 3 else bc      # vec4 = vec3 -> w = 0 (vec4.h:135-141 keeps w)
+        if len(bc) == 3:
+            m["baseColor"][3] = 1.0     # MaterialParameter() sets (0,0,0,1); operator=(vec3) keeps w
+        m["type"] = mtype
+        m["attrib"] = L.MTRL_ATTRIB.get(mtype, 0)
+        m["id"] = len(self.materials)
+        m["albedoMap"], m["normalMap"], m["roughnessMap"] = albedo_map, normal_map, roughness_map
+        s = dict(ior=1.0, roughness=0.5, shininess=1.0, subsurface=0.5, metallic=0.5, specular=0.5,
+                 specularTint=0.5, anisotropic=0.5, sheen=0.5, sheenTint=0.5, clearcoat=0.5, clearcoatGloss=0.5)
+        s.update(std)
+        m["standard"] = [s[k] for k in L.STANDARD_FIELDS]
+        m["medium"][3] = np.int32(-1).view(F32)     # MediumParameter.grid_idx = -1
+        m["medium"][4] = -1.0                       # majorant
+        self.materials.append((name, m))
+        return len(self.materials) - 1
+
+    def find_material(self, name):
+        for i, (n, _) in enumerate(self.materials):
+            if n == name:
+                return i
+        return -1
+
+    def add_texture(self, name, rgba):
+        """rgba: float32 [h, w, 4] already in aten's storage order (row 0 = image bottom)."""
+        for i, (n, _) in enumerate(self.textures):
+            if n == name:
+                return i
+        self.textures.append((name, np.ascontiguousarray(rgba, F32)))
+        return len(self.textures) - 1
+
+    def load_image(self, path):
+        """aten::Image::Load for LDR images: bytes * (1/255), vertical flip, missing alpha = 1."""
+        from PIL import Image
+        real = _resolve_case(path)
+        if real is None:
+            return -1
+        tag = os.path.basename(path)
+        for i, (n, _) in enumerate(self.textures):
+            if n == tag:
+                return i
+        img = Image.open(real)
+        if img.mode not in ("RGB", "RGBA", "L"):
+            img = img.convert("RGB")
+        a = np.asarray(img)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        h, w, ch = a.shape
+        out = np.zeros((h, w, 4), F32)
+        out[:, :, 3] = 1.0
+        norm = F32(1.0) / F32(255)
+        out[:, :, :min(ch, 4)] = a[:, :, :4].astype(F32) * norm
+        return self.add_texture(tag, out[::-1])
+
+    # ---------------------------------------------------------------- geometry
+    def load_obj(self, path, create_mtrl=None, separate_objs=False, normal_on_the_fly=False):
+        """ObjLoader::Load.  Returns the list of created PolygonObject ids."""
+        P, T, N, shapes, mtls = obj_loader.load_obj(path)
+        base = os.path.dirname(path)
+        objs = []
+        cur_obj = None
+
+        def new_obj(name):
+            self.objects.append(dict(type=L.OBJ_POLYGONS, name=name, meshes=[], first_tri=None))
+            return len(self.objects) - 1
+
+        for si, sh in enumerate(shapes):
+            ntri = len(sh.material_ids)
+            base_v = len(self.pos)
+            flags = []
+            for (v, vt, vn) in sh.corners:
+                px, py, pz = P[v]
+                uvz = 0.0
+                if vn < 0:
+                    nx, ny, nz = 0.0, 1.0, 0.0      # reference leaves nml unset; needNormal is set
+                    uvz = 1.0
+                else:
+                    nx, ny, nz = N[vn]
+                    uvz = 1.0 if normal_on_the_fly else 0.0
+                if np.isnan(nx) or np.isnan(ny) or np.isnan(nz):
+                    nx, ny, nz = 0.0, 1.0, 0.0
+                if vt >= 0:
+                    u, w = T[vt]
+                else:
+                    u, w = 0.0, 0.0
+                    uvz = -1.0
+                self.pos.append((px, py, pz, u))
+                self.nml.append((nx, ny, nz, w))
+                flags.append(uvz)
+
+            mesh = None
+            prev = None
+            for i in range(ntri):
+                mid = sh.material_ids[i]
+                if mesh is None or prev != mid:
+                    if mesh is not None:
+                        cur_obj = self._register_mesh(mesh, cur_obj, sh.name, objs, new_obj, False)
+                    mesh = dict(tris=[], mtrl=self._resolve_material(mid, mtls, base, create_mtrl),
+                                mesh_id=self._next_mesh_id())
+                    prev = mid
+                i0, i1, i2 = base_v + 3 * i, base_v + 3 * i + 1, base_v + 3 * i + 2
+                need = 1 if (flags[3 * i] == 1.0 or flags[3 * i + 1] == 1.0 or flags[3 * i + 2] == 1.0
+                             or normal_on_the_fly) else 0
+                self.tris.append(dict(idx=(i0, i1, i2), needNormal=need, mtrlid=mesh["mtrl"], mesh_id=mesh["mesh_id"]))
+                mesh["tris"].append(len(self.tris) - 1)
+
+            if separate_objs:
+                if cur_obj is None:
+                    cur_obj = new_obj(sh.name)
+                self.objects[cur_obj]["meshes"].append(mesh)
+                objs.append(cur_obj)
+                cur_obj = new_obj("") if si + 1 < len(shapes) else None
+            else:
+                cur_obj = self._register_mesh(mesh, cur_obj, sh.name, objs, new_obj, True)
+
+        if not separate_objs and cur_obj is not None:
+            objs.append(cur_obj)
+        for o in objs:
+            self.blas.setdefault(o, None)
+        return objs
+
+    def _register_mesh(self, mesh, cur_obj, shape_name, objs, new_obj, at_shape_end):
+        mtype = int(self.materials[mesh["mtrl"]][1]["type"])
+        if mtype == L.MTRL_EMISSIVE:
+            e = new_obj(shape_name)
+            self.objects[e]["meshes"].append(mesh)
+            objs.append(e)
+            return cur_obj
+        if cur_obj is None:
+            cur_obj = new_obj(shape_name)
+        self.objects[cur_obj]["meshes"].append(mesh)
+        return cur_obj
+
+    def _next_mesh_id(self):
+        self.mesh_counter += 1
+        return self.mesh_counter - 1
+
+    def _resolve_material(self, mid, mtls, base, create_mtrl):
+        if mid < 0:
+            i = self.find_material("")
+            if i < 0:
+                i = (create_mtrl("", L.MTRL_DIFFUSE, (1, 1, 1), "", "") if create_mtrl
+                     else self.add_material("", L.MTRL_DIFFUSE, (1, 1, 1)))
+            return i
+        m = mtls[mid]
+        i = self.find_material(m.name)
+        if i >= 0:
+            return i
+        if create_mtrl:
+            return create_mtrl(m.name, L.MTRL_DIFFUSE, m.diffuse, m.diffuse_texname, m.bump_texname)
+        alb = self.load_image(os.path.join(base, m.diffuse_texname)) if m.diffuse_texname else -1
+        nm = self.load_image(os.path.join(base, m.bump_texname)) if m.bump_texname else -1
+        return self.add_material(m.name, L.MTRL_DIFFUSE, m.diffuse, albedo_map=alb, normal_map=nm)
+
+    def add_mesh(self, name, positions, indices, mtrl, normals=None, uvs=None, need_normal=True):
+        """Programmatic PolygonObject (one TriangleGroupMesh).  positions [N,3], indices [M,3]."""
+        positions = np.asarray(positions, F32)
+        indices = np.asarray(indices, np.int64)
+        self.objects.append(dict(type=L.OBJ_POLYGONS, name=name, meshes=[], first_tri=None))
+        oid = len(self.objects) - 1
+        mesh = dict(tris=[], mtrl=mtrl, mesh_id=self._next_mesh_id())
+        for tri in indices:
+            base_v = len(self.pos)
+            for k in tri:
+                p = positions[k]
+                n = normals[k] if normals is not None else (0.0, 1.0, 0.0)
+                uv = uvs[k] if uvs is not None else (0.0, 0.0)
+                self.pos.append((p[0], p[1], p[2], uv[0]))
+                self.nml.append((n[0], n[1], n[2], uv[1]))
+            self.tris.append(dict(idx=(base_v, base_v + 1, base_v + 2), needNormal=1 if need_normal else 0,
+                                  mtrlid=mtrl, mesh_id=mesh["mesh_id"]))
+            mesh["tris"].append(len(self.tris) - 1)
+        self.objects[oid]["meshes"].append(mesh)
+        self.blas[oid] = None
+        return oid
+
+    def create_instance(self, obj_id, mtx_L2W=None):
+        """TransformableFactory::createInstance: adds an (L2W, W2L) matrix pair and an Instance entry."""
+        M = np.eye(4, dtype=F32) if mtx_L2W is None else np.asarray(mtx_L2W, F32).reshape(4, 4)
+        Minv = np.linalg.inv(M.astype(np.float64)).astype(F32) if mtx_L2W is not None else np.eye(4, dtype=F32)
+        mid = len(self.matrices)
+        self.matrices.append(M)
+        self.matrices.append(Minv)
+        self.objects.append(dict(type=L.OBJ_INSTANCE, object_id=obj_id, mtx_id=mid, light_id=-1))
+        return len(self.objects) - 1
+
+    def import_sbvh(self, obj_id, path):
+        """PolygonObject::importInternalAccelTree + sbvh::buildAsNestedTree's triangle offset."""
+        hdr, mtrl_names, nodes = read_sbvh(path)
+        self.blas[obj_id] = ("imported", nodes, hdr)
+
+    # ---------------------------------------------------------------- lights
+    def add_area_light(self, instance_id, color, intensity, scale=1.0):
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_AREA
+        l["attrib"] = 0
+        l["light_color"] = color
+        l["innerAngle"] = l["outerAngle"] = np.pi
+        l["scale"], l["intensity"] = scale, intensity
+        l["arealight_objid"] = instance_id
+        l["envmapidx"] = -1
+        self.lights.append(l)
+        lid = len(self.lights) - 1
+        o = self.objects[instance_id]
+        o["light_id"] = lid
+        if o["type"] == L.OBJ_INSTANCE:
+            self.objects[o["object_id"]]["light_id"] = lid
+        return lid
+
+    def add_ibl(self, envmap_tex, scale=1.0, avg_illum=None, multiplyer=1.0):
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_IBL
+        l["attrib"] = L.LATTR_INFINITE | L.LATTR_IBL
+        l["innerAngle"] = l["outerAngle"] = np.pi
+        l["scale"], l["intensity"] = scale, 1.0
+        l["arealight_objid"] = -1
+        l["envmapidx"] = envmap_tex
+        self.lights.append(l)
+        self.config.bg.envmap_tex_idx = envmap_tex
+        self.config.bg.multiplyer = multiplyer
+        if avg_illum is not None:
+            self.config.bg.avgIllum = avg_illum
+        return len(self.lights) - 1
+
+    def add_point_light(self, pos, color, intensity, scale=1.0):
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_POINT
+        l["attrib"] = L.LATTR_SINGULAR
+        l["pos"] = list(pos) + [1.0]
+        l["light_color"] = color
+        l["innerAngle"] = l["outerAngle"] = np.pi
+        l["scale"], l["intensity"] = scale, intensity
+        l["arealight_objid"] = -1
+        l["envmapidx"] = -1
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def set_background(self, color):
+        self.config.bg.bg_color[:] = color
+
+    # ---------------------------------------------------------------- build
+    def build(self):
+        fs = FlatScene()
+        lib = hostlib()
+        pos = np.asarray(self.pos, F32).reshape(-1, 4)
+        nml = np.asarray(self.nml, F32).reshape(-1, 4)
+        nt = len(self.tris)
+        tris = np.zeros(nt, L.TRIANGLE_PARAM)
+        if nt:
+            idx = np.asarray([t["idx"] for t in self.tris], np.int32)
+            tris["idx"] = idx
+            tris["needNormal"] = [t["needNormal"] for t in self.tris]
+            tris["mtrlid"] = [t["mtrlid"] for t in self.tris]
+            tris["mesh_id"] = [t["mesh_id"] for t in self.tris]
+            # triangle::BuildTriangle: area = 0.5 * |cross(e0, e1)| in fp32 (triangle.cpp:125-130)
+            p0, p1, p2 = pos[idx[:, 0], :3], pos[idx[:, 1], :3], pos[idx[:, 2], :3]
+            e0, e1 = (p1 - p0).astype(F32), (p2 - p0).astype(F32)
+            cx = e0[:, 1] * e1[:, 2] - e0[:, 2] * e1[:, 1]
+            cy = e0[:, 2] * e1[:, 0] - e0[:, 0] * e1[:, 2]
+            cz = e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0]
+            tris["area"] = F32(0.5) * _length3(cx, cy, cz)
+
+        objs = np.zeros(len(self.objects), L.OBJECT_PARAM)
+        objs["object_id"] = -1; objs["mtx_id"] = -1; objs["triangle_id"] = -1; objs["light_id"] = -1
+        objs["sphere_mtrl_id"] = -1
+        obj_bbox = {}
+        bvh_lists = [None]          # [0] = TLAS
+        blas_index = {}
+        for oid, o in enumerate(self.objects):
+            if o["type"] != L.OBJ_POLYGONS:
+                continue
+            tri_ids = [t for m in o["meshes"] for t in m["tris"]]
+            if not tri_ids:
+                continue
+            first, num = tri_ids[0], len(tri_ids)
+            area = F32(0)
+            for m in o["meshes"]:
+                ma = F32(0)
+                for t in m["tris"]:
+                    ma = F32(ma + tris["area"][t])
+                area = F32(area + ma)
+            objs[oid]["type"] = L.OBJ_POLYGONS
+            objs[oid]["area"] = area
+            objs[oid]["triangle_id"] = first
+            objs[oid]["triangle_num"] = num
+            objs[oid]["light_id"] = o.get("light_id", -1)
+            spec = self.blas.get(oid)
+            if spec is not None and spec[0] == "imported":
+                nodes = spec[1].copy()
+                leaf = nodes["f0"] >= 0
+                nodes["f1"][leaf] += F32(first)     # sbvh::buildAsNestedTree, sbvh.cpp:109-128
+                hdr = spec[2]
+                bmin, bmax = np.asarray(hdr["boxmin"], F32), np.asarray(hdr["boxmax"], F32)
+            else:
+                out = C.c_void_p(); cnt = C.c_uint32()
+                bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
+                ids = np.asarray(tri_ids, np.uint32)
+                rc = lib.atns_build_blas(L.ptr(pos), L.ptr(tris), L.ptr(ids), num, C.byref(out), C.byref(cnt), bmin, bmax)
+                if rc != 0:
+                    raise RuntimeError("atns_build_blas failed: %d" % rc)
+                nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
+                lib.atns_free(out)
+                bmin, bmax = np.asarray(list(bmin), F32), np.asarray(list(bmax), F32)
+            obj_bbox[oid] = (bmin, bmax)
+            bvh_lists.append(nodes)
+            blas_index[oid] = len(bvh_lists) - 1
+
+        inst = []
+        for oid, o in enumerate(self.objects):
+            if o["type"] != L.OBJ_INSTANCE:
+                continue
+            objs[oid]["type"] = L.OBJ_INSTANCE
+            objs[oid]["object_id"] = o["object_id"]
+            objs[oid]["mtx_id"] = o["mtx_id"]
+            objs[oid]["light_id"] = o.get("light_id", -1)
+            bmin, bmax = obj_bbox[o["object_id"]]
+            M = self.matrices[o["mtx_id"]]
+            corners = np.array([[x, y, z, 1.0] for x in (bmin[0], bmax[0]) for y in (bmin[1], bmax[1]) for z in (bmin[2], bmax[2])], F32)
+            w = (corners @ M.T)[:, :3]
+            inst.append((oid, blas_index[o["object_id"]], w.min(0), w.max(0)))
+
+        if inst:
+            boxes = np.asarray([np.concatenate([a, b]) for (_, _, a, b) in inst], F32)
+            oids = np.asarray([i[0] for i in inst], np.int32)
+            exids = np.asarray([i[1] for i in inst], np.int32)
+            mesh_ids = np.full(len(inst), -1, np.int32)
+            out = C.c_void_p(); cnt = C.c_uint32()
+            rc = lib.atns_build_tlas(L.ptr(boxes), L.ptr(oids), L.ptr(exids), L.ptr(mesh_ids), len(inst), C.byref(out), C.byref(cnt))
+            if rc != 0:
+                raise RuntimeError("atns_build_tlas failed: %d" % rc)
+            tlas = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
+            lib.atns_free(out)
+            bvh_lists[0] = tlas
+            smin, smax = boxes[:, :3].min(0), boxes[:, 3:].max(0)
+        else:
+            raise RuntimeError("scene has no instances")
+
+        mats = np.zeros(len(self.materials), L.MATERIAL_PARAM)
+        for i, (_, m) in enumerate(self.materials):
+            mats[i] = m
+        lights = np.zeros(len(self.lights), L.LIGHT_PARAM)
+        for i, l in enumerate(self.lights):
+            lights[i] = l
+        mtx = np.asarray(self.matrices, F32).reshape(-1, 4, 4) if self.matrices else np.zeros((0, 4, 4), F32)
+
+        lists = (L.BvhList * len(bvh_lists))()
+        for i, n in enumerate(bvh_lists):
+            lists[i].nodes = n.ctypes.data
+            lists[i].count = len(n)
+        texd = (L.TextureDesc * max(1, len(self.textures)))()
+        for i, (_, t) in enumerate(self.textures):
+            texd[i].texels = t.ctypes.data
+            texd[i].height, texd[i].width = t.shape[0], t.shape[1]
+
+        d = fs.desc
+        d.objects, d.n_objects = L.ptr(objs), len(objs)
+        d.matrices, d.n_matrices = L.ptr(mtx), len(mtx)
+        d.materials, d.n_materials = L.ptr(mats), len(mats)
+        d.lights, d.n_lights = L.ptr(lights), len(lights)
+        d.triangles, d.n_triangles = L.ptr(tris), len(tris)
+        d.vtx_pos, d.vtx_nml, d.n_vertices = L.ptr(pos), L.ptr(nml), len(pos)
+        d.bvh_lists, d.n_bvh_lists = C.addressof(lists), len(bvh_lists)
+        d.textures, d.n_textures = C.addressof(texd), len(self.textures)
+        d.config = self.config
+        d.scene_bbox_min[:] = [float(x) for x in smin]
+        d.scene_bbox_max[:] = [float(x) for x in smax]
+        fs.keep = [objs, mtx, mats, lights, tris, pos, nml, bvh_lists, lists, texd, [t for _, t in self.textures]]
+        fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lights, triangles=tris,
+                         vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, textures=[t for _, t in self.textures])
+        fs.names = dict(materials=[n for n, _ in self.materials], textures=[n for n, _ in self.textures])
+        return fs
+
+
+def _resolve_case(path):
+    """Case-insensitive file lookup (sponza.mtl names SP_LUK.JPG, the file is sp_luk.JPG)."""
+    if os.path.exists(path):
+        return path
+    d, f = os.path.dirname(path) or ".", os.path.basename(path)
+    if not os.path.isdir(d):
+        return None
+    for e in os.listdir(d):
+        if e.lower() == f.lower():
+            return os.path.join(d, e)
+    return None
+
+
+def read_sbvh(path):
+    """SbvhFileHeader + voxel-material table + ThreadedSbvhNode[] (accelerator/sbvh.cpp:1220-1235,1345-1400)."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    magic, ver, node_num, max_depth, cnt_mtrl = struct.unpack_from("<4sIIII", buf, 0)
+    box = struct.unpack_from("<6f", buf, 20)
+    off = 44
+    if magic != b"SBVH":
+        raise ValueError("not an SBVH file: %r" % magic)
+    names = {}
+    for _ in range(cnt_mtrl):
+        mid, ln = struct.unpack_from("<ii", buf, off)
+        off += 8
+        names[mid] = buf[off:off + ln].split(b"\0")[0].decode()
+        off += ln
+    nodes = np.frombuffer(buf, L.BVH_NODE, count=node_num, offset=off).copy()
+    assert off + node_num * 48 == len(buf), "trailing bytes in sbvh file"
+    hdr = dict(version=ver, nodeNum=node_num, maxDepth=max_depth, boxmin=box[:3], boxmax=box[3:])
+    return hdr, names, nodes

@@ -1,0 +1,137 @@
+/*
+ * aten_amd.h -- C-ABI of the MI355X path-tracing integrator (libaten_amd.so).
+ *
+ * Drop-in boundary: these entry points take exactly the flat arrays that aten's existing GPU
+ * seam, idaten::Renderer (src/libidaten/kernel/renderer.h:17-179 of the reference), extracts
+ * from aten::context, and perform what idaten::PathTracing does with them -- but with the
+ * sample stream and semantics of the CPU renderer aten::PathTracing (the parity target).
+ * INTEGRATION.md shows the C++ adapter an aten application adds.
+ *
+ * All functions return 0 on success or a negative atn_status; they never throw.  A context is
+ * not thread-safe (the reference's renderer objects are single-threaded, one per window thread);
+ * distinct contexts are independent.  The library fails loudly (ATN_ERR_NO_DEVICE) when no HIP
+ * device is present: there is no CPU fallback.
+ */
+#ifndef ATEN_AMD_H_
+#define ATEN_AMD_H_
+
+#include "aten_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct atn_ctx atn_ctx;
+
+typedef enum atn_status {
+    ATN_OK = 0,
+    ATN_ERR_INVALID_ARG = -1,
+    ATN_ERR_NO_DEVICE = -2,
+    ATN_ERR_HIP = -3,
+    ATN_ERR_NO_SCENE = -4,
+    ATN_ERR_UNSUPPORTED = -5,
+    ATN_ERR_OUT_OF_MEMORY = -6
+} atn_status;
+
+/* aten::Destination (src/libaten/renderer/renderer.h:15-23) plus what the reference keeps as
+ * renderer state: the frame counter (renderer.h:31-39,71; CPU starts at 0, CUDA at 1) and the
+ * film flavour (Film vs FilmProgressive, src/libaten/renderer/film.cpp:33-71). */
+typedef struct atn_destination {
+    int32_t width;
+    int32_t height;
+    int32_t maxDepth;
+    int32_t russianRouletteDepth;
+    int32_t sample;                 /* samples per pixel this frame */
+    uint32_t frame;                 /* aten::Renderer::GetFrameCount() */
+    int32_t progressive;            /* 1 = FilmProgressive::put running mean, 0 = Film::put overwrite */
+    int32_t break_on_terminate;     /* 1 = reproduce pathtracing.cpp:350-352 (stop sampling a pixel after a
+                                       terminated path; the CPU renderer's behaviour), 0 = take all samples */
+    int32_t count_stats;            /* 1 = count rays / node visits / triangle tests (slower; atn_get_stats) */
+    int32_t profile;                /* 1 = bracket every launch with HIP events (atn_get_kernel_times) */
+} atn_destination;
+
+/* ≙ idaten::Renderer construction + cudaSetDevice.  device_ordinal: HIP device index. */
+int atn_create(atn_ctx** out, int device_ordinal);
+void atn_destroy(atn_ctx* ctx);
+const char* atn_last_error(atn_ctx* ctx);
+
+/* ≙ idaten::Renderer::UpdateSceneData (src/libidaten/kernel/renderer.cpp:12-131): copies the
+ * scene to HBM (and re-lays-out the BVH).  The caller keeps ownership of `scene`. */
+int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene);
+
+/* ≙ idaten::Renderer::updateCamera (renderer.cpp:202-205). */
+int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
+
+/* ≙ aten::initSampler(width, height, seed) (src/libaten/sampler/sampler.cpp:8-18) followed by
+ * idaten::PathTracing::initSamplerParameter's upload of aten::getRandom()
+ * (src/libidaten/kernel/renderer.h:113-124): one std::mt19937(seed) draw per pixel. */
+int atn_init_sampler(atn_ctx* ctx, int32_t width, int32_t height, int32_t seed);
+/* Same, with caller-provided seeds (aten::getRandom()). */
+int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n);
+
+/* Screen-space sharding for multi-GPU: the image is cut into 8x8-pixel tiles, tile t (row-major)
+ * is rendered by rank t % world.  Default (0, 1) = whole image.  No reference analogue (the
+ * reference is single-GPU). */
+int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world);
+
+/* ≙ idaten::PathTracing::render(width, height, maxSamples, maxBounce)
+ * (src/libidaten/kernel/pathtracing.cpp:49-153) with aten::PathTracing::OnRender's semantics
+ * (src/libaten/renderer/pathtracing/pathtracing.cpp:269-366).
+ * out_host: optional vec4[width*height], row 0 = bottom (like aten::Film); NULL = stay on device. */
+int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host);
+
+/* ≙ idaten::Renderer::reset (renderer.h:40-43): clears the progressive film. */
+int atn_reset(atn_ctx* ctx);
+
+/* Device-side results of the last atn_render (valid until the next call on ctx). */
+void* atn_film_device(atn_ctx* ctx);            /* float4[width*height]; only this rank's pixels are written */
+void* atn_tile_device(atn_ctx* ctx);            /* float4[atn_tile_slots]: this rank's pixels in slot order */
+uint32_t atn_tile_slots(atn_ctx* ctx);          /* identical on every rank: ceil(n_tiles / world) * 64 */
+void* atn_stream(atn_ctx* ctx);                 /* hipStream_t all work is enqueued on */
+int atn_synchronize(atn_ctx* ctx);
+
+/* Scatter an all-gathered tile buffer (rank-major, world * atn_tile_slots float4, device memory)
+ * into film_dev_out (float4[width*height], device memory; NULL = the context's own film). */
+int atn_assemble_tiles(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out);
+int atn_download_film(atn_ctx* ctx, atn_vec4* out_host);
+
+/* Counters of the last atn_render with count_stats = 1:
+ * {closest rays, shadow rays, shaded hits, closest node visits, closest triangle tests,
+ *  shadow node visits, shadow triangle tests, 0}. */
+int atn_get_stats(atn_ctx* ctx, uint64_t out[8]);
+
+/* Kernel classes for atn_get_kernel_times. */
+enum { ATN_K_GEN = 0, ATN_K_TRACE_CLOSEST = 1, ATN_K_SHADE = 2, ATN_K_TRACE_SHADOW = 3,
+       ATN_K_ACCUM = 4, ATN_K_GATHER = 5, ATN_K_COUNT = 6 };
+/* HIP-event time (ms) and launch count per kernel class, accumulated over every atn_render with
+ * profile = 1 since the last atn_reset_kernel_times. */
+int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT]);
+int atn_reset_kernel_times(atn_ctx* ctx);
+
+/* ---- stage entry points (parity tests; each mirrors one reference function) ---------------- */
+/* GeneratePath for every pixel (src/libaten/renderer/pathtracing/pathtracing_impl.h:65-110). */
+int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t sample, uint32_t frame, atn_ray* out_host);
+/* ThreadedBvhTraverser::Traverse<Closest> (src/libaten/accelerator/threaded_bvh_traverser.h:98-304).
+ * stats_out (optional): {node visits, triangle tests}. */
+int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float t_min, float t_max,
+                      atn_intersection* out_host, uint64_t* stats_out);
+/* n successive CMJ::nextSample() (src/libaten/sampler/cmj.h:32-37). */
+int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t scramble, int32_t n, float* out_host);
+/* material::sampleMaterial / samplePDF / sampleBSDF tables (src/libaten/material/material_impl.h:24-206).
+ * out_sample: n*7 {dir, bsdf, pdf}; out_eval: n*5 {samplePDF, sampleBSDF.bsdf, sampleBSDF.pdf} at wo = dir. */
+int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
+                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                       float* out_sample, float* out_eval);
+/* Stable compaction of indices with flag > 0 (contract of idaten::StreamCompaction::compact,
+ * src/libidaten/kernel/StreamCompaction.cu:175-316). */
+int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* out_idx_host, uint32_t* out_count);
+
+/* ABI self-description for binding checks. */
+uint32_t atn_sizeof_scene_desc(void);
+uint32_t atn_sizeof_destination(void);
+uint32_t atn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATEN_AMD_H_ */

@@ -1,0 +1,199 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * C entry points (ctypes) over the CPU restatement in orc_*.h.  Loaded only by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by aten_amd/.
+ * Parity status: see orc_core.h header ("parity unpinned" except the three reference KATs).
+ */
+#include "orc_pt.h"
+#include <cstdio>
+#include <omp.h>
+
+using namespace orc;
+
+extern "C" {
+
+// aten::initSampler, sampler/sampler.cpp:8-18
+void orc_init_sampler(uint32_t* out, int w, int h, int seed)
+{
+    std::vector<uint32_t> s;
+    init_sampler(s, w, h, seed);
+    std::memcpy(out, s.data(), s.size() * 4);
+}
+
+// n successive CMJ::nextSample() values after init(index, dimension, scramble)
+void orc_cmj_samples(uint32_t index, uint32_t dimension, uint32_t scramble, int n, float* out)
+{
+    CMJ c; c.init(index, dimension, scramble);
+    for (int i = 0; i < n; i++) out[i] = c.nextSample();
+}
+
+void orc_create_camera(atn_camera_param* out, const float* origin, const float* lookat, const float* up,
+    float vfov, float z_near, float z_far, int32_t width, int32_t height)
+{
+    *out = CreateCameraParam(ld3(origin), ld3(lookat), ld3(up), vfov, z_near, z_far, width, height);
+}
+
+float orc_pixel_width_at_distance(const atn_camera_param* cam, float dist)
+{
+    return ComputePixelWidthAtDistance(*cam, dist);
+}
+
+void orc_ray_offset(const float* o, const float* n, int count, float* out)
+{
+    for (int i = 0; i < count; i++) {
+        v3 r = Ray::Offset(ld3(o + 3 * i), ld3(n + 3 * i));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+
+// GeneratePath for every pixel of a w x h image (sample index `sample`, frame `frame`).
+void orc_generate_paths(const atn_camera_param* cam, const uint32_t* seeds, uint32_t n_seeds,
+    int w, int h, int sample, uint32_t frame, atn_ray* rays_out)
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            int idx = y * w + x;
+            PathState p; Ray r;
+            GeneratePath(r, x, y, sample, frame, p, *cam, seeds[idx % n_seeds]);
+            atn_ray& o = rays_out[idx];
+            o.org[0] = r.org.x; o.org[1] = r.org.y; o.org[2] = r.org.z;
+            o.dir[0] = r.dir.x; o.dir[1] = r.dir.y; o.dir[2] = r.dir.z;
+        }
+    }
+}
+
+// Traverse<Closest> for a batch of rays.  stats_out = {node visits, triangle tests} (may be null)
+void orc_trace_closest(const atn_scene_desc* scene, const atn_ray* rays, uint32_t n,
+    float t_min, float t_max, atn_intersection* out, uint64_t* stats_out)
+{
+    Scene ctxt(scene);
+    uint64_t nodes = 0, tris = 0;
+#pragma omp parallel for reduction(+:nodes,tris)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        Ray r; r.org = ld3(rays[i].org); r.dir = ld3(rays[i].dir);
+        Isect is; TraverseStats st;
+        TraverseClosest(is, ctxt, r, t_min, t_max, &st);
+        nodes += st.nodes; tris += st.tris;
+        atn_intersection& o = out[i];
+        o.t = is.t; o.objid = is.objid; o.mtrlid = is.mtrlid; o.meshid = is.meshid;
+        o.tri_id = is.tri_id; o.a = is.a; o.b = is.b; o.isVoxel = is.isVoxel;
+    }
+    if (stats_out) { stats_out[0] = nodes; stats_out[1] = tris; }
+}
+
+// evaluate_hit_result for a batch of (ray, intersection): out = {p.xyz, area, n.xyz, u, v} (9 floats)
+void orc_evaluate_hits(const atn_scene_desc* scene, const atn_ray* rays, const atn_intersection* isects,
+    uint32_t n, float* out)
+{
+    Scene ctxt(scene);
+    for (uint32_t i = 0; i < n; i++) {
+        Isect is; is.t = isects[i].t; is.objid = isects[i].objid; is.mtrlid = isects[i].mtrlid;
+        is.meshid = isects[i].meshid; is.tri_id = isects[i].tri_id; is.a = isects[i].a; is.b = isects[i].b;
+        float* o = out + 9 * i;
+        if (is.objid < 0) { for (int k = 0; k < 9; k++) o[k] = 0; continue; }
+        Ray r; r.org = ld3(rays[i].org); r.dir = ld3(rays[i].dir);
+        HitRec rec;
+        evaluate_hit_result(rec, ctxt.GetObject(is.objid), ctxt, r, is);
+        o[0] = rec.p.x; o[1] = rec.p.y; o[2] = rec.p.z; o[3] = rec.area;
+        o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z; o[7] = rec.u; o[8] = rec.v;
+    }
+}
+
+// BSDF tables.  For case i: normal n[i], incoming wi[i], sampler (index[i], dimension 0, scramble[i]),
+// uv[i].  out_sample = {dir.xyz, bsdf.xyz, pdf} ; then pdf/bsdf re-evaluated at wo = sampled dir:
+// out_eval = {samplePDF, sampleBSDF.bsdf.xyz, sampleBSDF.pdf}.
+void orc_material_table(const atn_scene_desc* scene, int32_t mtrl_id, uint32_t n,
+    const float* nrm, const float* wi, const uint32_t* index, const uint32_t* scramble, const float* uv,
+    float* out_sample, float* out_eval)
+{
+    Scene ctxt(scene);
+    atn_material_param m;
+    FillMaterial(m, ctxt, mtrl_id);
+    for (uint32_t i = 0; i < n; i++) {
+        CMJ s; s.init(index[i], 0, scramble[i]);
+        MaterialSampling ms;
+        v3 N = ld3(nrm + 3 * i), WI = ld3(wi + 3 * i);
+        sampleMaterial(&ms, ctxt, &m, N, WI, &s, uv[2 * i], uv[2 * i + 1]);
+        float* o = out_sample + 7 * i;
+        o[0] = ms.dir.x; o[1] = ms.dir.y; o[2] = ms.dir.z;
+        o[3] = ms.bsdf.x; o[4] = ms.bsdf.y; o[5] = ms.bsdf.z; o[6] = ms.pdf;
+        float p = samplePDF(ctxt, &m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+        MaterialSampling ev = sampleBSDF(ctxt, &m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+        float* e = out_eval + 5 * i;
+        e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
+    }
+}
+
+struct orc_destination {    // aten::Destination (renderer/renderer.h:15-23) + explicit frame
+    int32_t width, height, maxDepth, russianRouletteDepth, sample;
+    uint32_t frame;
+    int32_t progressive;    // 1: FilmProgressive::put (film.cpp:61-71), 0: Film::put (film.cpp:33-45)
+    int32_t nthreads;       // OMPUtil::setThreadNum; <=0 = all
+};
+
+// aten::PathTracing::OnRender, renderer/pathtracing/pathtracing.cpp:269-366.
+// film: vec4[w*h], row 0 = bottom.  counters_out (may be null): {closest rays, shadow rays, hits,
+// node visits, triangle tests}.
+void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
+    const uint32_t* seeds, uint32_t n_seeds, const orc_destination* dst, atn_vec4* film,
+    uint64_t* counters_out)
+{
+    Scene ctxt(scene);
+    const int32_t width = dst->width, height = dst->height;
+    const uint32_t samples = (uint32_t)dst->sample;
+    int32_t maxDepth = dst->maxDepth;
+    int32_t rrDepth = dst->russianRouletteDepth;
+    if (rrDepth > maxDepth) rrDepth = maxDepth - 1;     // pathtracing.cpp:282-284
+
+    uint64_t c_closest = 0, c_shadow = 0, c_hits = 0, c_nodes = 0, c_tris = 0;
+    const bool count = counters_out != nullptr;
+    if (dst->nthreads > 0) omp_set_num_threads(dst->nthreads);
+
+#pragma omp parallel for reduction(+:c_closest,c_shadow,c_hits,c_nodes,c_tris)
+    for (int32_t y = 0; y < height; y++) {
+        for (int32_t x = 0; x < width; x++) {
+            v3 col(0); uint32_t cnt = 0;
+            int32_t idx = y * width + x;
+            PathState path;     // path_host_.Clear() zeroes contrib/attrib each frame (pt_params.h:101-119)
+            path.samples = 0;
+            Ray ray; ShadowRay shadow_ray;
+            PathCounters pc;
+            for (uint32_t i = 0; i < samples; i++) {
+                const uint32_t rnd = seeds[idx % n_seeds];
+                GeneratePath(ray, x, y, (int32_t)i, dst->frame, path, *camera, rnd);
+                path.contrib = v3(0);
+                radiance(path, ray, shadow_ray, x, y, width, height, ctxt, *camera, maxDepth, rrDepth, count ? &pc : nullptr);
+                if (isInvalidColor(path.contrib)) continue;
+                col += path.contrib;
+                cnt++;
+                if (path.is_terminated) break;          // pathtracing.cpp:350-352
+            }
+            col /= (float)cnt;
+            v4 v(col, 1);
+            atn_vec4& cur = film[idx];
+            if (dst->progressive) {
+                float n = static_cast<float>(static_cast<int32_t>(cur.w));
+                v4 c(cur.x, cur.y, cur.z, cur.w);
+                c = n * c + v;
+                float d = n + 1;
+                cur.x = c.x / d; cur.y = c.y / d; cur.z = c.z / d;
+                cur.w = n + 1;
+            }
+            else {
+                cur.x = v.x; cur.y = v.y; cur.z = v.z; cur.w = v.w;
+            }
+            c_closest += pc.closest_rays; c_shadow += pc.shadow_rays; c_hits += pc.hits;
+            c_nodes += pc.trav.nodes; c_tris += pc.trav.tris;
+        }
+    }
+    if (counters_out) {
+        counters_out[0] = c_closest; counters_out[1] = c_shadow; counters_out[2] = c_hits;
+        counters_out[3] = c_nodes; counters_out[4] = c_tris;
+    }
+}
+
+int orc_num_procs() { return omp_get_num_procs(); }
+
+} // extern "C"

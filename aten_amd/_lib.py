@@ -33,7 +33,7 @@ class Destination(C.Structure):
 def lib():
     global _lib
     if _lib is None:
-        path = build.HIP_LIB
+        path = os.environ.get("ATEN_AMD_LIB", build.HIP_LIB)    # override: kernel-variant experiments (tools/)
         if not os.path.exists(path):
             raise RuntimeError(
                 "aten_amd: %s is missing. Build it with `python -m aten_amd.build hip` "

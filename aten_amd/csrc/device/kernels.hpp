@@ -34,6 +34,8 @@ struct PathBuffers {
     uint32_t* shadow_q; // slots with an active shadow ray this bounce
     uint32_t* q_count;  // [maxDepth + 1] live count entering bounce b
     uint32_t* sh_count; // [maxDepth]
+    uint32_t* fetch_closest;    // [maxDepth] dynamic job-fetch cursors of the trace kernels
+    uint32_t* fetch_shadow;     // [maxDepth]
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
 };
 
@@ -176,25 +178,50 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
     }
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_closest(PathBuffers pb, DevScene sc, int32_t bounce)
+#ifndef ATN_TRACE_WAVES
+#define ATN_TRACE_WAVES 1
+#endif
+// REFILL selects the persistent, lane-refilling walk (large trees) or the plain grid-stride walk
+// (small trees, where the refill bookkeeping costs more than the idle lanes it removes).
+template <bool COUNT, bool REFILL, class Job>
+ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc)
 {
-    const uint32_t count = pb.q_count[bounce];
-    const uint32_t* __restrict__ q = pb.queue[bounce & 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
-    uint32_t nrays = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    if constexpr (REFILL) {
+        __shared__ TraceShared sh;
+        trace_refill<COUNT>(sc, sh, count, fetch_counter, job, tc);
+    }
+    else {
+        trace_simple<COUNT>(sc, count, job, tc);
+    }
+}
+
+struct ClosestJob {
+    PathBuffers pb;
+    const uint32_t* __restrict__ q;
+    float t_min;
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    {
         const uint32_t slot = q[j];
         const float4 ro = pb.ray_o[slot], rd = pb.ray_d[slot];
-        Hit h;
-        traverse_closest<COUNT>(h, sc, mk3(ro), mk3(rd), kEps, kInf, &tc);
+        a = make_float4(ro.x, ro.y, ro.z, kInf);
+        b = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
+    }
+    ATN_DEV void finish(uint32_t slot, const Hit& h, bool) const
+    {
         pb.isect[slot] = make_float4(h.t, h.a, h.b, __int_as_float(h.tri));
         pb.isect2[slot] = make_int2(h.objid, h.meshid);
-        nrays++;
     }
+};
+
+template <bool COUNT, bool REFILL>
+__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_closest(PathBuffers pb, DevScene sc, int32_t bounce)
+{
+    const uint32_t count = pb.q_count[bounce];
+    const ClosestJob job{ pb, pb.queue[bounce & 1], kEps };
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_closest[bounce], job, &tc);
     if (COUNT) {
-        wave_add_stat(&pb.stats[0], nrays);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[0], (unsigned long long)count);
         wave_add_stat(&pb.stats[3], tc.nodes);
         wave_add_stat(&pb.stats[4], tc.tris);
     }
@@ -392,38 +419,49 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 // HitShadowRay -> HitTestToTargetLight -> scene::hitLight
 // (pathtracing_impl.h:266-393, scene/scene.h:64-134): closest hit toward the light, visible iff
 // the hit object IS the light object (or nothing is hit / infinite / singular rules).
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
-{
-    const uint32_t count = pb.sh_count[bounce];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
-    uint32_t nrays = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+struct ShadowJob {
+    PathBuffers pb;
+    DevScene sc;
+    float t_min;
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    {
         const uint32_t slot = pb.shadow_q[j];
         const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
-        const float distToLight = so.w;
-        const int32_t li = __float_as_int(sd.w);
-        const atn_light_param lp = sc.lights[li];
         const f3 dir = normalize(mk3(sd));      // aten::ray(org, dir) constructor re-normalises (pathtracing_impl.h:380)
-        Hit h;
-        const bool isHit = traverse_closest<COUNT>(h, sc, mk3(so), dir, kEps, distToLight - kEps, &tc);
-        const int32_t lightobj = (lp.type == ATN_LIGHT_AREA && lp.arealight_objid >= 0) ? lp.arealight_objid : -1;
+        a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)
+        b = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
+    }
+    ATN_DEV void finish(uint32_t slot, const Hit& h, bool isHit) const
+    {
+        const float distToLight = pb.sh_o[slot].w;
+        const int32_t li = __float_as_int(pb.sh_d[slot].w);
+        const atn_light_param* lp = &sc.lights[li];
+        const int32_t ltype = lp->type, lobj = lp->arealight_objid;
+        const uint32_t lattr = lp->attrib;
+        const int32_t lightobj = (ltype == ATN_LIGHT_AREA && lobj >= 0) ? lobj : -1;
         const int32_t hitobj = isHit ? h.objid : lightobj;
         bool visible;
         if (hitobj == lightobj) visible = true;
-        else if (lp.attrib & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
-        else if (lp.attrib & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
+        else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
+        else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
         else visible = false;
         if (visible) {
             const float4 c = pb.contrib[slot];
             const float4 lc = pb.sh_c[slot];
             pb.contrib[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
         }
-        nrays++;
     }
+};
+
+template <bool COUNT, bool REFILL>
+__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
+{
+    const uint32_t count = pb.sh_count[bounce];
+    const ShadowJob job{ pb, sc, kEps };
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_shadow[bounce], job, &tc);
     if (COUNT) {
-        wave_add_stat(&pb.stats[1], nrays);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[1], (unsigned long long)count);
         wave_add_stat(&pb.stats[5], tc.nodes);
         wave_add_stat(&pb.stats[6], tc.tris);
     }
@@ -493,17 +531,19 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(const float4* __restrict
 }
 
 // ---- stage kernels used by the parity tests through the C-ABI --------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_batch(DevScene sc, const atn_ray* __restrict__ rays, uint32_t n,
-                                                     float t_min, float t_max, atn_intersection* out,
-                                                     unsigned long long* stats)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
-    if (i < n) {
-        const atn_ray r = rays[i];
-        Hit h;
-        traverse_closest<COUNT>(h, sc, mk3(r.org[0], r.org[1], r.org[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), t_min, t_max, &tc);
+struct BatchJob {
+    DevScene sc;
+    const atn_ray* __restrict__ rays;
+    atn_intersection* out;
+    float t_min, t_max;
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    {
+        const atn_ray r = rays[j];
+        a = make_float4(r.org[0], r.org[1], r.org[2], t_max);
+        b = make_float4(r.dir[0], r.dir[1], r.dir[2], __uint_as_float(j));
+    }
+    ATN_DEV void finish(uint32_t j, const Hit& h, bool) const
+    {
         atn_intersection o;
         o.t = h.t; o.objid = h.objid; o.tri_id = h.tri; o.a = h.a; o.b = h.b; o.isVoxel = 0;
         o.mtrlid = -1; o.meshid = -1;
@@ -512,8 +552,19 @@ __global__ void __launch_bounds__(256) k_trace_batch(DevScene sc, const atn_ray*
             o.mtrlid = tp.mtrlid;
             o.meshid = tp.mesh_id < 0 ? h.meshid : tp.mesh_id;     // threaded_bvh_traverser.h:206-209
         }
-        out[i] = o;
+        out[j] = o;
     }
+};
+
+// The renderer's traversal core over caller-provided rays (parity probe, atn_trace_closest).
+template <bool COUNT, bool REFILL>
+__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_batch(DevScene sc, const atn_ray* __restrict__ rays, uint32_t n,
+                                                     float t_min, float t_max, atn_intersection* out,
+                                                     unsigned long long* stats)
+{
+    const BatchJob job{ sc, rays, out, t_min, t_max };
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    trace_dispatch<COUNT, REFILL>(sc, n, reinterpret_cast<uint32_t*>(&stats[7]), job, &tc);     // stats[7]: zeroed fetch cursor
     if (COUNT) { wave_add_stat(&stats[3], tc.nodes); wave_add_stat(&stats[4], tc.tris); }
 }
 

@@ -9,24 +9,30 @@ namespace atn {
 // One 48-byte record per BVH node, all node lists concatenated into a single array with ABSOLUTE
 // indices, each list re-laid-out in walk (pre-)order so that an inner node's hit link is always
 // index + 1.  The walk order -- and therefore every hit/miss decision -- is exactly the
-// reference's (threaded_bvh_traverser.h:98-304); only the storage differs:
+// reference's (threaded_bvh_traverser.h:98-304); only the storage differs.
 //
-//   q0.w = tag:  -1 inner | >= 0 triangle leaf (value = triangle id) | -2 TLAS leaf with nested
-//                tree | -3 TLAS leaf without one (sphere: never tested)
-//   inner    : q0 = {boxmin.xyz, -1}        q1 = {boxmax.xyz, miss}
-//   tri leaf : q0 = {v0.xyz, triid}         q1 = {e1.xyz, next}      q2 = {e2.xyz, 0}
+// Links are int32 bit patterns: kLinkEnd (-1) = leave this list; otherwise the BYTE offset of the
+// target record in `nodes` (a multiple of 16) with the target's type in the low bits:
+// kLinkLeafBit = triangle leaf, kLinkTlasBit = TLAS leaf with a nested tree, 0 = inner node.
+//
+//   inner    : q0 = {boxmin.xyz, tag}       q1 = {boxmax.xyz, miss link}
+//              tag (int bits) = type bits of the NEXT record (offset + 48), i.e. of the implicit hit link
+//   tri leaf : q0 = {v0.xyz, triangle id}   q1 = {e1.xyz, next link}   q2 = {e2.xyz, 0}
 //              (v0, e1 = v1 - v0, e2 = v2 - v0 of the leaf's triangle: the three dependent
 //               gathers node -> TriangleParameter -> 3 vertices become one 48-byte read;
 //               e1/e2 are the same IEEE subtractions intersectTriangle performs, done at upload)
-//   TLAS leaf: q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), blas_root, -2}
-//              q1 = {meshid, top_hit, top_miss, 0}     (ints stored as bit patterns)
-struct DevNodes {
-    const float4* q;
-};
-
-constexpr float kTagInner = -1.0F;
-constexpr float kTagTlasNested = -2.0F;
-constexpr float kTagTlasDead = -3.0F;
+//   TLAS leaf: q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), BLAS root link, 0}
+//              q1 = {meshid, top hit link, top miss link, 0}
+//   dead leaf: a leaf with neither triangle nor nested tree (sphere instance: never tested on this
+//              path); typed as an inner record whose tag is kTagDead: always "miss".
+//              q0 = {0,0,0, kTagDead}      q1 = {0,0,0, miss link}
+constexpr int32_t kLinkEnd = -1;
+constexpr int32_t kLinkLeafBit = 1;
+constexpr int32_t kLinkTlasBit = 2;
+constexpr int32_t kLinkTypeMask = 3;
+constexpr uint32_t kLinkOffsetMask = ~15u;
+constexpr uint32_t kNodeBytes = 48;
+constexpr int32_t kTagDead = 8;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
 struct DevMaterial {
@@ -70,6 +76,7 @@ struct DevScene {
     float avgIllum;
     float multiplyer;
     int32_t enable_env_map;
+    int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
 };
 

@@ -1,8 +1,19 @@
-// Stackless two-level (TLAS -> BLAS) hit/miss-link walk + Moeller-Trumbore, one ray per lane.
-// Decision-for-decision the walk of aten::ThreadedBvhTraverser<true>::Traverse<Closest>
+// Stackless two-level (TLAS -> BLAS) hit/miss-link walk + Moeller-Trumbore.
+//
+// Per ray this is decision-for-decision the walk of
+// aten::ThreadedBvhTraverser<true>::Traverse<Closest>
 // (src/libaten/accelerator/threaded_bvh_traverser.h:98-304) over the device node records of
 // scene_dev.hpp; box test = aabb::hit (src/libaten/math/aabb.h:62-86), triangle test =
 // intersectTriangle (src/libaten/math/intersect.h:45-90) + triangle::hit (geometry/triangle.h:40-67).
+//
+// The trace kernels are bound by wave-level VALU issue and vector-memory instruction count, not by
+// bytes (rocprof), so the loop is written to issue as little as possible:
+//   * links are byte offsets with the target's node type in the low bits: no index arithmetic, no
+//     float<->int conversion, and the loads use a scalar base + 32-bit vector offset;
+//   * the two 16-byte halves every node kind needs are loaded once, before the type branch;
+//   * hardware min/max for the slab test whenever the ray's 1/dir is finite (see slab_hit_fast);
+//   * the world-space slab constants are kept, so leaving a nested tree costs moves, not divides.
+// None of this changes a ray's own operation sequence, so results stay bit-identical.
 #pragma once
 #include "scene_dev.hpp"
 
@@ -20,16 +31,23 @@ struct TravCounters { uint32_t nodes, tris; };
 
 // Per-ray constants of aabb::hit: invdir = 1 / (dir + 1e-6), oxinvdir = -org * invdir.
 // The reference recomputes them at every node from the same inputs; hoisting is value-identical.
-struct RaySlab { f3 org, dir, invdir, oxinvdir; };
+struct RaySlab { f3 org, dir, invdir, oxinvdir; bool finite; };
+
+ATN_DEV bool is_finite3(const f3& v)
+{
+    return (fabsf(v.x) <= kInf) && (fabsf(v.y) <= kInf) && (fabsf(v.z) <= kInf);   // false for NaN and inf
+}
 
 ATN_DEV void slab_setup(RaySlab& s, const f3& org, const f3& dir)
 {
     s.org = org; s.dir = dir;
     s.invdir = 1.0F / (dir + 1e-6F);
     s.oxinvdir = (-org) * s.invdir;
+    s.finite = is_finite3(s.invdir) && is_finite3(s.oxinvdir);
 }
 
-ATN_DEV bool slab_hit(const RaySlab& s, const f3& bmin, const f3& bmax, float t_min, float t_max)
+// aabb::hit with the host's std::max / std::min (select form: NaN-sensitive, math.h:148-180).
+ATN_DEV bool slab_hit_exact(const RaySlab& s, const f3& bmin, const f3& bmax, float t_min, float t_max)
 {
     const f3 f = bmax * s.invdir + s.oxinvdir;
     const f3 n = bmin * s.invdir + s.oxinvdir;
@@ -40,95 +58,279 @@ ATN_DEV bool slab_hit(const RaySlab& s, const f3& bmin, const f3& bmax, float t_
     return t0 <= t1;
 }
 
-template <bool COUNT>
-ATN_DEV bool traverse_closest(Hit& hit, const DevScene& sc, const f3& org, const f3& dir,
-                              float t_min, float t_max, TravCounters* cnt)
+// Same test with hardware min/max.  With finite invdir / oxinvdir and finite boxes no NaN can
+// arise (finite * finite + finite is finite or +-inf), and for non-NaN operands v_max/v_min equal
+// the select form except for the sign of a zero, which `t0 <= t1` cannot see.
+ATN_DEV bool slab_hit_fast(const RaySlab& s, const f3& bmin, const f3& bmax, float t_min, float t_max)
 {
-    t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : t_min;
+    const f3 f = bmax * s.invdir + s.oxinvdir;
+    const f3 n = bmin * s.invdir + s.oxinvdir;
+    const float t1 = fminf(fminf(fminf(fmaxf(f.x, n.x), fmaxf(f.y, n.y)), fmaxf(f.z, n.z)), t_max);
+    const float t0 = fmaxf(fmaxf(fmaxf(fminf(f.x, n.x), fminf(f.y, n.y)), fminf(f.z, n.z)), t_min);
+    return t0 <= t1;
+}
 
-    hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
+constexpr int kTraceBlock = 256;
 
-    RaySlab ray;
-    slab_setup(ray, org, dir);
+ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const float4*>(base + byte_off);
+}
 
-    int32_t nodeid = 0;
-    int32_t objid = -1, meshid = -1;
-    int32_t top_hit = -1, top_miss = -1;
-    const float4* __restrict__ nodes = sc.nodes;
+// Job interface (all jobs of a launch share t_min):
+//   float t_min
+//   void fetch(uint32_t j, float4& a, float4& b)   a = {org.xyz, t_max}, b = {dir.xyz, payload bits}
+//   void finish(uint32_t payload, const Hit& h, bool is_hit)
+// One ray per lane for the lifetime of its walk; grid-stride over the jobs.
+template <bool COUNT, class Job>
+ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
+{
+    const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
+    const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        float4 a, b;
+        job.fetch(j, a, b);
+        float t_max = a.w;
+        const uint32_t payload = __float_as_uint(b.w);
+        RaySlab wray, ray;
+        slab_setup(wray, mk3(a), mk3(b));
+        ray = wray;
+        Hit hit; hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
+        int32_t node = sc.root_link, objid = -1, meshid = -1, top_hit = kLinkEnd, top_miss = kLinkEnd;
 
-    while (nodeid >= 0) {
-        const float4 q0 = nodes[3 * nodeid + 0];
-        const float4 q1 = nodes[3 * nodeid + 1];
-        if (COUNT) cnt->nodes++;
-        bool is_hit;
-        int32_t next_hit, next_miss;
-
-        if (q0.w == kTagInner) {
-            is_hit = slab_hit(ray, mk3(q0), mk3(q1), t_min, t_max);
-            next_hit = nodeid + 1;
-            next_miss = (int32_t)q1.w;
-        }
-        else if (q0.w >= 0.0F) {
-            // triangle leaf: v0, e1, e2 embedded
-            const float4 q2 = nodes[3 * nodeid + 2];
-            if (COUNT) cnt->tris++;
-            const f3 e1 = mk3(q1), e2 = mk3(q2);
-            const f3 r = ray.org - mk3(q0);
-            const f3 u = cross(ray.dir, e2);
-            const f3 v = cross(r, e1);
-            const float inv = 1.0F / dot(u, e1);
-            const float t = dot(v, e2) * inv;
-            const float beta = dot(u, r) * inv;
-            const float gamma = dot(v, ray.dir) * inv;
-            const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
-                && (beta + gamma <= 1.0F) && t >= 0.0F);
-            is_hit = isect && (t < kInf);                       // triangle::hit against isect_tmp.t = INF
-            const bool accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
-            if (accept) {
-                hit.t = t; hit.a = beta; hit.b = gamma;
-                hit.objid = objid; hit.tri = (int32_t)q0.w; hit.meshid = meshid;
-                t_max = t;
+        while (node != kLinkEnd) {
+            const uint32_t off = (uint32_t)node & kLinkOffsetMask;
+            const float4 q0 = ld16(nb, off);
+            const float4 q1 = ld16(nb, off + 16u);
+            if (COUNT) cnt->nodes++;
+            bool is_hit;
+            if (!(node & kLinkTypeMask)) {
+                // inner node (or a leaf with nothing to test: its tag makes the slab result irrelevant)
+                is_hit = ray.finite ? slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max)
+                                    : slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
+                const int32_t tag = __float_as_int(q0.w);
+                const int32_t hit_link = (int32_t)(off + kNodeBytes) | tag;       // tag = type bits of the next node
+                node = (is_hit && tag != kTagDead) ? hit_link : __float_as_int(q1.w);
+                is_hit = is_hit && tag != kTagDead;
             }
-            next_hit = next_miss = (int32_t)q1.w;
-        }
-        else if (q0.w == kTagTlasNested) {
-            objid = __float_as_int(q0.x);
-            const int32_t w2l = __float_as_int(q0.y);
-            meshid = __float_as_int(q1.x);
-            top_hit = __float_as_int(q1.y);
-            top_miss = __float_as_int(q1.z);
-            if (w2l >= 0) {
-                // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
-                m4 m;
-                m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
-                m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
-                const f3 o = m4_apply(m, org);
-                const f3 d = normalize(m4_applyXYZ(m, dir));
-                slab_setup(ray, o, d);
+            else if (node & kLinkLeafBit) {
+                const float4 q2 = ld16(nb, off + 32u);
+                if (COUNT) cnt->tris++;
+                const f3 e1 = mk3(q1), e2 = mk3(q2);
+                const f3 r = ray.org - mk3(q0);
+                const f3 u = cross(ray.dir, e2);
+                const f3 v = cross(r, e1);
+                const float inv = 1.0F / dot(u, e1);
+                const float t = dot(v, e2) * inv;
+                const float beta = dot(u, r) * inv;
+                const float gamma = dot(v, ray.dir) * inv;
+                const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
+                    && (beta + gamma <= 1.0F) && t >= 0.0F);
+                is_hit = isect && (t < kInf);                       // triangle::hit against isect_tmp.t = INF
+                const bool accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
+                if (accept) {
+                    hit.t = t; hit.a = beta; hit.b = gamma;
+                    hit.objid = objid; hit.tri = __float_as_int(q0.w); hit.meshid = meshid;
+                    t_max = t;
+                }
+                node = __float_as_int(q1.w);        // leaf: hit link == miss link
             }
             else {
-                slab_setup(ray, org, dir);
+                // TLAS leaf with a nested tree
+                objid = __float_as_int(q0.x);
+                const int32_t w2l = __float_as_int(q0.y);
+                meshid = __float_as_int(q1.x);
+                top_hit = __float_as_int(q1.y);
+                top_miss = __float_as_int(q1.z);
+                if (w2l >= 0) {
+                    // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
+                    m4 m;
+                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
+                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                    const f3 o = m4_apply(m, wray.org);
+                    const f3 d = normalize(m4_applyXYZ(m, wray.dir));
+                    slab_setup(ray, o, d);
+                }
+                else {
+                    ray = wray;
+                }
+                is_hit = true;
+                node = __float_as_int(q0.z);        // BLAS root link
             }
-            is_hit = true;
-            next_hit = __float_as_int(q0.z);    // BLAS root
-            next_miss = top_miss;
+            if (node == kLinkEnd) {
+                // leave the bottom layer (top_* are kLinkEnd inside the top layer)
+                node = is_hit ? top_hit : top_miss;
+                top_hit = kLinkEnd; top_miss = kLinkEnd;
+                ray = wray;
+            }
         }
-        else {
-            // TLAS leaf without nested tree: nothing is tested (threaded_bvh_traverser.h:146-219)
-            is_hit = false;
-            next_hit = next_miss = (int32_t)q1.w;
+        job.finish(payload, hit, hit.objid >= 0);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Same per-ray walk, but the wave is persistent: it reserves chunks of kFetchChunk jobs with one
+// atomicAdd, stages the chunk's rays in LDS with one coalesced burst, and whenever kRefillLanes
+// lanes have finished their rays it hands them new ones (ballot + popcount prefix).  Rays visit
+// very different numbers of nodes (sponza_lod: mean 56, long tail); without refill a wave idles
+// ~60 % of its lane-iterations waiting for its longest ray.
+#ifndef ATN_REFILL_LANES
+#define ATN_REFILL_LANES 16
+#endif
+constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
+#ifndef ATN_FETCH_CHUNK
+#define ATN_FETCH_CHUNK 128
+#endif
+constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
+constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
+struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; };   // 16 KB
+
+template <bool COUNT, class Job>
+ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
+                          const Job& job, TravCounters* cnt)
+{
+    const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
+    const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
+    const uint32_t lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    float4 (*stage)[2] = sh.stage[threadIdx.x >> 6];
+
+    uint32_t c_count = 0, c_next = 0;   // wave-uniform: staged chunk size / next unassigned entry
+    bool drained = false;               // wave-uniform: the global queue is empty
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    bool first_chunk = true;            // wave-uniform
+
+    uint32_t payload = 0;
+    float t_max = 0.0F;
+    RaySlab wray, ray;
+    slab_setup(wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
+    ray = wray;
+    Hit hit; hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
+    int32_t node = kLinkEnd, objid = -1, meshid = -1, top_hit = kLinkEnd, top_miss = kLinkEnd;
+    // a lane is idle <=> node == kLinkEnd
+
+    for (;;) {
+        const unsigned long long m_idle = __ballot(node == kLinkEnd);
+        const uint32_t n_idle = (uint32_t)__popcll(m_idle);
+        if (n_idle >= kRefillLanes) {
+            if (c_next >= c_count && !drained) {
+                // The first chunk of every wave is pre-assigned (chunk index = global wave id) and the shared
+                // cursor starts after those: a same-address atomic retires only every ~11 ns, so a launch that
+                // opens with one atomic per wave (5 K waves) would stall for tens of microseconds.
+                uint32_t base = 0;
+                if (first_chunk) {
+                    base = wave_id * kFetchChunk;
+                    first_chunk = false;
+                }
+                else {
+                    if (lane == 0) base = (atomicAdd(fetch_counter, 1u) + n_waves) * kFetchChunk;
+                }
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= count) { drained = true; c_count = 0; c_next = 0; }
+                else {
+                    c_count = count - base < kFetchChunk ? count - base : kFetchChunk;
+                    c_next = 0;
+#pragma unroll
+                    for (uint32_t e = 0; e < kFetchChunk; e += 64) {
+                        if (e + lane < c_count) {
+                            float4 a, b;
+                            job.fetch(base + e + lane, a, b);
+                            stage[e + lane][0] = a;
+                            stage[e + lane][1] = b;
+                        }
+                    }
+                }
+            }
+            if (c_next < c_count) {
+                const uint32_t avail = c_count - c_next;
+                if (node == kLinkEnd) {
+                    const uint32_t k = (uint32_t)__popcll(m_idle & lt);
+                    if (k < avail) {
+                        const float4 a = stage[c_next + k][0];
+                        const float4 b = stage[c_next + k][1];
+                        t_max = a.w;
+                        payload = __float_as_uint(b.w);
+                        hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
+                        slab_setup(wray, mk3(a), mk3(b));
+                        ray = wray;
+                        node = sc.root_link; objid = -1; meshid = -1; top_hit = kLinkEnd; top_miss = kLinkEnd;
+                    }
+                }
+                c_next += n_idle < avail ? n_idle : avail;
+            }
+            else if (n_idle == 64u) {
+                break;          // drained, chunk empty, nothing in flight
+            }
         }
 
-        nodeid = is_hit ? next_hit : next_miss;
-
-        if (nodeid < 0) {
-            // leave the bottom layer (or finish the top layer: top_* are -1 there)
-            nodeid = is_hit ? top_hit : top_miss;
-            top_hit = -1; top_miss = -1;
-            slab_setup(ray, org, dir);
+        const bool step = node != kLinkEnd;
+        if (step) {
+            const uint32_t off = (uint32_t)node & kLinkOffsetMask;
+            const float4 q0 = ld16(nb, off);
+            const float4 q1 = ld16(nb, off + 16u);
+            if (COUNT) cnt->nodes++;
+            bool is_hit;
+            if (!(node & kLinkTypeMask)) {
+                is_hit = ray.finite ? slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max)
+                                    : slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
+                const int32_t tag = __float_as_int(q0.w);
+                const int32_t hit_link = (int32_t)(off + kNodeBytes) | tag;
+                node = (is_hit && tag != kTagDead) ? hit_link : __float_as_int(q1.w);
+                is_hit = is_hit && tag != kTagDead;
+            }
+            else if (node & kLinkLeafBit) {
+                const float4 q2 = ld16(nb, off + 32u);
+                if (COUNT) cnt->tris++;
+                const f3 e1 = mk3(q1), e2 = mk3(q2);
+                const f3 r = ray.org - mk3(q0);
+                const f3 u = cross(ray.dir, e2);
+                const f3 v = cross(r, e1);
+                const float inv = 1.0F / dot(u, e1);
+                const float t = dot(v, e2) * inv;
+                const float beta = dot(u, r) * inv;
+                const float gamma = dot(v, ray.dir) * inv;
+                const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
+                    && (beta + gamma <= 1.0F) && t >= 0.0F);
+                is_hit = isect && (t < kInf);
+                const bool accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
+                if (accept) {
+                    hit.t = t; hit.a = beta; hit.b = gamma;
+                    hit.objid = objid; hit.tri = __float_as_int(q0.w); hit.meshid = meshid;
+                    t_max = t;
+                }
+                node = __float_as_int(q1.w);
+            }
+            else {
+                objid = __float_as_int(q0.x);
+                const int32_t w2l = __float_as_int(q0.y);
+                meshid = __float_as_int(q1.x);
+                top_hit = __float_as_int(q1.y);
+                top_miss = __float_as_int(q1.z);
+                if (w2l >= 0) {
+                    m4 m;
+                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
+                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                    const f3 o = m4_apply(m, wray.org);
+                    const f3 d = normalize(m4_applyXYZ(m, wray.dir));
+                    slab_setup(ray, o, d);
+                }
+                else {
+                    ray = wray;
+                }
+                is_hit = true;
+                node = __float_as_int(q0.z);
+            }
+            if (node == kLinkEnd) {
+                node = is_hit ? top_hit : top_miss;
+                top_hit = kLinkEnd; top_miss = kLinkEnd;
+                ray = wray;
+                if (node == kLinkEnd) job.finish(payload, hit, hit.objid >= 0);
+            }
         }
     }
-    return hit.objid >= 0;
 }
 
 } // namespace atn

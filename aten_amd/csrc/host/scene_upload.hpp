@@ -64,12 +64,22 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     if (total >= (1u << 24)) { err = "more than 2^24 BVH nodes: float-encoded links would lose precision"; return false; }
     img.nodes.assign((size_t)total * 3, make_float4(0, 0, 0, 0));
 
+    auto type_bits = [&](uint32_t k, uint32_t old_idx) -> int32_t {
+        const atn_bvh_node& n = s->bvh_lists[k].nodes[old_idx];
+        if (!(n.f0 >= 0 || n.f1 >= 0)) return 0;        // inner
+        if (n.f2 >= 0) return kLinkTlasBit;             // nested tree
+        if (n.f1 >= 0) return kLinkLeafBit;             // triangle
+        return 0;                                       // dead leaf: handled on the inner path by its tag
+    };
+    // typed link of a (list, float link): kLinkEnd, or absolute index | leaf bit; -2 = invalid
     auto remap = [&](uint32_t k, float link) -> int32_t {
         const int32_t l = (int32_t)link;
-        if (l < 0) return -1;
+        if (l < 0) return kLinkEnd;
         if ((uint32_t)l >= s->bvh_lists[k].count || new_index[k][l] < 0) return -2;
-        return (int32_t)img.list_root[k] + new_index[k][l];
+        const int32_t abs = (int32_t)img.list_root[k] + new_index[k][l];
+        return (int32_t)((uint32_t)abs * kNodeBytes) | type_bits(k, (uint32_t)l);
     };
+    if ((uint64_t)total * kNodeBytes >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
 
     // ---- pass 2: emit device records
     for (uint32_t k = 0; k < nl; k++) {
@@ -84,9 +94,9 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             if (h == -2 || m == -2) { err = "BVH link points to an unreachable node"; return false; }
             const bool leaf = (n.f0 >= 0 || n.f1 >= 0);         // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
             if (!leaf) {
-                if (h != (int32_t)abs + 1) { err = "inner node whose hit link is not the next node in walk order"; return false; }
-                q0 = make_float4(n.boxmin[0], n.boxmin[1], n.boxmin[2], kTagInner);
-                q1 = make_float4(n.boxmax[0], n.boxmax[1], n.boxmax[2], (float)m);
+                if (h == kLinkEnd || ((uint32_t)h & kLinkOffsetMask) != (abs + 1) * kNodeBytes) { err = "inner node whose hit link is not the next node in walk order"; return false; }
+                q0 = make_float4(n.boxmin[0], n.boxmin[1], n.boxmin[2], i2f(h & kLinkTypeMask));
+                q1 = make_float4(n.boxmax[0], n.boxmax[1], n.boxmax[2], i2f(m));
                 img.n_inner++;
             }
             else if (n.f2 >= 0) {
@@ -96,14 +106,15 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
                 if (objid < 0 || (uint32_t)objid >= s->n_objects) { err = "TLAS leaf object id out of range"; return false; }
                 const uint32_t bits = f2u(n.f2);
                 const int32_t exid = ATN_EXID_MAIN(bits);
-                if (exid <= 0 || (uint32_t)exid >= nl) { err = "TLAS leaf references a missing BLAS list"; return false; }
+                if (exid <= 0 || (uint32_t)exid >= nl || order[exid].empty()) { err = "TLAS leaf references a missing BLAS list"; return false; }
                 const atn_object_param& obj = s->objects[objid];
                 int32_t w2l_row = -1;
                 if (obj.mtx_id >= 0) {
                     if ((uint32_t)obj.mtx_id + 1 >= s->n_matrices) { err = "object matrix index out of range"; return false; }
                     w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
                 }
-                q0 = make_float4(i2f(objid), i2f(w2l_row), i2f((int32_t)img.list_root[exid]), kTagTlasNested);
+                const int32_t root = remap((uint32_t)exid, 0.0F);
+                q0 = make_float4(i2f(objid), i2f(w2l_row), i2f(root), 0.0F);
                 q1 = make_float4(i2f((int32_t)n.f3), i2f(h), i2f(m), 0.0F);
                 img.n_tlas_leaf++;
             }
@@ -117,15 +128,15 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
                 const atn_vec4& c = s->vtx_pos[t.idx[2]];
                 // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions intersectTriangle performs
                 // per test (math/intersect.h:61-62), hoisted to upload time.
-                q0 = make_float4(a.x, a.y, a.z, (float)tri);
-                q1 = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, (float)h);
+                q0 = make_float4(a.x, a.y, a.z, i2f((int32_t)tri));
+                q1 = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, i2f(h));
                 q2 = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0F);
                 img.n_tri_leaf++;
             }
             else {
                 // leaf without triangle or nested tree (sphere instance): never tested on this path
-                q0 = make_float4(0, 0, 0, kTagTlasDead);
-                q1 = make_float4(0, 0, 0, (float)m);
+                q0 = make_float4(0, 0, 0, i2f(kTagDead));
+                q1 = make_float4(0, 0, 0, i2f(m));
             }
         }
     }
@@ -169,6 +180,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     }
 
     DevScene& p = img.params;
+    p.root_link = remap(0, 0.0F);
     p.n_lights = (int32_t)s->n_lights; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
     p.bvh_hit_min = s->config.bvh_hit_min;
     p.bg_color[0] = s->config.bg.bg_color[0]; p.bg_color[1] = s->config.bg.bg_color[1]; p.bg_color[2] = s->config.bg.bg_color[2];

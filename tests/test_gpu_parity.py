@@ -112,6 +112,30 @@ def test_trace_random_rays_and_tmax(gpu, orc, sponza):
     assert len(gpu.trace_closest(rays[:0])) == 0
 
 
+@pytest.mark.parametrize("flavour", ["r", "s"])
+def test_trace_both_traversal_flavours(gpu, orc, cornell, sponza, golden, flavour, monkeypatch):
+    """The renderer picks the persistent lane-refilling walk for large trees and the plain grid-stride
+    walk for small ones; both must give the oracle's records and visit counts on both scenes."""
+    monkeypatch.setenv("ATEN_AMD_TRACE", flavour)       # read at UpdateSceneData
+    _setup(gpu, orc, cornell, 64, 64)
+    got, st = gpu.trace_closest(golden["rays_cornell64_f0"], stats=True)
+    assert got.tobytes() == golden["isect_cornell64"].tobytes()
+    assert np.array_equal(st, golden["isect_cornell64_stats"])
+    film = gpu.render(64, 64, 5, 3, frame=0)
+    fs, c, seeds = _setup(gpu, orc, sponza, 128, 72)
+    rays = orc.generate_paths(c, seeds, 128, 72, 0, 0)
+    got, st = gpu.trace_closest(rays, stats=True)
+    assert got.tobytes() == golden["isect_sponza128x72"].tobytes()
+    assert np.array_equal(st, golden["isect_sponza128x72_stats"])
+    film2 = gpu.render(128, 72, 5, 3, frame=0)
+    frac, mean_err = frame_tolerance_report(film2, golden["film_sponza128x72_d5_f0"])
+    assert frac >= 0.99 and mean_err <= 5e-3
+    monkeypatch.delenv("ATEN_AMD_TRACE")
+    # flavour-independent pixels: re-render Cornell with the default choice and compare exactly
+    _setup(gpu, orc, cornell, 64, 64)
+    assert np.array_equal(gpu.render(64, 64, 5, 3, frame=0), film, equal_nan=True)
+
+
 # ---- BSDF tables: few ulp (transcendentals differ between glibc and ocml) -------------------------
 @pytest.mark.parametrize("which", ["diffuse", "specular", "ggx", "disney"])
 def test_material_tables(gpu, orc, cornell, sponza_disney, which):

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collect PMC counters for bench.py in separate passes (counters only, no trace domains).
+# usage: tools/pmc_collect.sh <outdir> <passes e.g. "1 2 5 6 7"> [bench args...]
+# (a pass with TA_* counters hung the profiler on this pool and is not offered)
+set -u
+OUT=$1; shift
+PASSES=$1; shift
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+declare -A SETS
+SETS[1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+SETS[2]="SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+SETS[3]="TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+SETS[5]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+SETS[6]="FETCH_SIZE"
+SETS[7]="WRITE_SIZE"
+for i in $PASSES; do
+  PMC=${SETS[$i]}
+  timeout 300 rocprofv3 --pmc $PMC --output-format csv -d "$OUT/pass$i" -o pmc -- python bench.py $ARGS > "$OUT/pass$i.log" 2>&1
+  echo "pass $i rc=$? : $PMC"
+done

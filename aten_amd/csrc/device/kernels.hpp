@@ -428,7 +428,13 @@ struct ShadowJob {
         const uint32_t slot = pb.shadow_q[j];
         const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
         const f3 dir = normalize(mk3(sd));      // aten::ray(org, dir) constructor re-normalises (pathtracing_impl.h:380)
-        a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)
+        // scene::hitLight (scene/scene.h:118-131) needs the closest hit's OBJECT only for area lights.  For
+        // infinite and singular lights its answer is exactly `!isHit` (lightobj is null; t <= t_max < dist),
+        // so those shadow rays are any-hit jobs.
+        const atn_light_param* lp = &sc.lights[__float_as_int(sd.w)];
+        const bool needs_closest = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
+        const float t_max = so.w - kEps;                        // distToLight - AT_MATH_EPSILON (:304)
+        a = make_float4(so.x, so.y, so.z, (needs_closest || !(t_max > 0.0F)) ? t_max : -t_max);
         b = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
     }
     ATN_DEV void finish(uint32_t slot, const Hit& h, bool isHit) const

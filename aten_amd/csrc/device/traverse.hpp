@@ -79,7 +79,10 @@ ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
 
 // Job interface (all jobs of a launch share t_min):
 //   float t_min
-//   void fetch(uint32_t j, float4& a, float4& b)   a = {org.xyz, t_max}, b = {dir.xyz, payload bits}
+//   void fetch(uint32_t j, float4& a, float4& b)   a = {org.xyz, +-t_max}, b = {dir.xyz, payload bits}
+//        a.w < 0 marks an "any hit" job: only finish()'s is_hit is used, so the walk may stop at its first
+//        accepted hit.  This is exact, not an approximation: up to its first accepted hit the closest-hit
+//        walk is the same walk, and it reports is_hit = true iff it accepts at least one hit.
 //   void finish(uint32_t payload, const Hit& h, bool is_hit)
 // One ray per lane for the lifetime of its walk; grid-stride over the jobs.
 template <bool COUNT, class Job>
@@ -91,7 +94,8 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
         float4 a, b;
         job.fetch(j, a, b);
-        float t_max = a.w;
+        float t_max = fabsf(a.w);
+        const bool any_hit = a.w < 0.0F;        // see Job::fetch
         const uint32_t payload = __float_as_uint(b.w);
         RaySlab wray, ray;
         slab_setup(wray, mk3(a), mk3(b));
@@ -135,6 +139,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     t_max = t;
                 }
                 node = __float_as_int(q1.w);        // leaf: hit link == miss link
+                if (any_hit && accept) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
             }
             else {
                 // TLAS leaf with a nested tree
@@ -205,6 +210,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
 
     uint32_t payload = 0;
     float t_max = 0.0F;
+    bool any_hit = false;
     RaySlab wray, ray;
     slab_setup(wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
     ray = wray;
@@ -251,7 +257,8 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     if (k < avail) {
                         const float4 a = stage[c_next + k][0];
                         const float4 b = stage[c_next + k][1];
-                        t_max = a.w;
+                        t_max = fabsf(a.w);
+                        any_hit = a.w < 0.0F;
                         payload = __float_as_uint(b.w);
                         hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
                         slab_setup(wray, mk3(a), mk3(b));
@@ -302,6 +309,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     t_max = t;
                 }
                 node = __float_as_int(q1.w);
+                if (any_hit && accept) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
             }
             else {
                 objid = __float_as_int(q0.x);

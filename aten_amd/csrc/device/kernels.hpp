@@ -88,16 +88,11 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t posA[kChunkItems], posB[kChunkItems];
     uint32_t totA = 0, totB = 0;
 #pragma unroll
     for (int k = 0; k < kChunkItems; k++) {
-        const unsigned long long mA = __ballot((flagsA >> k) & 1u);
-        const unsigned long long mB = __ballot((flagsB >> k) & 1u);
-        posA[k] = totA + (uint32_t)__popcll(mA & lt);
-        posB[k] = totB + (uint32_t)__popcll(mB & lt);
-        totA += (uint32_t)__popcll(mA);
-        totB += (uint32_t)__popcll(mB);
+        totA += (uint32_t)__popcll(__ballot((flagsA >> k) & 1u));
+        totB += (uint32_t)__popcll(__ballot((flagsB >> k) & 1u));
     }
     if (lane == 0) { sh.wave_total[0][wave] = totA; sh.wave_total[1][wave] = totB; }
     __syncthreads();
@@ -112,8 +107,12 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
     for (uint32_t w = 0; w < wave; w++) { offA += sh.wave_total[0][w]; offB += sh.wave_total[1][w]; }
 #pragma unroll
     for (int k = 0; k < kChunkItems; k++) {
-        if ((flagsA >> k) & 1u) qA[offA + posA[k]] = entry(k);
-        if ((flagsB >> k) & 1u) qB[offB + posB[k]] = entry(k);
+        const unsigned long long mA = __ballot((flagsA >> k) & 1u);
+        const unsigned long long mB = __ballot((flagsB >> k) & 1u);
+        if ((flagsA >> k) & 1u) qA[offA + (uint32_t)__popcll(mA & lt)] = entry(k);
+        if ((flagsB >> k) & 1u) qB[offB + (uint32_t)__popcll(mB & lt)] = entry(k);
+        offA += (uint32_t)__popcll(mA);
+        offB += (uint32_t)__popcll(mB);
     }
     __syncthreads();    // sh is reused by the next chunk
 }
@@ -294,20 +293,14 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 const int32_t tri_id = __float_as_int(is4.w);
                 HitRec rec;
                 evaluate_hit(rec, sc, is2.x, tri_id, is4.y, is4.z);
-                const atn_triangle_param tp = sc.tris[tri_id];
-                const int32_t mtrlid = tp.mtrlid;
+                const int32_t mtrlid = sc.tris[tri_id].mtrlid;
 
                 const bool isBackfacing = dot(rec.normal, -ray_dir) < 0.0F;
                 f3 orienting_normal = rec.normal;
 
-                DevMaterial m;
-                if (mtrlid >= 0) m = sc.materials[mtrlid];
-                else {  // FillMaterial fallback, material_impl.h:253-259
-                    m.baseColor = make_float4(1, 1, 1, 1); m.type = ATN_MTRL_DIFFUSE; m.attrib = 0; m.id = 0;
-                    m.albedoMap = m.normalMap = m.roughnessMap = -1; m.ior = 1.0F; m.roughness = 0.5F;
-                    m.subsurface = m.metallic = m.specular = m.specularTint = 0.5F;
-                    m.sheen = m.sheenTint = m.clearcoat = m.clearcoatGloss = 0.5F;
-                }
+                // FillMaterial (material_impl.h:232-262): a negative id selects the white-diffuse fallback, which
+                // the upload appends after the last real material
+                const DevMaterial& m = sc.materials[mtrlid >= 0 ? mtrlid : sc.n_materials];
                 float4 albedo4 = sample_texture(sc, m.albedoMap, rec.u, rec.v, m.baseColor);
                 albedo4 = add4(mul4(1.0F, albedo4), make_float4(0, 0, 0, 0));
                 const f3 albedo = mk3(albedo4);
@@ -316,8 +309,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 // HitTeminatedMaterial -> HitImplicitLight, pathtracing_impl.h:395-509
                 if (m.type == ATN_MTRL_EMISSIVE && (m.attrib & ATN_MTRL_ATTR_EMISSIVE) && !isBackfacing) {
                     const atn_object_param* obj = &sc.objects[is2.x];
-                    const atn_light_param lp = sc.lights[obj->light_id];
-                    const f3 light_color = area_light_color(lp, rec.area);
+                    const f3 light_color = area_light_color(sc.lights[obj->light_id], rec.area);
                     float weight = 1.0f;
                     if (bounce > 0) {
                         const float cosLight = dot(rec.normal, -ray_dir);
@@ -345,9 +337,8 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         int32_t li = (int32_t)(cmj_next(smp) * (float)sc.n_lights);
                         li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
                         const float lightSelectPdf = 1.0f / (float)sc.n_lights;
-                        const atn_light_param lp = sc.lights[li];
                         LightSample ls;
-                        sample_light(ls, lp, sc, rec.p, orienting_normal, smp);
+                        sample_light(ls, sc.lights[li], sc, rec.p, orienting_normal, smp);
                         const f3 dirToLight = normalize(ls.dir);
                         const float distToLight = length(ls.pos - rec.p);
                         const f3 so = ray_offset(rec.p, orienting_normal);

@@ -30,9 +30,12 @@ ATN_DEV void evaluate_hit(HitRec& rec, const DevScene& sc, int32_t objid, int32_
     m4 L2W = m4_identity();
     if (mtx_id >= 0) L2W = load_m4(sc, mtx_id);
 
-    const atn_triangle_param tri = sc.tris[tri_id];
-    const float4 p0 = sc.vtx_pos[tri.idx[0]], p1 = sc.vtx_pos[tri.idx[1]], p2 = sc.vtx_pos[tri.idx[2]];
-    const float4 n0 = sc.vtx_nml[tri.idx[0]], n1 = sc.vtx_nml[tri.idx[1]], n2 = sc.vtx_nml[tri.idx[2]];
+    // TriangleParameter = two 16-byte halves {idx[3], pad}{area, needNormal, mtrlid, mesh_id}: only the
+    // first half and needNormal are needed here
+    const int4 tidx = *reinterpret_cast<const int4*>(&sc.tris[tri_id]);
+    const int32_t need_normal = sc.tris[tri_id].needNormal;
+    const float4 p0 = sc.vtx_pos[tidx.x], p1 = sc.vtx_pos[tidx.y], p2 = sc.vtx_pos[tidx.z];
+    const float4 n0 = sc.vtx_nml[tidx.x], n1 = sc.vtx_nml[tidx.y], n2 = sc.vtx_nml[tidx.z];
     const float c = 1 - a - b;
 
     float4 P = add4(add4(mul4(c, p0), mul4(a, p1)), mul4(b, p2));
@@ -41,7 +44,7 @@ ATN_DEV void evaluate_hit(HitRec& rec, const DevScene& sc, int32_t objid, int32_
     rec.normal = mk3(N);
     rec.u = (c * p0.w + a * p1.w) + b * p2.w;
     rec.v = (c * n0.w + a * n1.w) + b * n2.w;
-    if (tri.needNormal > 0) {
+    if (need_normal > 0) {
         float4 e01 = sub4(p1, p0), e02 = sub4(p2, p0);
         e01.w = 0.0F; e02.w = 0.0F;
         rec.normal = mk3(normalize4(cross4(e01, e02)));
@@ -283,64 +286,62 @@ ATN_DEV float dis_specular_pdf(float roughness, const f3& V, const f3& L, const 
     const f3 H = normalize(V + L);
     return ggx_pdf_h(roughness, N, H, L);
 }
-ATN_DEV void dis_weights(float w[4], const f3& base, float metalic, float sheen, float specular, float clearcoat)
+struct DisW { float d, sh, sp, cc; };     // lobe weights: diffuse, sheen, specular, clearcoat (disney_brdf.h:105-111)
+
+ATN_DEV DisW dis_weights(const f3& base, float metalic, float sheen, float specular, float clearcoat)   // :311-335
 {
     const float lum = luminance(base.x, base.y, base.z);
-    w[0] = lum * (1 - metalic);
-    w[1] = sheen * (1 - metalic);
-    w[2] = mixf(specular, 1.0F, metalic);
-    w[3] = 0.25F * clearcoat;
+    DisW w;
+    w.d = lum * (1 - metalic);
+    w.sh = sheen * (1 - metalic);
+    w.sp = mixf(specular, 1.0F, metalic);
+    w.cc = 0.25F * clearcoat;
     float norm = 0.0F;
-    norm += w[0]; norm += w[1]; norm += w[2]; norm += w[3];
-    if (norm > 0) { w[0] /= norm; w[1] /= norm; w[2] /= norm; w[3] /= norm; }
+    norm += w.d; norm += w.sh; norm += w.sp; norm += w.cc;
+    if (norm > 0) { w.d /= norm; w.sh /= norm; w.sp /= norm; w.cc /= norm; }
+    return w;
 }
 // evaluate every lobe whose weight is > 0 at (V, wo) and add weight * pdf (disney_brdf.cpp:404-433,527-550)
-ATN_DEV void dis_eval_rest(const DevMaterial& m, const f3& base, const float w[4], const f3& V, const f3& wo, const f3& N,
-                           f3& d, f3& sh, f3& sp, f3& cc, float& p, bool weight_first)
+ATN_DEV void dis_eval_rest(const DevMaterial& m, const f3& base, const DisW& w, const f3& V, const f3& wo, const f3& N,
+                           f3& d, f3& sh, f3& sp, f3& cc, float& p)
 {
-    if (w[0] > 0.0F) {
+    if (w.d > 0.0F) {
         d = dis_diffuse_brdf(base, m.roughness, m.subsurface, V, wo, N);
-        const float prob = diffuse_pdf(N, wo);
-        p += weight_first ? w[0] * prob : prob * w[0];
+        p += w.d * diffuse_pdf(N, wo);
     }
-    if (w[1] > 0.0F) {
+    if (w.sh > 0.0F) {
         sh = dis_sheen_brdf(base, m.sheen, m.sheenTint, V, wo);
-        const float prob = 1 / kPi;
-        p += weight_first ? w[1] * prob : prob * w[1];
+        p += w.sh * (1 / kPi);
     }
-    if (w[2] > 0.0F) {
+    if (w.sp > 0.0F) {
         sp = dis_specular_brdf(base, m.roughness, m.metallic, m.specular, m.specularTint, V, wo, N);
-        const float prob = dis_specular_pdf(m.roughness, V, wo, N);
-        p += weight_first ? w[2] * prob : prob * w[2];
+        p += w.sp * dis_specular_pdf(m.roughness, V, wo, N);
     }
-    if (w[3] > 0.0F) {
+    if (w.cc > 0.0F) {
         cc = dis_clearcoat_brdf(m.clearcoat, V, wo);
-        const float prob = dis_clearcoat_pdf(m.roughness, V, wo, N);   // reference quirk: roughness, not gloss (:431,517,548)
-        p += weight_first ? w[3] * prob : prob * w[3];
+        p += w.cc * dis_clearcoat_pdf(m.roughness, V, wo, N);   // reference quirk: roughness, not gloss (:431,517,548)
     }
 }
 ATN_DEV float disney_pdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)   // :347-378
 {
-    float w[4];
     const f3 base = mk3(m.baseColor);
-    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const DisW w = dis_weights(base, m.metallic, m.sheen, m.specular, m.clearcoat);
     const f3 V = -wi;
     float p = 0.0F;
-    p += w[0] * diffuse_pdf(n, wo);
-    p += w[1] * (1 / kPi);
-    p += w[2] * dis_specular_pdf(m.roughness, V, wo, n);
-    p += w[3] * dis_clearcoat_pdf(m.clearcoatGloss, V, wo, n);
+    p += w.d * diffuse_pdf(n, wo);
+    p += w.sh * (1 / kPi);
+    p += w.sp * dis_specular_pdf(m.roughness, V, wo, n);
+    p += w.cc * dis_clearcoat_pdf(m.clearcoatGloss, V, wo, n);
     return p;
 }
 ATN_DEV MtrlSample disney_bsdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)   // :380-441
 {
-    float w[4];
     const f3 base = mk3(m.baseColor);
-    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const DisW w = dis_weights(base, m.metallic, m.sheen, m.specular, m.clearcoat);
     const f3 V = -wi;
     f3 d = mk3(0.0F), sh = mk3(0.0F), sp = mk3(0.0F), cc = mk3(0.0F);
     float p = 0.0F;
-    dis_eval_rest(m, base, w, V, wo, n, d, sh, sp, cc, p, false);
+    dis_eval_rest(m, base, w, V, wo, n, d, sh, sp, cc, p);
     MtrlSample r;
     r.bsdf = ((1 - m.metallic) * (d + sh) + sp) + cc;
     r.pdf = p;
@@ -350,10 +351,9 @@ ATN_DEV MtrlSample disney_bsdf(const DevMaterial& m, const f3& n, const f3& wi, 
 ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp)  // :443-555
 {
     const float r1 = cmj_next(smp), r2 = cmj_next(smp), r3 = cmj_next(smp);
-    float w[4];
     const f3 base = mk3(m.baseColor);
-    dis_weights(w, base, m.metallic, m.sheen, m.specular, m.clearcoat);
-    const float c0 = w[0], c1 = c0 + w[1], c2 = c1 + w[2];
+    DisW w = dis_weights(base, m.metallic, m.sheen, m.specular, m.clearcoat);
+    const float c0 = w.d, c1 = c0 + w.sh, c2 = c1 + w.sp;      // GetCDF, :337-345
     const f3 V = -wi, N = n;
     f3 wo; float p = 0;
     f3 d = mk3(0.0F), sh = mk3(0.0F), sp = mk3(0.0F), cc = mk3(0.0F);
@@ -361,28 +361,28 @@ ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, c
         wo = diffuse_dir(N, r1, r2);
         d = dis_diffuse_brdf(base, m.roughness, m.subsurface, V, wo, N);
         p = diffuse_pdf(N, wo);
-        p *= w[0]; w[0] = 0.0F;
+        p *= w.d; w.d = 0.0F;
     }
     else if (r3 < c1) {
         wo = diffuse_dir(N, r1, r2);
         sh = dis_sheen_brdf(base, m.sheen, m.sheenTint, V, wo);
         p = 1 / kPi;
-        p *= w[1]; w[1] = 0.0F;
+        p *= w.sh; w.sh = 0.0F;
     }
     else if (r3 < c2) {
         wo = ggx_dir(r1, r2, m.roughness, -V, N);
         sp = dis_specular_brdf(base, m.roughness, m.metallic, m.specular, m.specularTint, V, wo, N);
         p = dis_specular_pdf(m.roughness, V, wo, N);
-        p *= w[2]; w[2] = 0.0F;
+        p *= w.sp; w.sp = 0.0F;
     }
     else {
         const float a = mixf(0.1F, 0.001F, m.clearcoatGloss);
         wo = reflect_vector(-V, ggx_sample_m(a, N, r1, r2));
         cc = dis_clearcoat_brdf(m.clearcoat, V, wo);
         p = dis_clearcoat_pdf(m.roughness, V, wo, N);
-        p *= w[3]; w[3] = 0.0F;
+        p *= w.cc; w.cc = 0.0F;
     }
-    dis_eval_rest(m, base, w, V, wo, N, d, sh, sp, cc, p, true);
+    dis_eval_rest(m, base, w, V, wo, N, d, sh, sp, cc, p);
     res.pdf = p;
     res.bsdf = ((1 - m.metallic) * (d + sh) + sp) + cc;
     res.dir = wo;
@@ -475,8 +475,6 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
 {
     res.pdf = 0.0F; res.dist = 0.0F; res.color = mk3(0.0F);
     res.pos = org; res.dir = mk3(0.0F, 1.0F, 0.0F); res.nml = mk3(0.0F, 1.0F, 0.0F);
-    const f3 lpos = mk3(lp.pos.x, lp.pos.y, lp.pos.z);
-    const f3 lcol = mk3(lp.light_color[0], lp.light_color[1], lp.light_color[2]);
     switch (lp.type) {
     case ATN_LIGHT_AREA: {      // AreaLight::sample, arealight.h:65-143 (polygon lights)
         if (lp.arealight_objid < 0) break;
@@ -515,6 +513,8 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
         break;
     }
     case ATN_LIGHT_POINT: {     // light/pointlight.h:40-58
+        const f3 lpos = mk3(lp.pos.x, lp.pos.y, lp.pos.z);
+        const f3 lcol = mk3(lp.light_color[0], lp.light_color[1], lp.light_color[2]);
         res.pdf = 1.0f;
         res.dir = lpos - org;
         res.dist = length(res.dir);
@@ -526,6 +526,8 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
         break;
     }
     case ATN_LIGHT_SPOT: {      // light/spotlight.h:58-92
+        const f3 lpos = mk3(lp.pos.x, lp.pos.y, lp.pos.z);
+        const f3 lcol = mk3(lp.light_color[0], lp.light_color[1], lp.light_color[2]);
         const f3 ldir = mk3(lp.dir.x, lp.dir.y, lp.dir.z);
         res.pdf = 1.0f;
         res.pos = lpos;
@@ -549,6 +551,7 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
         break;
     }
     case ATN_LIGHT_DIRECTION: { // light/directionallight.h:40-63
+        const f3 lcol = mk3(lp.light_color[0], lp.light_color[1], lp.light_color[2]);
         res.pdf = 1.0f;
         const float4 nd = normalize4(make_float4(lp.dir.x, lp.dir.y, lp.dir.z, lp.dir.w));
         res.dir = mk3(-nd.x, -nd.y, -nd.z);

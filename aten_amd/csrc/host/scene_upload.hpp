@@ -165,6 +165,14 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         d.specular = st.specular; d.specularTint = st.specularTint; d.sheen = st.sheen; d.sheenTint = st.sheenTint;
         d.clearcoat = st.clearcoat; d.clearcoatGloss = st.clearcoatGloss;
     }
+    {   // FillMaterial's fallback for mtrl_id < 0 (material_impl.h:253-259), stored at index n_materials
+        DevMaterial d{};
+        d.baseColor = make_float4(1, 1, 1, 1); d.type = ATN_MTRL_DIFFUSE; d.attrib = 0; d.id = 0;
+        d.albedoMap = d.normalMap = d.roughnessMap = -1; d.ior = 1.0F; d.roughness = 0.5F;
+        d.subsurface = d.metallic = d.specular = d.specularTint = 0.5F;
+        d.sheen = d.sheenTint = d.clearcoat = d.clearcoatGloss = 0.5F;
+        img.materials.push_back(d);
+    }
     img.lights.assign(s->lights, s->lights + s->n_lights);
     img.textures.resize(s->n_textures);
     size_t ntex = 0;

@@ -36,6 +36,22 @@ def algorithmic_bytes(nodes, tris, rays):
     return 48 * nodes + 80 * tris + 56 * rays
 
 
+def measured_traffic(scene, w, h):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*traffic.json,
+    written from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); None when
+    no profile matches the workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if scene in d.get("workload", "") and ("%dx%d" % (w, h)) in d.get("workload", ""):
+            best = d
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,9 +162,12 @@ def main():
     launches_per_frame = tc_n / max(frames_prof, 1)
     avg_launch_ms = tc_ms / max(tc_n, 1)
     achieved = (bytes_per_frame / max(launches_per_frame, 1)) / (avg_launch_ms * 1e-3) / 1e9 if tc_n else 0.0
+    tr = measured_traffic("sponza_lod" if args.scene == "sponza" else "cornell", W, H) if world == 1 else None
     roofline = {
         "kernel": "k_trace_closest", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+        "traffic_source": tr["source"] if tr else None,
         "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),

@@ -103,3 +103,74 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
         b.set_background((1.0, 1.0, 1.0))
     cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)         # scenedefs.cpp:847-860
     return b.build(), cam
+
+
+def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
+    """Parity-test variant of the Cornell box (not a reference scene): the two boxes are instanced with
+    non-identity matrices (translation / rotation about y, so the W2L ray transform, the L2W hit transform
+    and the instance area ratio are exercised) and the light set is selectable:
+      "area"  the reference's polygon light            "point" / "spot" / "directional"  punctual lights
+      "mixed" area + point + spot + directional (uniform light pick among four)
+    """
+    asset_dir = asset_dir or os.path.join(ASSETS, "cornellbox")
+    b = SceneBuilder()
+    emit = b.add_material("light", L.MTRL_EMISSIVE, (1.0, 1.0, 1.0))
+
+    def create_mtrl(name, mtype, clr, albedo, nml):
+        if name == "shortBox":
+            return b.add_material(name, L.MTRL_DISNEY, (0.7, 0.6, 0.5), roughness=0.35, metallic=0.3,
+                                  specular=0.6, clearcoat=0.4, clearcoatGloss=0.7, sheen=0.3)
+        if name == "floor":
+            return b.add_material(name, L.MTRL_GGX, (0.7, 0.6, 0.5), roughness=0.1, ior=0.01)
+        return b.add_material(name, mtype, clr)
+
+    objs = b.load_obj(os.path.join(asset_dir, "orig.obj"), create_mtrl=create_mtrl,
+                      separate_objs=True, normal_on_the_fly=True)
+    names = [b.objects[o]["name"] for o in objs]
+
+    def rot_y_trans(deg, t):
+        c, s_ = np.cos(np.radians(deg)), np.sin(np.radians(deg))
+        return np.array([[c, 0, s_, t[0]], [0, 1, 0, t[1]], [-s_, 0, c, t[2]], [0, 0, 0, 1]], np.float32)
+
+    inst = {}
+    for o, n in zip(objs, names):
+        if n == "light" and lights not in ("area", "mixed"):
+            continue        # an emissive object without a registered light has light_id = -1 (the reference would index lights[-1])
+        M = None
+        if move_boxes and n == "tallBox":
+            M = rot_y_trans(17.0, (0.15, 0.0, 0.1))
+        if move_boxes and n == "shortBox":
+            M = rot_y_trans(-23.0, (-0.2, 0.25, 0.05))
+        inst[n] = b.create_instance(o, M)
+    if lights in ("area", "mixed"):
+        b.add_area_light(inst["light"], (1.0, 1.0, 1.0), 200.0)
+    if lights in ("point", "mixed"):
+        b.add_point_light((0.3, 1.6, 0.4), (1.0, 0.9, 0.8), 40.0)
+    if lights in ("spot", "mixed"):
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_SPOT
+        l["attrib"] = L.LATTR_SINGULAR
+        l["pos"] = (-0.5, 1.8, 0.6, 1.0)
+        d = np.array([0.3, -1.0, -0.4], np.float32)
+        d /= np.linalg.norm(d)
+        l["dir"] = (d[0], d[1], d[2], 0.0)
+        l["light_color"] = (0.8, 0.9, 1.0)
+        l["innerAngle"], l["outerAngle"] = np.radians(25.0), np.radians(60.0)
+        l["scale"], l["intensity"] = 1.0, 60.0
+        l["arealight_objid"], l["envmapidx"] = -1, -1
+        b.lights.append(l)
+    if lights in ("directional", "mixed"):
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_DIRECTION
+        l["attrib"] = L.LATTR_SINGULAR | L.LATTR_INFINITE
+        d = np.array([-0.2, -0.6, -1.0], np.float32)
+        d /= np.linalg.norm(d)
+        l["dir"] = (d[0], d[1], d[2], 0.0)
+        l["light_color"] = (1.0, 0.95, 0.9)
+        l["innerAngle"] = l["outerAngle"] = np.pi
+        l["scale"], l["intensity"] = 1.0, 3.0
+        l["arealight_objid"], l["envmapidx"] = -1, -1
+        b.lights.append(l)
+    b.set_background((0.02, 0.03, 0.05))
+    cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)
+    return b.build(), cam

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -75,9 +77,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -104,25 +108,28 @@ def main():
 
     gathered = None
     full = None
+    ext_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=dev) if use_dist else None
 
     def step(frame, profile):
         r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, download=False, profile=profile)
-        if world > 1:
+        if use_dist:
+            # Exchange step: every rank contributes its tile buffer; no host synchronisation -- the collective
+            # is issued from the renderer's own HIP stream (torch orders RCCL's stream against it with events),
+            # and the assemble kernel follows on that stream.
             nonlocal gathered, full
             n = r.tile_slots()
             if gathered is None:
                 gathered = torch.empty((world * n, 4), dtype=torch.float32, device=dev)
                 full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-            r.synchronize()         # renderer stream -> torch stream hand-off
-            mine = tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev)
-            dist.all_gather_into_tensor(gathered, mine)
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(ext_stream):
+                mine = tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev)
+                dist.all_gather_into_tensor(gathered, mine)
             r.assemble_tiles(gathered.data_ptr(), world, full.data_ptr())
 
     def sync_all():
         r.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -136,11 +143,14 @@ def main():
         step(i, True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktimes = r.kernel_times()
+    final_img = None
+    if args.dump and rank == 0:
+        final_img = full.cpu().numpy() if use_dist else r.download_film()
 
     ms_per_step = 1e3 * elapsed / args.steps
     mrays = W * H * spp / 1e6 / (elapsed / args.steps)
@@ -195,9 +205,8 @@ def main():
                         "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305" % (cw, ch, len(ts)),
                         "ms_per_frame_sample": round(1e3 * med, 2)}
 
-    if args.dump and rank == 0:
-        img = full.cpu().numpy() if world > 1 else r.download_film()
-        np.save(args.dump, img)
+    if final_img is not None:
+        np.save(args.dump, final_img)
 
     if rank == 0:
         out = {
@@ -216,7 +225,7 @@ def main():
         }
         print(json.dumps(out))
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

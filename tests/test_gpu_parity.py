@@ -249,6 +249,30 @@ def test_spp_and_break_on_terminate_quirk(gpu, orc, cornell):
     assert not np.array_equal(full, got)
 
 
+
+
+@pytest.mark.parametrize("lights", ["area", "point", "spot", "directional", "mixed"])
+def test_transformed_instances_and_punctual_lights(gpu, orc, lights):
+    """Instances with rotation + translation (W2L ray transform, L2W hit transform, area ratio), a Disney
+    box, and every light type of light_impl.h:12-43 that consumes no texture."""
+    from aten_amd.scene import scenedefs
+    scene = scenedefs.cornell_box_variant(lights=lights)
+    fs, c, seeds = _setup(gpu, orc, scene, 96, 96)
+    rays = orc.generate_paths(c, seeds, 96, 96, 0, 0)
+    want_i, wst = orc.trace_closest(fs, rays)
+    got_i, gst = gpu.trace_closest(rays, stats=True)
+    assert got_i.tobytes() == want_i.tobytes() and np.array_equal(gst, wst)
+    for frame in (0, 5):
+        gpu.reset()
+        got = gpu.render(96, 96, 5, 3, frame=frame)
+        want = orc.render(fs, c, seeds, 96, 96, 5, 3, frame=frame)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.995, (lights, frame, frac)
+        assert mean_err <= 2e-3, (lights, frame, mean_err)
+    assert np.nanmax(got[..., :3]) > 0.0
+
+
+
 # ---- size-independent properties at BASELINE's full sizes ---------------------------------------
 def test_full_size_properties_1080p(gpu, orc, cornell):
     """1920x1080 (config 2): determinism, progressive count, exact linearity in light intensity,

@@ -480,6 +480,55 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
         if (lp.arealight_objid < 0) break;
         const atn_object_param* obj = &sc.objects[lp.arealight_objid];
         const atn_object_param* real_obj = obj->type == ATN_OBJ_INSTANCE ? &sc.objects[obj->object_id] : obj;
+        if (real_obj->type == ATN_OBJ_SPHERE) {
+            // sphere::SamplePosAndNormal (geometry/sphere.cpp:109-150) -> sphere::hit (:30-91) along the ray to
+            // the sampled point -> sphere::EvaluateHitResult (:93-107) -> evaluate_hit_result's L2W step
+            const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+            const float rad = real_obj->sphere.radius;
+            const f3 center = mk3(real_obj->sphere.center[0], real_obj->sphere.center[1], real_obj->sphere.center[2]);
+            const float z = 2.0F * r1 - 1.0F;
+            const float sin_theta = sqrtf(1 - z * z);
+            const float phi = (2 * kPi) * r2;
+            const float x = cosf(phi) * sin_theta;
+            const float y = sinf(phi) * sin_theta;
+            const f3 sdir = normalize(mk3(x, y, z));
+            const f3 spos = center + sdir * (rad + kEps);
+            const f3 rdir = normalize(spos - org);
+            // sphere::hit reads the LIGHT object's own parameters (arealight.h:115 passes &obj)
+            const f3 ocenter = mk3(obj->sphere.center[0], obj->sphere.center[1], obj->sphere.center[2]);
+            const float orad = obj->sphere.radius;
+            const f3 p_o = ocenter - org;
+            const float b = dot(p_o, rdir);
+            const float D4 = (b * b - dot(p_o, p_o)) + orad * orad;
+            if (D4 < 0.0F) break;
+            const float sqrt_D4 = sqrtf(D4);
+            const float t1 = b - sqrt_D4, t2 = b + sqrt_D4;
+            // isClose(|b|, sqrt_D4, 2500 ulps), math/math.h:340-372
+            int32_t ai = __float_as_int(fabsf(b)), bi = __float_as_int(sqrt_D4);
+            if (ai < 0) ai = (int32_t)(0x80000000u - (uint32_t)ai);
+            if (bi < 0) bi = (int32_t)(0x80000000u - (uint32_t)bi);
+            const bool close = abs(ai - bi) <= 2500;
+            float t;
+            if (t1 > kEps && !close) t = t1;
+            else if (t2 > kEps && !close) t = t2;
+            else break;
+            const bool is_inst = obj->type == ATN_OBJ_INSTANCE;
+            m4 L2W = m4_identity();
+            if (is_inst && obj->mtx_id >= 0) L2W = load_m4(sc, obj->mtx_id);
+            f3 p = org + t * rdir;
+            f3 n = (p - center) / rad;
+            const float area = ((4 * kPi) * rad) * rad;
+            p = m4_apply(L2W, p);
+            n = normalize(m4_applyXYZ(L2W, n));
+            res.pos = p;
+            res.pdf = 1 / area;
+            res.dir = p - org;
+            res.dist = length(res.dir);
+            res.dir = normalize(res.dir);
+            res.nml = n;
+            res.color = area_light_color(lp, area);
+            break;
+        }
         if (real_obj->type != ATN_OBJ_POLYGONS) break;
         // PolygonObject::SamplePosAndNormal (PolygonObject.h:113-156) + triangle::SamplePosAndNormal (triangle.h:122-162)
         const float r = cmj_next(smp);

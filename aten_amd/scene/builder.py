@@ -243,6 +243,13 @@ class SceneBuilder:
         self.blas[oid] = None
         return oid
 
+    def add_sphere(self, center, radius, mtrl):
+        """TransformableFactory::createSphere (geometry/sphere.h:16-28): a transformable of type Sphere.  The
+        BVH traverser never tests spheres, so on this path a sphere only matters as an area light's shape."""
+        self.objects.append(dict(type=L.OBJ_SPHERE, center=tuple(float(x) for x in center), radius=float(radius),
+                                 mtrl=mtrl, light_id=-1))
+        return len(self.objects) - 1
+
     def create_instance(self, obj_id, mtx_L2W=None):
         """TransformableFactory::createInstance: adds an (L2W, W2L) matrix pair and an Instance entry."""
         M = np.eye(4, dtype=F32) if mtx_L2W is None else np.asarray(mtx_L2W, F32).reshape(4, 4)
@@ -376,6 +383,18 @@ class SceneBuilder:
 
         inst = []
         for oid, o in enumerate(self.objects):
+            if o["type"] == L.OBJ_SPHERE:
+                objs[oid]["type"] = L.OBJ_SPHERE
+                r = F32(o["radius"])
+                objs[oid]["area"] = F32(0)      # transformable default; sphere area is computed on the fly
+                objs[oid]["sphere_center"] = o["center"]
+                objs[oid]["sphere_radius"] = r
+                objs[oid]["sphere_mtrl_id"] = o["mtrl"]
+                objs[oid]["light_id"] = o.get("light_id", -1)
+                c = np.asarray(o["center"], F32)
+                # scene->add(sphere): a top-layer leaf without nested tree (exid = -1), never tested
+                inst.append((oid, -1, c - r, c + r))
+                continue
             if o["type"] != L.OBJ_INSTANCE:
                 continue
             objs[oid]["type"] = L.OBJ_INSTANCE

@@ -111,6 +111,7 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
     and the instance area ratio are exercised) and the light set is selectable:
       "area"  the reference's polygon light            "point" / "spot" / "directional"  punctual lights
       "mixed" area + point + spot + directional (uniform light pick among four)
+      "sphere" a sphere area light (AreaLight over a sphere object; the sphere itself is never hit by rays)
     """
     asset_dir = asset_dir or os.path.join(ASSETS, "cornellbox")
     b = SceneBuilder()
@@ -144,6 +145,10 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
         inst[n] = b.create_instance(o, M)
     if lights in ("area", "mixed"):
         b.add_area_light(inst["light"], (1.0, 1.0, 1.0), 200.0)
+    if lights == "sphere":
+        sm = b.add_material("sphere_emit", L.MTRL_EMISSIVE, (1.0, 0.9, 0.8))
+        sp = b.add_sphere((0.1, 1.55, 0.2), 0.18, sm)
+        b.add_area_light(sp, (1.0, 0.9, 0.8), 30.0)
     if lights in ("point", "mixed"):
         b.add_point_light((0.3, 1.6, 0.4), (1.0, 0.9, 0.8), 40.0)
     if lights in ("spot", "mixed"):

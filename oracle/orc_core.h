@@ -362,9 +362,38 @@ inline void PolygonObject_evaluate_hit_result(const atn_object_param& obj, const
     rec.mtrlid = isect.mtrlid;
 }
 
+// isClose(A, B, maxUlps), math/math.h:340-372
+inline bool isCloseUlps(float A, float B, int32_t maxUlps)
+{
+    int32_t aInt = float_as_int(A);
+    if (aInt < 0) aInt = (int32_t)(0x80000000u - (uint32_t)aInt);
+    int32_t bInt = float_as_int(B);
+    if (bInt < 0) bInt = (int32_t)(0x80000000u - (uint32_t)bInt);
+    int32_t intDiff = std::abs(aInt - bInt);
+    return intDiff <= maxUlps;
+}
+
+// sphere::hit, geometry/sphere.cpp:30-91.  Only reached through AreaLight::sample for sphere lights:
+// the BVH traverser never tests spheres.
+inline bool sphere_hit(const atn_object_param& prm, const Ray& r, float t_min, float t_max, Isect* isect)
+{
+    (void)t_min; (void)t_max;
+    const v3 p_o = ld3(prm.sphere.center) - r.org;
+    const float b = dot(p_o, r.dir);
+    const float D4 = b * b - dot(p_o, p_o) + prm.sphere.radius * prm.sphere.radius;
+    if (D4 < 0.0F) return false;
+    const float sqrt_D4 = std::sqrt(D4);
+    const float t1 = b - sqrt_D4;
+    const float t2 = b + sqrt_D4;
+    const bool close = isCloseUlps(std::fabs(b), sqrt_D4, 2500);
+    if (t1 > EPS && !close) isect->t = t1;
+    else if (t2 > EPS && !close) isect->t = t2;
+    else return false;
+    return true;
+}
+
 inline void evaluate_hit_result(HitRec& rec, const atn_object_param& obj, const Scene& ctxt, const Ray& r, const Isect& isect)
 {
-    (void)r;
     const atn_object_param& real_obj = obj.type == ATN_OBJ_INSTANCE ? ctxt.GetObject(obj.object_id) : obj;
     const int32_t mtx_id = obj.type == ATN_OBJ_INSTANCE ? obj.mtx_id : -1;
     m4 mtx_L2W = m4::identity();
@@ -373,7 +402,18 @@ inline void evaluate_hit_result(HitRec& rec, const atn_object_param& obj, const 
     if (real_obj.type == ATN_OBJ_POLYGONS) {
         PolygonObject_evaluate_hit_result(real_obj, ctxt, mtx_L2W, rec, isect);
     }
-    // Sphere objects: not on this path; see DESIGN.md "out of scope".
+    else if (real_obj.type == ATN_OBJ_SPHERE) {
+        // sphere::EvaluateHitResult (geometry/sphere.cpp:93-107) + getUV (:5-12)
+        rec.p = r.org + isect.t * r.dir;
+        rec.normal = (rec.p - ld3(real_obj.sphere.center)) / real_obj.sphere.radius;
+        rec.mtrlid = isect.mtrlid;
+        const float radius = real_obj.sphere.radius;
+        rec.area = 4 * PI * radius * radius;
+        const float phi = std::asin(rec.normal.y);
+        const float theta = std::atan(rec.normal.x / rec.normal.z);
+        rec.u = (theta + PI * 0.5F) / PI;
+        rec.v = (phi + PI * 0.5F) / PI;
+    }
 
     rec.p = mtx_L2W.apply(rec.p);
     rec.normal = normalize(mtx_L2W.applyXYZ(rec.normal));

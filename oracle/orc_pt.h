@@ -493,7 +493,35 @@ inline void AreaLight_sample(LightSampleResult& result, const atn_light_param& p
     // evaluate SamplePosAndNormal (EvaluateHitResult.h:74-111) -> PolygonObject::SamplePosAndNormal
     // (PolygonObject.h:113-156) -> triangle::SamplePosAndNormal (triangle.h:122-162)
     const atn_object_param& real_obj = obj.type == ATN_OBJ_INSTANCE ? ctxt.GetObject(obj.object_id) : obj;
-    if (real_obj.type != ATN_OBJ_POLYGONS) return;   // sphere lights: out of scope
+    if (real_obj.type == ATN_OBJ_SPHERE) {
+        // sphere::SamplePosAndNormal (geometry/sphere.cpp:109-150): result.triangle_id stays -1, so
+        // AreaLight::sample falls to sphere::hit along the ray towards the sampled point (arealight.h:105-116)
+        const float r1 = sampler->nextSample();
+        const float r2 = sampler->nextSample();
+        const float rad = real_obj.sphere.radius;
+        const v3 center = ld3(real_obj.sphere.center);
+        const float z = 2.0F * r1 - 1.0F;
+        const float sin_theta = std::sqrt(1 - z * z);
+        const float phi = 2 * PI * r2;
+        const float x = std::cos(phi) * sin_theta;
+        const float y = std::sin(phi) * sin_theta;
+        v3 sdir = normalize(v3(x, y, z));
+        const v3 pos = center + sdir * (rad + EPS);
+        Ray ray(org, pos - org);
+        Isect isect;
+        if (!sphere_hit(obj, ray, EPS, INF, &isect)) return;
+        HitRec rec;
+        evaluate_hit_result(rec, obj, ctxt, ray, isect);
+        result.pos = rec.p;
+        result.pdf = 1 / rec.area;
+        result.dir = rec.p - org;
+        result.dist_to_light = length(result.dir);
+        result.dir = normalize(result.dir);
+        result.nml = rec.normal;
+        result.light_color = AreaLight_ComputeLightColor(param, rec.area);
+        return;
+    }
+    if (real_obj.type != ATN_OBJ_POLYGONS) return;
 
     float r = sampler->nextSample();
     uint32_t tri_idx = static_cast<uint32_t>(real_obj.triangle_num * r);

@@ -251,7 +251,7 @@ def test_spp_and_break_on_terminate_quirk(gpu, orc, cornell):
 
 
 
-@pytest.mark.parametrize("lights", ["area", "point", "spot", "directional", "mixed"])
+@pytest.mark.parametrize("lights", ["area", "point", "spot", "directional", "mixed", "sphere"])
 def test_transformed_instances_and_punctual_lights(gpu, orc, lights):
     """Instances with rotation + translation (W2L ray transform, L2W hit transform, area ratio), a Disney
     box, and every light type of light_impl.h:12-43 that consumes no texture."""

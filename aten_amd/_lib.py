@@ -13,7 +13,7 @@ _lib = None
 K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sample", "gather"]
 
 SYMBOLS = [
-    "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera",
+    "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera", "atn_update_tlas",
     "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
     "atn_assemble_tiles", "atn_download_film", "atn_get_stats", "atn_get_kernel_times",
@@ -45,6 +45,7 @@ def lib():
         l.atn_last_error.argtypes = [vp]; l.atn_last_error.restype = C.c_char_p
         l.atn_upload_scene.argtypes = [vp, vp]
         l.atn_update_camera.argtypes = [vp, vp]
+        l.atn_update_tlas.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
         l.atn_init_sampler.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         l.atn_set_random.argtypes = [vp, vp, C.c_uint32]
         l.atn_set_screen_shard.argtypes = [vp, C.c_int32, C.c_int32]

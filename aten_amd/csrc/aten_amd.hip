@@ -63,6 +63,8 @@ public:
     DevBuf<DevTexture> textures;
     DevScene scene{};
     bool has_scene = false, has_camera = false;
+    std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
+    uint32_t top_base = 0, n_host_matrices = 0;
     atn_camera_param camera{};
 
     // sampler
@@ -132,8 +134,60 @@ public:
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.textures = textures.p;
         has_scene = true;
+        list_root_link = img.list_root_link;
+        top_base = img.list_root[0];
+        n_host_matrices = s->n_matrices;
         use_refill = img.nodes.size() / 3 >= kRefillMinNodes;
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) use_refill = (e[0] == 'r');   // 'r'efill / 's'imple: experiments
+        return ATN_OK;
+    }
+
+    // ≙ idaten::Renderer::updateBVH, src/libidaten/kernel/renderer.cpp:133-153: new object parameters and matrices
+    // plus a rebuilt top layer; the bottom-level lists stay where they are in HBM.
+    int updateBVH(const atn_object_param* objs, uint32_t n_objs, const atn_mat4* mtxs, uint32_t n_mtxs,
+                  const atn_bvh_node* top, uint32_t n_top)
+    {
+        if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+        if (!objs || n_objs == 0 || !top || n_top == 0) return fail(ATN_ERR_INVALID_ARG, "empty object or top-layer array");
+        ATN_HIP(hipSetDevice(device));
+        if ((uint64_t)(top_base + n_top) * kNodeBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
+        ListEmitCtx c;
+        c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
+        c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
+        c.top = true;
+        std::vector<float4> rec((size_t)n_top * 3);
+        std::string err;
+        int32_t root = kLinkEnd;
+        uint64_t counts[3] = { 0, 0, 0 };
+        if (!emit_list(rec.data(), top, n_top, top_base, c, root, counts, err)) return fail(ATN_ERR_UNSUPPORTED, err);
+        const size_t need = ((size_t)top_base + n_top) * 3;
+        if (need > nodes.n) {
+            // grow: keep the bottom-level lists (device-to-device), drop the old top layer
+            float4* bigger = nullptr;
+            ATN_HIP(hipMalloc((void**)&bigger, need * sizeof(float4)));
+            hipError_t e = hipMemcpyAsync(bigger, nodes.p, (size_t)top_base * 3 * sizeof(float4), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { (void)hipFree(bigger); return fail(ATN_ERR_HIP, hipGetErrorString(e)); }
+            nodes.release();
+            nodes.p = bigger; nodes.n = need;
+        }
+        ATN_HIP(hipMemcpyAsync(nodes.p + (size_t)top_base * 3, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
+        std::vector<atn_object_param> ov(objs, objs + n_objs);
+        ATN_HIP(objects.upload(ov, stream));
+        std::vector<float4> mv;
+        if (n_mtxs) {
+            if (!mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
+            mv.resize((size_t)n_mtxs * 4);
+            for (uint32_t i = 0; i < n_mtxs; i++)
+                for (int r = 0; r < 4; r++)
+                    mv[4 * (size_t)i + r] = make_float4(mtxs[i].m[r][0], mtxs[i].m[r][1], mtxs[i].m[r][2], mtxs[i].m[r][3]);
+            ATN_HIP(matrices.upload(mv, stream));
+            n_host_matrices = n_mtxs;
+        }
+        ATN_HIP(hipStreamSynchronize(stream));
+        list_root_link[0] = root;
+        scene.root_link = root;
+        scene.nodes = nodes.p; scene.objects = objects.p; scene.matrices = matrices.p;
         return ATN_OK;
     }
 
@@ -391,6 +445,13 @@ int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene)
 }
 
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAIL(ctx); return ctx->r.updateCamera(camera); }
+
+int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
+                    const atn_bvh_node* top_nodes, uint32_t n_top_nodes)
+{
+    CTX_OR_FAIL(ctx);
+    return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes);
+}
 int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_OR_FAIL(ctx); return ctx->r.initSampler(w, h, seed); }
 int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_OR_FAIL(ctx); return ctx->r.setRandom(seeds, n); }
 

@@ -12,7 +12,8 @@ namespace atn {
 
 struct HostSceneImage {
     std::vector<float4> nodes;          // 3 per node
-    std::vector<uint32_t> list_root;    // absolute index of each list's root
+    std::vector<uint32_t> list_root;    // absolute index of each list's first node
+    std::vector<int32_t> list_root_link; // typed link of each list's root
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
     std::vector<atn_object_param> objects;
@@ -46,100 +47,127 @@ inline bool walk_order(const atn_bvh_node* nodes, uint32_t count, std::vector<in
     return true;
 }
 
-inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err)
+// What a list's records need from the rest of the scene.
+struct ListEmitCtx {
+    const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
+    const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0;
+    const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
+    bool top = false;
+};
+
+// Emits the device records of one threaded list in walk order at absolute node index `base`.
+// Returns the typed link of the list's root through `root_link`.
+inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint32_t base, const ListEmitCtx& c,
+                      int32_t& root_link, uint64_t counts[3], std::string& err)
 {
-    if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
-    const uint32_t nl = s->n_bvh_lists;
-
-    // ---- pass 1: walk orders and absolute offsets
-    std::vector<std::vector<int32_t>> new_index(nl);
-    std::vector<std::vector<uint32_t>> order(nl);
-    img.list_root.assign(nl, 0);
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < nl; k++) {
-        if (!walk_order(s->bvh_lists[k].nodes, s->bvh_lists[k].count, new_index[k], order[k], err)) return false;
-        img.list_root[k] = total;
-        total += (uint32_t)order[k].size();
-    }
-    if (total >= (1u << 24)) { err = "more than 2^24 BVH nodes: float-encoded links would lose precision"; return false; }
-    img.nodes.assign((size_t)total * 3, make_float4(0, 0, 0, 0));
-
-    auto type_bits = [&](uint32_t k, uint32_t old_idx) -> int32_t {
-        const atn_bvh_node& n = s->bvh_lists[k].nodes[old_idx];
+    std::vector<int32_t> new_index;
+    std::vector<uint32_t> order;
+    if (!walk_order(src, count, new_index, order, err)) return false;
+    auto type_bits = [&](uint32_t old_idx) -> int32_t {
+        const atn_bvh_node& n = src[old_idx];
         if (!(n.f0 >= 0 || n.f1 >= 0)) return 0;        // inner
         if (n.f2 >= 0) return kLinkTlasBit;             // nested tree
         if (n.f1 >= 0) return kLinkLeafBit;             // triangle
         return 0;                                       // dead leaf: handled on the inner path by its tag
     };
-    // typed link of a (list, float link): kLinkEnd, or absolute index | leaf bit; -2 = invalid
-    auto remap = [&](uint32_t k, float link) -> int32_t {
+    // typed link of a float link: kLinkEnd, or absolute byte offset | type bits; -2 = invalid
+    auto remap = [&](float link) -> int32_t {
         const int32_t l = (int32_t)link;
         if (l < 0) return kLinkEnd;
-        if ((uint32_t)l >= s->bvh_lists[k].count || new_index[k][l] < 0) return -2;
-        const int32_t abs = (int32_t)img.list_root[k] + new_index[k][l];
-        return (int32_t)((uint32_t)abs * kNodeBytes) | type_bits(k, (uint32_t)l);
+        if ((uint32_t)l >= count || new_index[l] < 0) return -2;
+        const int32_t abs = (int32_t)base + new_index[l];
+        return (int32_t)((uint32_t)abs * kNodeBytes) | type_bits((uint32_t)l);
     };
-    if ((uint64_t)total * kNodeBytes >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
-
-    // ---- pass 2: emit device records
-    for (uint32_t k = 0; k < nl; k++) {
-        const atn_bvh_node* src = s->bvh_lists[k].nodes;
-        for (uint32_t j = 0; j < order[k].size(); j++) {
-            const atn_bvh_node& n = src[order[k][j]];
-            const uint32_t abs = img.list_root[k] + j;
-            float4& q0 = img.nodes[3 * (size_t)abs + 0];
-            float4& q1 = img.nodes[3 * (size_t)abs + 1];
-            float4& q2 = img.nodes[3 * (size_t)abs + 2];
-            const int32_t h = remap(k, n.hit), m = remap(k, n.miss);
-            if (h == -2 || m == -2) { err = "BVH link points to an unreachable node"; return false; }
-            const bool leaf = (n.f0 >= 0 || n.f1 >= 0);         // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
-            if (!leaf) {
-                if (h == kLinkEnd || ((uint32_t)h & kLinkOffsetMask) != (abs + 1) * kNodeBytes) { err = "inner node whose hit link is not the next node in walk order"; return false; }
-                q0 = make_float4(n.boxmin[0], n.boxmin[1], n.boxmin[2], i2f(h & kLinkTypeMask));
-                q1 = make_float4(n.boxmax[0], n.boxmax[1], n.boxmax[2], i2f(m));
-                img.n_inner++;
+    root_link = count ? remap(0.0F) : kLinkEnd;
+    for (uint32_t j = 0; j < order.size(); j++) {
+        const atn_bvh_node& n = src[order[j]];
+        const uint32_t abs = base + j;
+        float4& q0 = out[3 * (size_t)j + 0];
+        float4& q1 = out[3 * (size_t)j + 1];
+        float4& q2 = out[3 * (size_t)j + 2];
+        q0 = q1 = q2 = make_float4(0, 0, 0, 0);
+        const int32_t h = remap(n.hit), m = remap(n.miss);
+        if (h == -2 || m == -2) { err = "BVH link points to an unreachable node"; return false; }
+        const bool leaf = (n.f0 >= 0 || n.f1 >= 0);         // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
+        if (!leaf) {
+            if (h == kLinkEnd || ((uint32_t)h & kLinkOffsetMask) != (abs + 1) * kNodeBytes) { err = "inner node whose hit link is not the next node in walk order"; return false; }
+            q0 = make_float4(n.boxmin[0], n.boxmin[1], n.boxmin[2], i2f(h & kLinkTypeMask));
+            q1 = make_float4(n.boxmax[0], n.boxmax[1], n.boxmax[2], i2f(m));
+            counts[0]++;
+        }
+        else if (n.f2 >= 0) {
+            // nested tree (exid bit-field, threaded_bvh.h:29-37)
+            if (!c.top) { err = "nested BVH reference inside a bottom-level list"; return false; }
+            const int32_t objid = (int32_t)n.f0;
+            if (objid < 0 || (uint32_t)objid >= c.n_objects) { err = "TLAS leaf object id out of range"; return false; }
+            const uint32_t bits = f2u(n.f2);
+            const int32_t exid = ATN_EXID_MAIN(bits);
+            if (exid <= 0 || (uint32_t)exid >= c.n_lists || c.list_root_link[exid] == kLinkEnd) { err = "TLAS leaf references a missing BLAS list"; return false; }
+            const atn_object_param& obj = c.objects[objid];
+            int32_t w2l_row = -1;
+            if (obj.mtx_id >= 0) {
+                if ((uint32_t)obj.mtx_id + 1 >= c.n_matrices) { err = "object matrix index out of range"; return false; }
+                w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
             }
-            else if (n.f2 >= 0) {
-                // nested tree (exid bit-field, threaded_bvh.h:29-37)
-                if (k != 0) { err = "nested BVH reference inside a bottom-level list"; return false; }
-                const int32_t objid = (int32_t)n.f0;
-                if (objid < 0 || (uint32_t)objid >= s->n_objects) { err = "TLAS leaf object id out of range"; return false; }
-                const uint32_t bits = f2u(n.f2);
-                const int32_t exid = ATN_EXID_MAIN(bits);
-                if (exid <= 0 || (uint32_t)exid >= nl || order[exid].empty()) { err = "TLAS leaf references a missing BLAS list"; return false; }
-                const atn_object_param& obj = s->objects[objid];
-                int32_t w2l_row = -1;
-                if (obj.mtx_id >= 0) {
-                    if ((uint32_t)obj.mtx_id + 1 >= s->n_matrices) { err = "object matrix index out of range"; return false; }
-                    w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
-                }
-                const int32_t root = remap((uint32_t)exid, 0.0F);
-                q0 = make_float4(i2f(objid), i2f(w2l_row), i2f(root), 0.0F);
-                q1 = make_float4(i2f((int32_t)n.f3), i2f(h), i2f(m), 0.0F);
-                img.n_tlas_leaf++;
-            }
-            else if (n.f1 >= 0) {
-                const uint32_t tri = (uint32_t)n.f1;
-                if (tri >= s->n_triangles) { err = "leaf triangle id out of range"; return false; }
-                if (h != m) { err = "triangle leaf with hit != miss link"; return false; }
-                const atn_triangle_param& t = s->triangles[tri];
-                const atn_vec4& a = s->vtx_pos[t.idx[0]];
-                const atn_vec4& b = s->vtx_pos[t.idx[1]];
-                const atn_vec4& c = s->vtx_pos[t.idx[2]];
-                // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions intersectTriangle performs
-                // per test (math/intersect.h:61-62), hoisted to upload time.
-                q0 = make_float4(a.x, a.y, a.z, i2f((int32_t)tri));
-                q1 = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, i2f(h));
-                q2 = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0F);
-                img.n_tri_leaf++;
-            }
-            else {
-                // leaf without triangle or nested tree (sphere instance): never tested on this path
-                q0 = make_float4(0, 0, 0, i2f(kTagDead));
-                q1 = make_float4(0, 0, 0, i2f(m));
-            }
+            q0 = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), 0.0F);
+            q1 = make_float4(i2f((int32_t)n.f3), i2f(h), i2f(m), 0.0F);
+            counts[2]++;
+        }
+        else if (n.f1 >= 0) {
+            if (!c.tris) { err = "triangle leaves in this list need a full scene upload"; return false; }
+            const uint32_t tri = (uint32_t)n.f1;
+            if (tri >= c.n_triangles) { err = "leaf triangle id out of range"; return false; }
+            if (h != m) { err = "triangle leaf with hit != miss link"; return false; }
+            const atn_triangle_param& t = c.tris[tri];
+            const atn_vec4& a = c.vtx_pos[t.idx[0]];
+            const atn_vec4& b = c.vtx_pos[t.idx[1]];
+            const atn_vec4& cc = c.vtx_pos[t.idx[2]];
+            // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions intersectTriangle performs
+            // per test (math/intersect.h:61-62), hoisted to upload time.
+            q0 = make_float4(a.x, a.y, a.z, i2f((int32_t)tri));
+            q1 = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, i2f(h));
+            q2 = make_float4(cc.x - a.x, cc.y - a.y, cc.z - a.z, 0.0F);
+            counts[1]++;
+        }
+        else {
+            // leaf without triangle or nested tree (sphere instance): never tested on this path
+            q0 = make_float4(0, 0, 0, i2f(kTagDead));
+            q1 = make_float4(0, 0, 0, i2f(m));
         }
     }
+    return true;
+}
+
+// Node image = [BLAS list 1][BLAS list 2]...[top layer (list 0)]: the top layer comes last so that
+// update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it without moving the others.
+inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err)
+{
+    if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
+    const uint32_t nl = s->n_bvh_lists;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < nl; k++) total += s->bvh_lists[k].count;
+    if (total * kNodeBytes >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
+    img.nodes.assign((size_t)total * 3, make_float4(0, 0, 0, 0));
+    img.list_root.assign(nl, 0);
+    img.list_root_link.assign(nl, kLinkEnd);
+
+    ListEmitCtx c;
+    c.objects = s->objects; c.n_objects = s->n_objects; c.n_matrices = s->n_matrices;
+    c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles;
+    c.n_lists = nl;
+    uint64_t counts[3] = { 0, 0, 0 };
+    uint32_t base = 0;
+    for (uint32_t k = 1; k <= nl; k++) {
+        const uint32_t list = k % nl;       // 1, 2, ..., nl-1, 0
+        c.top = (list == 0);
+        c.list_root_link = img.list_root_link.data();
+        img.list_root[list] = base;
+        int32_t root = kLinkEnd;
+        if (!emit_list(img.nodes.data() + 3 * (size_t)base, s->bvh_lists[list].nodes, s->bvh_lists[list].count, base, c, root, counts, err)) return false;
+        img.list_root_link[list] = root;
+        base += s->bvh_lists[list].count;
+    }
+    img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
 
     // ---- plain copies
     img.tris.assign(s->triangles, s->triangles + s->n_triangles);
@@ -188,7 +216,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     }
 
     DevScene& p = img.params;
-    p.root_link = remap(0, 0.0F);
+    p.root_link = img.list_root_link[0];
     p.n_lights = (int32_t)s->n_lights; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
     p.bvh_hit_min = s->config.bvh_hit_min;
     p.bg_color[0] = s->config.bg.bg_color[0]; p.bg_color[1] = s->config.bg.bg_color[1]; p.bg_color[2] = s->config.bg.bg_color[2];

@@ -48,6 +48,16 @@ class PathTracing:
     def UpdateSceneData(self, scene):
         self._check(self._l.atn_upload_scene(self._ctx, C.cast(scene.ref(), C.c_void_p)))
 
+    def updateBVH(self, scene):
+        """idaten::Renderer::updateBVH (renderer.cpp:133-153): objects, matrices and the top layer of `scene`
+        (a FlatScene whose bottom-level lists are the ones already uploaded)."""
+        a = scene.arrays
+        objs = np.ascontiguousarray(a["objects"])
+        mtx = np.ascontiguousarray(a["matrices"])
+        top = np.ascontiguousarray(a["bvh_lists"][0])
+        self._check(self._l.atn_update_tlas(self._ctx, objs.ctypes.data, len(objs), mtx.ctypes.data if len(mtx) else None,
+                                            len(mtx), top.ctypes.data, len(top)))
+
     def updateCamera(self, cam):
         self._check(self._l.atn_update_camera(self._ctx, cam.ctypes.data))
 

@@ -177,6 +177,7 @@ class SceneBuilder:
                 if cur_obj is None:
                     cur_obj = new_obj(sh.name)
                 self.objects[cur_obj]["meshes"].append(mesh)
+                self.objects[cur_obj]["name"] = sh.name
                 objs.append(cur_obj)
                 cur_obj = new_obj("") if si + 1 < len(shapes) else None
             else:

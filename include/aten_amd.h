@@ -59,6 +59,14 @@ const char* atn_last_error(atn_ctx* ctx);
  * scene to HBM (and re-lays-out the BVH).  The caller keeps ownership of `scene`. */
 int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene);
 
+/* ≙ idaten::Renderer::updateBVH (src/libidaten/kernel/renderer.cpp:133-153): new ObjectParameters and
+ * matrices (aten::context::GetObjectParametersAndMatrices) and a rebuilt TOP layer (`nodes[0]`); the
+ * bottom-level lists uploaded by atn_upload_scene stay in place.  n_matrices == 0 keeps the old
+ * matrices, like the reference.  The list indices in the leaves' exid refer to the uploaded lists. */
+int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects,
+                    const atn_mat4* matrices, uint32_t n_matrices,
+                    const atn_bvh_node* top_nodes, uint32_t n_top_nodes);
+
 /* ≙ idaten::Renderer::updateCamera (renderer.cpp:202-205). */
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
 

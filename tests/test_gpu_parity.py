@@ -272,6 +272,45 @@ def test_transformed_instances_and_punctual_lights(gpu, orc, lights):
     assert np.nanmax(got[..., :3]) > 0.0
 
 
+def test_update_top_layer_equals_full_upload(gpu, orc):
+    """atn_update_tlas (idaten::Renderer::updateBVH, renderer.cpp:133-153): moving the instanced boxes through
+    an object/matrix/top-layer update gives the same bytes as uploading the moved scene from scratch, also
+    when the new top layer is larger than the old one (buffer growth) and smaller again."""
+    from aten_amd.scene import scenedefs
+    from aten_amd import layout as L
+    still = scenedefs.cornell_box_variant(lights="area", move_boxes=False)
+    moved = scenedefs.cornell_box_variant(lights="area", move_boxes=True)
+    fs_m, c, seeds = _setup(gpu, orc, moved, 80, 80)
+    full = gpu.render(80, 80, 5, 3, frame=2)
+    rays = orc.generate_paths(c, seeds, 80, 80, 0, 0)
+    want_i, _ = orc.trace_closest(fs_m, rays)
+
+    fs_s, c, seeds = _setup(gpu, orc, still, 80, 80)
+    base = gpu.render(80, 80, 5, 3, frame=2)
+    assert base.tobytes() != full.tobytes()
+    gpu.updateBVH(fs_m)
+    gpu.reset()
+    upd = gpu.render(80, 80, 5, 3, frame=2)
+    assert upd.tobytes() == full.tobytes()
+    got_i, _ = gpu.trace_closest(rays, stats=True)
+    assert got_i.tobytes() == want_i.tobytes()
+
+    # padded top layer (unreachable tail nodes): forces the node buffer to grow, result unchanged
+    import copy
+    padded = copy.copy(fs_m)
+    padded.arrays = dict(fs_m.arrays)
+    top = fs_m.arrays["bvh_lists"][0]
+    pad = np.zeros(4096, dtype=top.dtype)
+    for f in ("f0", "f1", "f2", "f3", "hit", "miss"):
+        pad[f] = -1.0
+    padded.arrays["bvh_lists"] = [np.concatenate([top, pad])] + list(fs_m.arrays["bvh_lists"][1:])
+    gpu.updateBVH(padded)
+    gpu.reset()
+    assert gpu.render(80, 80, 5, 3, frame=2).tobytes() == full.tobytes()
+    gpu.updateBVH(fs_s)
+    gpu.reset()
+    assert gpu.render(80, 80, 5, 3, frame=2).tobytes() == base.tobytes()
+
 
 # ---- size-independent properties at BASELINE's full sizes ---------------------------------------
 def test_full_size_properties_1080p(gpu, orc, cornell):

@@ -61,12 +61,19 @@ ATN_DEV bool slab_hit_exact(const RaySlab& s, const f3& bmin, const f3& bmax, fl
 // Same test with hardware min/max.  With finite invdir / oxinvdir and finite boxes no NaN can
 // arise (finite * finite + finite is finite or +-inf), and for non-NaN operands v_max/v_min equal
 // the select form except for the sign of a zero, which `t0 <= t1` cannot see.
+// The instructions are spelled out: through fminf/fmaxf the compiler prepends a canonicalising
+// `v_max_f32 x, x, x` to every operand (IEEE mode, operands not provably quiet), 8 extra VALU per node.
+ATN_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+ATN_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+ATN_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+ATN_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 ATN_DEV bool slab_hit_fast(const RaySlab& s, const f3& bmin, const f3& bmax, float t_min, float t_max)
 {
     const f3 f = bmax * s.invdir + s.oxinvdir;
     const f3 n = bmin * s.invdir + s.oxinvdir;
-    const float t1 = fminf(fminf(fminf(fmaxf(f.x, n.x), fmaxf(f.y, n.y)), fmaxf(f.z, n.z)), t_max);
-    const float t0 = fmaxf(fmaxf(fmaxf(fminf(f.x, n.x), fminf(f.y, n.y)), fminf(f.z, n.z)), t_min);
+    const float t1 = hw_min3(hw_min(hw_max(f.x, n.x), hw_max(f.y, n.y)), hw_max(f.z, n.z), t_max);
+    const float t0 = hw_max3(hw_max(hw_min(f.x, n.x), hw_min(f.y, n.y)), hw_min(f.z, n.z), t_min);
     return t0 <= t1;
 }
 

@@ -222,24 +222,30 @@ class SceneBuilder:
         nm = self.load_image(os.path.join(base, m.bump_texname)) if m.bump_texname else -1
         return self.add_material(m.name, L.MTRL_DIFFUSE, m.diffuse, albedo_map=alb, normal_map=nm)
 
-    def add_mesh(self, name, positions, indices, mtrl, normals=None, uvs=None, need_normal=True):
-        """Programmatic PolygonObject (one TriangleGroupMesh).  positions [N,3], indices [M,3]."""
+    def add_mesh(self, name, positions, indices, mtrl, normals=None, uvs=None, need_normal=True, into=None):
+        """Programmatic PolygonObject (one TriangleGroupMesh).  positions [N,3], indices [M,3].  `into` appends
+        the mesh to an existing polygon object (several materials in one object, like a loaded OBJ)."""
         positions = np.asarray(positions, F32)
         indices = np.asarray(indices, np.int64)
-        self.objects.append(dict(type=L.OBJ_POLYGONS, name=name, meshes=[], first_tri=None))
-        oid = len(self.objects) - 1
+        if into is None:
+            self.objects.append(dict(type=L.OBJ_POLYGONS, name=name, meshes=[], first_tri=None))
+            oid = len(self.objects) - 1
+        else:
+            oid = into
         mesh = dict(tris=[], mtrl=mtrl, mesh_id=self._next_mesh_id())
-        for tri in indices:
-            base_v = len(self.pos)
-            for k in tri:
-                p = positions[k]
-                n = normals[k] if normals is not None else (0.0, 1.0, 0.0)
-                uv = uvs[k] if uvs is not None else (0.0, 0.0)
-                self.pos.append((p[0], p[1], p[2], uv[0]))
-                self.nml.append((n[0], n[1], n[2], uv[1]))
-            self.tris.append(dict(idx=(base_v, base_v + 1, base_v + 2), needNormal=1 if need_normal else 0,
-                                  mtrlid=mtrl, mesh_id=mesh["mesh_id"]))
-            mesh["tris"].append(len(self.tris) - 1)
+        flat = indices.reshape(-1)
+        P = positions[flat]
+        Nn = np.asarray(normals, F32)[flat] if normals is not None else np.tile(np.array([0, 1, 0], F32), (len(flat), 1))
+        UV = np.asarray(uvs, F32)[flat] if uvs is not None else np.zeros((len(flat), 2), F32)
+        base_v = len(self.pos)
+        self.pos.extend(map(tuple, np.concatenate([P, UV[:, :1]], axis=1).tolist()))
+        self.nml.extend(map(tuple, np.concatenate([Nn, UV[:, 1:2]], axis=1).tolist()))
+        first = len(self.tris)
+        nn = 1 if need_normal else 0
+        mid = mesh["mesh_id"]
+        self.tris.extend(dict(idx=(base_v + 3 * i, base_v + 3 * i + 1, base_v + 3 * i + 2), needNormal=nn,
+                              mtrlid=mtrl, mesh_id=mid) for i in range(len(indices)))
+        mesh["tris"] = list(range(first, first + len(indices)))
         self.objects[oid]["meshes"].append(mesh)
         self.blas[oid] = None
         return oid

@@ -179,3 +179,136 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
     b.set_background((0.02, 0.03, 0.05))
     cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)
     return b.build(), cam
+
+
+# ---------------------------------------------------------------------------------------------------
+# Procedural stand-in for BASELINE config 4 (Crytek Sponza: sponza.obj/.sbvh are missing blobs)
+# ---------------------------------------------------------------------------------------------------
+def _grid_mesh(fn, nu, nv, uv_scale=(1.0, 1.0), flip=False):
+    """Tessellated parametric surface: fn(u, v) -> xyz for u, v in [0,1] (arrays).  Smooth vertex normals
+    from central differences; two triangles per cell."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    P = fn(U, V).astype(np.float64)
+    e = 1e-4
+    du = fn(np.clip(U + e, 0, 1), V) - fn(np.clip(U - e, 0, 1), V)
+    dv = fn(U, np.clip(V + e, 0, 1)) - fn(U, np.clip(V - e, 0, 1))
+    N = np.cross(du.reshape(-1, 3), dv.reshape(-1, 3))
+    N /= np.maximum(np.linalg.norm(N, axis=1, keepdims=True), 1e-20)
+    if flip:
+        N = -N
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b_, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tri = np.concatenate([np.stack([a, b_, c], 1), np.stack([a, c, d], 1)]) if not flip else \
+        np.concatenate([np.stack([a, c, b_], 1), np.stack([a, d, c], 1)])
+    uv = np.stack([U.ravel() * uv_scale[0], V.ravel() * uv_scale[1]], 1)
+    return P.reshape(-1, 3).astype(np.float32), N.astype(np.float32), uv.astype(np.float32), tri
+
+
+def _icosphere(level):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(i, j):
+            k = (min(i, j), max(i, j))
+            if k not in cache:
+                m = v[i] + v[j]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for (a, b_, c) in f:
+            ab, bc, ca = mid(a, b_), mid(b_, c), mid(c, a)
+            nf += [(a, ab, ca), (b_, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v, np.float64), np.asarray(f, np.int64)
+
+
+def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
+    """Procedural colonnaded hall, ~250 k unique triangles (+ 6 instances of a 20 k-triangle statue), Disney
+    materials with the Sponza albedo / normal-map textures, IBL + one polygon area light.  Stand-in for
+    BASELINE config 4 "Crytek Sponza 4K 8spp 8-bounce Disney + textures" (≈262 k triangles), whose
+    geometry blob is absent; deterministic (no RNG).  `detail` scales the tessellation."""
+    asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
+    b = SceneBuilder()
+
+    def tex(name):
+        return b.load_image(os.path.join(asset_dir, name))
+
+    def mtrl(name, clr, alb, nm, **kw):
+        if mtype == L.MTRL_DISNEY:
+            std = dict(roughness=0.5, metallic=0.0, specular=0.5, clearcoat=0.0, clearcoatGloss=0.5, sheen=0.0)
+            std.update(kw)
+            return b.add_material(name, L.MTRL_DISNEY, clr, albedo_map=tex(alb) if alb else -1,
+                                  normal_map=tex(nm) if nm else -1, **std)
+        return b.add_material(name, mtype, clr, albedo_map=tex(alb) if alb else -1, normal_map=tex(nm) if nm else -1,
+                              roughness=kw.get("roughness", 0.3), ior=0.01)
+
+    m_floor = mtrl("floor", (0.8, 0.8, 0.8), "KAMEN.JPG", "KAMEN-nml.png", roughness=0.25, specular=0.7, clearcoat=0.3)
+    m_wall = mtrl("wall", (0.8, 0.8, 0.8), "01_STUB.JPG", "01_STUB-nml.png", roughness=0.7)
+    m_col = mtrl("column", (0.8, 0.8, 0.8), "sp_luk.JPG", "sp_luk-nml.png", roughness=0.55, sheen=0.2)
+    m_gold = mtrl("statue", (0.9, 0.7, 0.3), None, None, roughness=0.3, metallic=0.9, specular=0.8)
+    m_emit = b.add_material("lamp", L.MTRL_EMISSIVE, (1.0, 0.95, 0.9))
+
+    def n(x):
+        return max(2, int(round(x * detail)))
+
+    X, Z, H = 8.0, 4.0, 6.0
+    # floor: gentle relief
+    P, N, UV, T = _grid_mesh(lambda u, v: np.stack([(2 * u - 1) * X, 0.02 * np.sin(37.0 * u) * np.cos(23.0 * v)
+                                                    + 0.01 * np.sin(211.0 * u + 89.0 * v), (1 - 2 * v) * Z], -1),
+                             n(320), n(160), uv_scale=(8.0, 4.0))
+    hall = b.add_mesh("hall", P, T, m_floor, normals=N, uvs=UV, need_normal=False)
+    # walls with brick-like relief; inward-facing
+    def wall(axis, sign):
+        def fn(u, v):
+            relief = 0.03 * np.sin(60.0 * u) * np.sin(40.0 * v) + 0.015 * np.sin(170.0 * u + 130.0 * v)
+            if axis == "z":
+                return np.stack([(2 * u - 1) * X * sign, v * H, np.full_like(u, sign * Z) - sign * relief], -1)
+            return np.stack([np.full_like(u, sign * X) - sign * relief, v * H, (1 - 2 * u) * Z * sign], -1)
+        return _grid_mesh(fn, n(160), n(64), uv_scale=(6.0, 3.0))
+    for axis, sign in (("z", 1.0), ("z", -1.0), ("x", 1.0), ("x", -1.0)):
+        P, N, UV, T = wall(axis, sign)
+        b.add_mesh("wall", P, T, m_wall, normals=N, uvs=UV, need_normal=False, into=hall)
+    # fluted columns
+    for side in (-1.0, 1.0):
+        for k in range(6):
+            cx, cz = -6.25 + 2.5 * k, side * 2.3
+
+            def col(u, v, cx=cx, cz=cz):
+                ang = 2 * np.pi * u
+                r = 0.28 + 0.02 * np.cos(16 * ang) + 0.06 * np.exp(-40.0 * v) + 0.06 * np.exp(-40.0 * (1 - v))
+                return np.stack([cx + r * np.cos(ang), v * 5.0, cz - r * np.sin(ang)], -1)
+            P, N, UV, T = _grid_mesh(col, n(48), n(40), uv_scale=(2.0, 5.0))
+            b.add_mesh("column", P, T, m_col, normals=N, uvs=UV, need_normal=False, into=hall)
+    # lamp: one quad under the open roof
+    lamp_p = np.array([[-1.0, 5.6, -0.6], [1.0, 5.6, -0.6], [1.0, 5.6, 0.6], [-1.0, 5.6, 0.6]], np.float32)
+    lamp = b.add_mesh("lamp", lamp_p, [[0, 1, 2], [0, 2, 3]], m_emit)
+    # statue: displaced icosphere, instanced
+    V, F = _icosphere(5 if detail >= 1.0 else 3)
+    disp = 1.0 + 0.12 * np.sin(7.0 * V[:, 0]) * np.sin(9.0 * V[:, 1]) * np.sin(5.0 * V[:, 2]) + 0.05 * np.sin(23.0 * V[:, 1])
+    SP = (V * disp[:, None]).astype(np.float32)
+    statue = b.add_mesh("statue", SP, F, m_gold, need_normal=True)
+
+    def trs(scale, deg, t):
+        c, s_ = np.cos(np.radians(deg)), np.sin(np.radians(deg))
+        return np.array([[c * scale, 0, s_ * scale, t[0]], [0, scale, 0, t[1]], [-s_ * scale, 0, c * scale, t[2]],
+                         [0, 0, 0, 1]], np.float32)
+
+    b.create_instance(hall)
+    li = b.create_instance(lamp)
+    b.add_area_light(li, (1.0, 0.95, 0.9), 60.0)
+    for k in range(6):
+        b.create_instance(statue, trs(0.45 + 0.05 * (k % 3), 30.0 * k, (-5.0 + 2.0 * k, 0.62 + 0.05 * (k % 3), (-1) ** k * 0.9)))
+    env = synthetic_envmap()
+    tid = b.add_texture("synthetic_sky_2048x1024", env)
+    b.add_ibl(tid, avg_illum=envmap_avg_illum(env))
+    cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
+    return b.build(), cam

@@ -57,7 +57,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scene", default="sponza", choices=["sponza", "cornell"])
+    ap.add_argument("--scene", default="sponza", choices=["sponza", "cornell", "atrium"])
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4"],
+                    help="BASELINE.json config shortcuts: c2 = Cornell 1080p 1spp 5-bounce, c3 = Sponza 1080p 1spp 5-bounce "
+                         "(default), c4 = 4K 8spp 8-bounce Disney + textures on the procedural atrium stand-in")
+    ap.add_argument("--all-samples", action="store_true",
+                    help="with spp > 1: trace every sample (the CPU reference stops a pixel's sample loop at the first "
+                         "terminated path, pathtracing.cpp:350-352; default reproduces that)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1)
@@ -67,6 +73,10 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
+    if args.config == "c2":
+        args.scene = "cornell"
+    elif args.config == "c4":
+        args.scene, args.width, args.height, args.spp, args.depth, args.all_samples = "atrium", 3840, 2160, 8, 8, True
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -94,9 +104,15 @@ def main():
     if args.scene == "sponza":
         fs, cam = scenedefs.sponza_lod()
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh (stand-in for missing sponza.obj)" % (W, H, spp, depth)
+    elif args.scene == "atrium":
+        fs, cam = scenedefs.atrium()
+        workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; stand-in for the missing "
+                    "Crytek Sponza blob) %dx%d %dspp %d-bounce%s" % (len(fs.arrays["triangles"]), W, H, spp, depth,
+                                                                 " all samples traced" if args.all_samples else ""))
     else:
         fs, cam = scenedefs.cornell_box()
         workload = "cornell box %dx%d %dspp %d-bounce NEE" % (W, H, spp, depth)
+    brk = not args.all_samples
     camera = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
 
     dev = "cuda:%d" % local_rank
@@ -111,7 +127,8 @@ def main():
     ext_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=dev) if use_dist else None
 
     def step(frame, profile):
-        r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, download=False, profile=profile)
+        r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
+                 profile=profile)
         if use_dist:
             # Exchange step: every rank contributes its tile buffer; no host synchronisation -- the collective
             # is issued from the renderer's own HIP stream (torch orders RCCL's stream against it with events),
@@ -160,7 +177,8 @@ def main():
     tot = dict(closest_rays=0, shadow_rays=0, hits=0, closest_nodes=0, closest_tris=0, shadow_nodes=0, shadow_tris=0)
     n_count = min(args.steps, 4)
     for i in range(n_count):
-        r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, download=False, count_stats=True)
+        r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False,
+                 count_stats=True)
         s = r.stats()
         for k in tot:
             tot[k] += s[k]
@@ -172,7 +190,7 @@ def main():
     launches_per_frame = tc_n / max(frames_prof, 1)
     avg_launch_ms = tc_ms / max(tc_n, 1)
     achieved = (bytes_per_frame / max(launches_per_frame, 1)) / (avg_launch_ms * 1e-3) / 1e9 if tc_n else 0.0
-    tr = measured_traffic("sponza_lod" if args.scene == "sponza" else "cornell", W, H) if world == 1 else None
+    tr = measured_traffic({"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene], W, H) if world == 1 else None
     roofline = {
         "kernel": "k_trace_closest", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -189,28 +207,42 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample of the same workload: same scene / camera / seeds at 1/3 linear resolution
         cw, ch = max(W // 3, 8), max(H // 3, 8)
+        if args.scene == "atrium":
+            cw, ch = max(W // 6, 8), max(H // 6, 8)
         ccam = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], cw, ch)
         cseeds = orc.init_sampler(cw, ch, 0)
-        orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=0)      # warm-up
-        ts = []
-        f = 0
-        t_all = time.perf_counter()
-        while (len(ts) < 5 or time.perf_counter() - t_all < 10.0) and time.perf_counter() - t_all < 30.0:
-            t1 = time.perf_counter()
-            orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f)
-            ts.append(time.perf_counter() - t1)
-            f += 1
-        med = float(np.median(ts))
+
+        def cpu_frame(f, nthreads=0):
+            if brk or spp == 1:
+                orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, nthreads=nthreads)
+            else:       # every sample traced: spp passes of one sample (same work as the GPU's all-samples mode)
+                for i in range(spp):
+                    orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=1, frame=f * spp + i, nthreads=nthreads)
+
+        def cpu_median(nthreads, min_frames, budget_s):
+            cpu_frame(0, nthreads)      # warm-up
+            ts = []
+            t_all = time.perf_counter()
+            while (len(ts) < min_frames or time.perf_counter() - t_all < budget_s / 3) and time.perf_counter() - t_all < budget_s:
+                t1 = time.perf_counter()
+                cpu_frame(len(ts), nthreads)
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts)), len(ts)
+
+        med, nfr = cpu_median(0, 5, 20.0)
+        med8, nfr8 = cpu_median(8, 2, 10.0)     # the reference app's own setting (host_renderer/main.cpp:18-23,271)
         cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": orc.lib().orc_num_procs(),
-                        "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305" % (cw, ch, len(ts)),
-                        "ms_per_frame_sample": round(1e3 * med, 2)}
+                        "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305" % (cw, ch, nfr),
+                        "ms_per_frame_sample": round(1e3 * med, 2),
+                        "value_8_threads": round(cw * ch * spp / 1e6 / med8, 4), "frames_8_threads": nfr8}
 
     if final_img is not None:
         np.save(args.dump, final_img)
 
     if rank == 0:
         out = {
-            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce",
+            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5))
+            else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

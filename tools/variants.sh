@@ -19,7 +19,7 @@ for f in glob.glob('/tmp/pmc_$name/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         acc[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in acc:
-    if 'trace_closest<false>' in k or 'k_shade' in k:
+    if 'trace_closest<false' in k or 'k_shade' in k:
         c=acc[k]; m=lambda n: sum(c[n])/max(len(c[n]),1)/1e6
         print('    %-40s VALU %.1fM SALU %.1fM VMEM %.2fM waves %d wavecyc %.0fM wait %.0fM valu_active %.0fM' % (k[-40:], m('SQ_INSTS_VALU'), m('SQ_INSTS_SALU'), m('SQ_INSTS_VMEM_RD'), m('SQ_WAVES')*1e6, m('SQ_WAVE_CYCLES'), m('SQ_WAIT_ANY'), m('SQ_ACTIVE_INST_VALU')))
 PY

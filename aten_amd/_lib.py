@@ -10,11 +10,14 @@ from . import build
 
 _lib = None
 
-K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sample", "gather"]
+K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sample", "gather",
+           "svgf_prepare", "svgf_temporal", "svgf_variance", "svgf_atrous"]
 
 SYMBOLS = [
     "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera", "atn_update_tlas",
     "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset",
+    "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
+    "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
     "atn_assemble_tiles", "atn_download_film", "atn_get_stats", "atn_get_kernel_times",
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples",
@@ -51,6 +54,15 @@ def lib():
         l.atn_set_screen_shard.argtypes = [vp, C.c_int32, C.c_int32]
         l.atn_render.argtypes = [vp, C.POINTER(Destination), vp]
         l.atn_reset.argtypes = [vp]
+        l.atn_svgf_render.argtypes = [vp, vp, C.c_int32, vp, vp]
+        l.atn_svgf_set_motion_depth.argtypes = [vp, vp, C.c_uint32]
+        l.atn_svgf_reset.argtypes = [vp]
+        l.atn_svgf_set_atrous_iterations.argtypes = [vp, C.c_int32]
+        l.atn_svgf_download.argtypes = [vp, C.c_int32, vp]
+        l.atn_svgf_denoise.argtypes = [vp, vp, C.c_int32, vp, vp]
+        l.atn_svgf_upload.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        l.atn_svgf_output_device.argtypes = [vp]
+        l.atn_svgf_output_device.restype = vp
         l.atn_film_device.argtypes = [vp]; l.atn_film_device.restype = vp
         l.atn_tile_device.argtypes = [vp]; l.atn_tile_device.restype = vp
         l.atn_tile_slots.argtypes = [vp]; l.atn_tile_slots.restype = C.c_uint32

@@ -15,6 +15,7 @@
 
 #include "../../include/aten_amd.h"
 #include "device/kernels.hpp"
+#include "device/svgf.hpp"
 #include "host/scene_upload.hpp"
 
 namespace atn {
@@ -370,7 +371,7 @@ public:
                 launch_trace<false>(pb, g_trace, count, b);
                 prof_end(prof);
                 prof_begin(prof, ATN_K_SHADE);
-                hipLaunchKernelGGL(k_shade, dim3(g_slots), dim3(256), 0, stream, pb, scene, fp, camera, b);
+                hipLaunchKernelGGL((k_shade<false>), dim3(g_slots), dim3(256), 0, stream, pb, scene, fp, camera, b, SvgfShade{});
                 prof_end(prof);
                 prof_begin(prof, ATN_K_TRACE_SHADOW);
                 launch_trace<true>(pb, g_trace, count, b);
@@ -393,6 +394,219 @@ public:
         }
         if (out_host || count) ATN_HIP(hipStreamSynchronize(stream));
         return ATN_OK;      // profiling spans are resolved lazily in kernel_times() (no sync in the frame loop)
+    }
+
+    // ------------------------------------------------------------------------------------------------
+    // SVGF (aten::SVGFRenderer, src/libaten/renderer/svgf/svgf.cpp): frame-persistent state = SVGFParams
+    // (svgf_types.h:54-166) + MatricesForRendering (pt_params.h:150-185)
+    // ------------------------------------------------------------------------------------------------
+    DevBuf<float4> sv_aov[2][4], sv_scratch, sv_atrous[2], sv_tmp, sv_motion, sv_primary, sv_contribs, sv_out, sv_stages;
+    float4* sv_cv[2] = { nullptr, nullptr };    // colour+variance of the two AOV sets (the variance pass swaps with sv_spare)
+    float4* sv_spare = nullptr;
+    int32_t sv_w = 0, sv_h = 0, sv_curr = 0, sv_atrous_iters = 5;
+    bool sv_motion_set = false;
+    float sv_W2V[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    float sv_V2C[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    float sv_prevW2V[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+
+    static void mat_mul(const float* a, const float* b, float* out)        // mat4::operator*=, mat4.h:140-156
+    {
+        float tmp[16];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 4; k++) acc += a[4 * i + k] * b[4 * k + j];
+                tmp[4 * i + j] = acc;
+            }
+        std::memcpy(out, tmp, sizeof(tmp));
+    }
+
+    // MatricesForRendering::Reset = Camera::ComputeCameraMatrices: mat4::lookat(origin, center, up) and
+    // mat4::perspective(znear, zfar, vfov, aspect) written into the existing matrices (mat4.h:457-513)
+    void svgf_reset_matrices()
+    {
+        std::memcpy(sv_prevW2V, sv_W2V, sizeof(sv_W2V));
+        const float* e = camera.origin; const float* at = camera.center; const float* up = camera.up;
+        float z[3] = { e[0] - at[0], e[1] - at[1], e[2] - at[2] };
+        float il = 1.0f / std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);        // glm::normalize = v * inversesqrt(dot(v, v))
+        z[0] *= il; z[1] *= il; z[2] *= il;
+        float x[3] = { up[1] * z[2] - z[1] * up[2], up[2] * z[0] - z[2] * up[0], up[0] * z[1] - z[0] * up[1] };
+        il = 1.0f / std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        x[0] *= il; x[1] *= il; x[2] *= il;
+        const float y[3] = { z[1] * x[2] - x[1] * z[2], z[2] * x[0] - x[2] * z[0], z[0] * x[1] - x[0] * z[1] };
+        float* m = sv_W2V;
+        m[0] = x[0]; m[4] = y[0]; m[8] = z[0];
+        m[1] = x[1]; m[5] = y[1]; m[9] = z[1];
+        m[2] = x[2]; m[6] = y[2]; m[10] = z[2];
+        m[3] = -(x[0] * e[0] + x[1] * e[1] + x[2] * e[2]);
+        m[7] = -(y[0] * e[0] + y[1] * e[1] + y[2] * e[2]);
+        m[11] = -(z[0] * e[0] + z[1] * e[1] + z[2] * e[2]);
+        m[15] = 1;
+        const float fH = 1 / std::tan((3.14159265358979323846F * (camera.vfov) / 180.0F) * 0.5f);
+        const float fW = fH / camera.aspect;
+        float* p = sv_V2C;
+        p[0] = fW; p[5] = fH;
+        p[10] = camera.zfar / (camera.znear - camera.zfar);
+        p[11] = camera.znear * camera.zfar / (camera.znear - camera.zfar);
+        p[14] = -1.0f; p[15] = 0.0f;
+    }
+
+    int svgf_fill(float4* p, size_t n, float4 v)
+    {
+        hipLaunchKernelGGL(k_svgf_fill, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, p, (uint32_t)n, v);
+        return ATN_OK;
+    }
+
+    // SVGFParams::InitBuffers: vec4() = (0, 0, 0, 1) for every AOV texel
+    int svgf_ensure(int32_t w, int32_t h, bool stages)
+    {
+        const size_t n = (size_t)w * h;
+        if (w != sv_w || h != sv_h) {
+            const float4 init = make_float4(0.0F, 0.0F, 0.0F, 1.0F);
+            for (auto& set : sv_aov) for (auto& b : set) { ATN_HIP(b.resize(n)); svgf_fill(b.p, n, init); }
+            ATN_HIP(sv_scratch.resize(n)); svgf_fill(sv_scratch.p, n, init);
+            for (auto& b : sv_atrous) { ATN_HIP(b.resize(n)); svgf_fill(b.p, n, init); }
+            ATN_HIP(sv_tmp.resize(n)); svgf_fill(sv_tmp.p, n, init);
+            ATN_HIP(sv_primary.resize(n)); svgf_fill(sv_primary.p, n, make_float4(0, 0, 0, 0));
+            ATN_HIP(sv_contribs.resize(n)); ATN_HIP(sv_out.resize(n));
+            if (!sv_motion_set || sv_motion.n < n) { ATN_HIP(sv_motion.resize(n)); sv_motion_set = false; }
+            sv_cv[0] = sv_aov[0][2].p; sv_cv[1] = sv_aov[1][2].p; sv_spare = sv_scratch.p;
+            sv_w = w; sv_h = h; sv_curr = 0;
+        }
+        if (stages) ATN_HIP(sv_stages.resize(3 * n));
+        return ATN_OK;
+    }
+
+    // ≙ SVGFRenderer::SetMotionDepthBuffer (svgf.cpp:441-450)
+    int svgf_set_motion_depth(const atn_vec4* md, uint32_t n)
+    {
+        if (!md || n == 0) return fail(ATN_ERR_INVALID_ARG, "empty motion/depth buffer");
+        ATN_HIP(hipSetDevice(device));
+        ATN_HIP(sv_motion.resize(n));
+        ATN_HIP(hipMemcpyAsync(sv_motion.p, md, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, stream));
+        ATN_HIP(hipStreamSynchronize(stream));
+        sv_motion_set = true;
+        return ATN_OK;
+    }
+
+    int svgf_reset()
+    {
+        sv_w = 0; sv_h = 0; sv_curr = 0;        // buffers are re-initialised by the next svgf_render
+        const float id[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        std::memcpy(sv_W2V, id, sizeof(id)); std::memcpy(sv_V2C, id, sizeof(id)); std::memcpy(sv_prevW2V, id, sizeof(id));
+        return ATN_OK;
+    }
+
+    float4* svgf_buffer(int32_t which)
+    {
+        const int32_t c = sv_curr, p = 1 - sv_curr;
+        if (which >= 0 && which < 4) return which == 2 ? sv_cv[c] : sv_aov[c][which].p;
+        if (which < 8) return which == 6 ? sv_cv[p] : sv_aov[p][which - 4].p;
+        switch (which) {
+        case 8: return sv_tmp.p; case 9: return sv_motion.p; case 10: return sv_primary.p;
+        case 11: return sv_atrous[0].p; case 12: return sv_atrous[1].p; case 13: return sv_out.p; case 14: return sv_contribs.p;
+        }
+        return nullptr;
+    }
+
+    // ≙ aten::SVGFRenderer::OnRender (svgf.cpp:452-637)
+    int svgf_render(const atn_destination* d, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host, bool path_pass = true)
+    {
+        if (!d) return fail(ATN_ERR_INVALID_ARG, "null destination");
+        if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+        if (!has_camera) return fail(ATN_ERR_INVALID_ARG, "atn_update_camera has not been called");
+        if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
+        if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
+        if (world != 1) return fail(ATN_ERR_UNSUPPORTED, "SVGF needs the whole frame on one GPU (filter footprints cross tiles)");
+        ATN_HIP(hipSetDevice(device));
+        int rc = ensure_frame(d->width, d->height, d->maxDepth);
+        if (rc) return rc;
+        rc = svgf_ensure(d->width, d->height, stages_host != nullptr);
+        if (rc) return rc;
+        if (!compute_motion && (!sv_motion_set || sv_motion.n < (size_t)d->width * d->height))
+            return fail(ATN_ERR_INVALID_ARG, "no motion/depth buffer: call atn_svgf_set_motion_depth or pass compute_motion = 1");
+        const bool prof = d->profile != 0;
+        PathBuffers pb = buffers(false);
+        FrameParams fp = frame_params(*d);
+        fp.break_on_terminate = 1;
+
+        svgf_reset_matrices();
+        const int32_t cur = sv_curr, prv = 1 - sv_curr;
+        SvgfFrame sf{};
+        sf.nd = sv_aov[cur][0].p; sf.am = sv_aov[cur][1].p; sf.cv = sv_cv[cur]; sf.mt = sv_aov[cur][3].p;
+        sf.pnd = sv_aov[prv][0].p; sf.pam = sv_aov[prv][1].p; sf.pcv = sv_cv[prv]; sf.pmt = sv_aov[prv][3].p;
+        sf.cv_out = sv_spare;
+        sf.atrous[0] = sv_atrous[0].p; sf.atrous[1] = sv_atrous[1].p;
+        sf.tmp = sv_tmp.p; sf.motion = sv_motion.p; sf.primary = sv_primary.p; sf.contribs = sv_contribs.p;
+        sf.out = sv_out.p; sf.stages = stages_host ? sv_stages.p : nullptr;
+        mat_mul(sv_V2C, sv_W2V, sf.w2c);
+        mat_mul(sv_V2C, sv_prevW2V, sf.prev_w2c);
+        sf.width = d->width; sf.height = d->height; sf.frame = d->frame; sf.atrous_iter_cnt = sv_atrous_iters;
+        // Camera::ComputeScreenDistance (camera.h:216-221): tan of half the fov IN DEGREES, as the reference writes it
+        sf.camera_distance = (float)d->height / (2.0f * std::tan(0.5f * camera.vfov));
+        sf.compute_motion = compute_motion;
+        SvgfShade sv{};
+        sv.nd = sf.nd; sv.am = sf.am; sv.primary = sf.primary;
+        sv.w2c3[0] = sf.w2c[12]; sv.w2c3[1] = sf.w2c[13]; sv.w2c3[2] = sf.w2c[14]; sv.w2c3[3] = sf.w2c[15];
+
+        const uint32_t g_slots = grid_for(n_slots);
+        const uint32_t g_trace = trace_grid(n_slots);
+        const uint32_t g_all = (n_slots + 255u) / 256u;
+        for (int32_t s = 0; path_pass && s < d->sample; s++) {
+            fp.sample = s;
+            ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)4 * counters_depth * 4, stream));
+            prof_begin(prof, ATN_K_GEN);
+            hipLaunchKernelGGL(k_gen_path, dim3(g_slots), dim3(256), 0, stream, pb, fp, camera, (const uint32_t*)seeds.p);
+            prof_end(prof);
+            for (int32_t b = 0; b < d->maxDepth; b++) {
+                prof_begin(prof, ATN_K_TRACE_CLOSEST);
+                launch_trace<false>(pb, g_trace, false, b);
+                prof_end(prof);
+                prof_begin(prof, ATN_K_SHADE);
+                hipLaunchKernelGGL((k_shade<true>), dim3(g_slots), dim3(256), 0, stream, pb, scene, fp, camera, b, sv);
+                prof_end(prof);
+                prof_begin(prof, ATN_K_TRACE_SHADOW);
+                launch_trace<true>(pb, g_trace, false, b);
+                prof_end(prof);
+            }
+            prof_begin(prof, ATN_K_ACCUM);
+            hipLaunchKernelGGL(k_svgf_sample_end, dim3(g_all), dim3(256), 0, stream, pb, fp, sf);
+            prof_end(prof);
+        }
+        const dim3 gp((d->width + 7) / 8, (d->height + 31) / 32), tp(256);
+        prof_begin(prof, ATN_K_SVGF_PREPARE);
+        hipLaunchKernelGGL(k_svgf_prepare, gp, tp, 0, stream, sf);
+        prof_end(prof);
+        if (d->frame > 0) {
+            prof_begin(prof, ATN_K_SVGF_TEMPORAL);
+            hipLaunchKernelGGL(k_svgf_temporal, gp, tp, 0, stream, sf, 0.98f, 0.05f);
+            prof_end(prof);
+        }
+        else if (sf.stages) {
+            // frame 0: the temporal pass only re-puts the raw contribution (svgf.cpp:549-551)
+            ATN_HIP(hipMemcpyAsync(sf.stages + (size_t)d->width * d->height, sf.stages, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        }
+        prof_begin(prof, ATN_K_SVGF_VARIANCE);
+        hipLaunchKernelGGL(k_svgf_variance, gp, tp, 0, stream, sf);
+        prof_end(prof);
+        std::swap(sv_cv[cur], sv_spare);        // the pass wrote the new colour+variance into the spare buffer
+        sf.cv = sv_cv[cur]; sf.cv_out = sv_spare;
+        for (int32_t i = 0; i < sv_atrous_iters; i++) {
+            prof_begin(prof, ATN_K_SVGF_ATROUS);
+            hipLaunchKernelGGL(k_svgf_atrous, gp, tp, 0, stream, sf, i);
+            prof_end(prof);
+        }
+        prof_begin(prof, ATN_K_SVGF_PREPARE);
+        hipLaunchKernelGGL(k_svgf_copy, gp, tp, 0, stream, sf);
+        prof_end(prof);
+        ATN_HIP(hipGetLastError());
+        sv_curr = 1 - sv_curr;
+
+        const size_t n = (size_t)d->width * d->height;
+        if (out_host) ATN_HIP(hipMemcpyAsync(out_host, sv_out.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        if (stages_host) ATN_HIP(hipMemcpyAsync(stages_host, sv_stages.p, 3 * n * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        if (out_host || stages_host) ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;
     }
 
     // ≙ idaten::Renderer::reset, renderer.h:40-43
@@ -465,6 +679,53 @@ int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
 
 int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return ctx->r.render(dst, out_host); }
 int atn_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.reset(); }
+
+int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
+{
+    CTX_OR_FAIL(ctx);
+    return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host);
+}
+int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_OR_FAIL(ctx); return ctx->r.svgf_set_motion_depth(motion_depth, n); }
+int atn_svgf_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.svgf_reset(); }
+int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n)
+{
+    CTX_OR_FAIL(ctx);
+    if (n < 1 || n > 8) return ctx->r.fail(ATN_ERR_INVALID_ARG, "a-trous iteration count out of range");
+    ctx->r.sv_atrous_iters = n;
+    return ATN_OK;
+}
+int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    float4* p = r.sv_w > 0 ? r.svgf_buffer(which) : nullptr;
+    if (!p || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "no such SVGF buffer (or atn_svgf_render has not run)");
+    C_HIP(r, hipSetDevice(r.device));
+    C_HIP(r, hipMemcpyAsync(out_host, p, (size_t)r.sv_w * r.sv_h * sizeof(float4), hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+int atn_svgf_denoise(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
+{
+    CTX_OR_FAIL(ctx);
+    return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host, false);
+}
+int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, const atn_vec4* host)
+{
+    CTX_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!host || width <= 0 || height <= 0) return r.fail(ATN_ERR_INVALID_ARG, "bad SVGF upload");
+    C_HIP(r, hipSetDevice(r.device));
+    int rc = r.svgf_ensure(width, height, false);
+    if (rc) return rc;
+    float4* p = r.svgf_buffer(which);
+    if (!p) return r.fail(ATN_ERR_INVALID_ARG, "no such SVGF buffer");
+    C_HIP(r, hipMemcpyAsync(p, host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    if (which == 9) r.sv_motion_set = true;
+    return ATN_OK;
+}
+void* atn_svgf_output_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.sv_out.p : nullptr; }
 
 void* atn_film_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.film.p : nullptr; }
 void* atn_tile_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.tile_out.p : nullptr; }

@@ -16,6 +16,7 @@
 namespace atn {
 
 constexpr uint32_t F_TERMINATED = 1u, F_SINGULAR = 2u, F_HIT = 4u;
+constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.last_hit_mtrl_idx names a Specular material
 
 struct PathBuffers {
     float4* ray_o;      // org.xyz, pdfb
@@ -226,9 +227,21 @@ __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_closest(
     }
 }
 
+// AOV outputs of the SVGF flavour of shade (SVGFRenderer::Shade, src/libaten/renderer/svgf/svgf.cpp:89-229):
+// full-frame buffers indexed by pixel, and the fourth row of mtx_W2C (clip w = view depth).
+struct SvgfShade {
+    float4* nd;         // normal.xyz, clip-space w
+    float4* am;         // albedo texel.rgb, material id (svgf.cpp:131)
+    float4* primary;    // bounce-0 hit position, w = 1 (0 on a miss)
+    float w2c3[4];
+};
+
 // PathTracing::shade (pathtracing.cpp:91-236) + ShadeMiss (pathtracing_impl.h:112-176) for one path.
 // Returns updated flags; fills the next ray and the shadow ray.
-__global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce)
+// SVGF = true is SVGFRenderer::Shade + ShadeMiss with AOV spans: AOVs at bounce 0 (and at bounce 1 behind a Specular
+// hit), albedo read with default (1,1,1,1) and demodulated where the AOV took it.
+template <bool SVGF>
+__global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     __shared__ BlockAppendShared sh;
     const uint32_t count = pb.q_count[bounce];
@@ -274,6 +287,12 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                     }
                     const float4 emit = background_sample(sc, dir);
                     float misW = 1.0f;
+                    if (SVGF && (bounce == 0 || (bounce == 1 && (flags & F_SINGULAR)))) {
+                        // FillBasicAOVsIfHitMiss (renderer/aov.h:183-198)
+                        sv.nd[s4.w] = make_float4(0.0F, 0.0F, 0.0F, -1.0F);
+                        sv.am[s4.w] = make_float4(emit.x, emit.y, emit.z, -1.0F);
+                        if (bounce == 0) sv.primary[s4.w] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+                    }
                     if (!(bounce == 0 || (bounce == 1 && (flags & F_SINGULAR)))) {
                         // ImageBasedLight::samplePdf, light/ibl.h:46-58
                         float pdfLight = luminance(emit.x, emit.y, emit.z) / sc.avgIllum;
@@ -301,8 +320,24 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 // FillMaterial (material_impl.h:232-262): a negative id selects the white-diffuse fallback, which
                 // the upload appends after the last real material
                 const DevMaterial& m = sc.materials[mtrlid >= 0 ? mtrlid : sc.n_materials];
-                float4 albedo4 = sample_texture(sc, m.albedoMap, rec.u, rec.v, m.baseColor);
-                albedo4 = add4(mul4(1.0F, albedo4), make_float4(0, 0, 0, 0));
+                float4 albedo4;
+                if (SVGF) {
+                    int32_t albedo_map = m.albedoMap;
+                    if (bounce == 0 || (bounce == 1 && (flags & F_LAST_SPECULAR))) {
+                        // FillBasicAOVs (renderer/aov.h:158-181): the normal BEFORE back-face flip and normal map
+                        const float4 texcolor = sample_texture(sc, albedo_map, rec.u, rec.v, make_float4(1.0F, 1.0F, 1.0F, 1.0F));
+                        const float depth = sv.w2c3[0] * rec.p.x + sv.w2c3[1] * rec.p.y + sv.w2c3[2] * rec.p.z + sv.w2c3[3] * 1.0F;
+                        sv.nd[s4.w] = make_float4(rec.normal.x, rec.normal.y, rec.normal.z, depth);
+                        sv.am[s4.w] = make_float4(texcolor.x, texcolor.y, texcolor.z, (float)mtrlid);
+                        albedo_map = -1;        // "for exporting separated albedo"
+                        if (bounce == 0) sv.primary[s4.w] = make_float4(rec.p.x, rec.p.y, rec.p.z, 1.0F);
+                    }
+                    albedo4 = sample_texture(sc, albedo_map, rec.u, rec.v, make_float4(1.0F, 1.0F, 1.0F, 1.0F));
+                }
+                else {
+                    albedo4 = sample_texture(sc, m.albedoMap, rec.u, rec.v, m.baseColor);
+                    albedo4 = add4(mul4(1.0F, albedo4), make_float4(0, 0, 0, 0));
+                }
                 const f3 albedo = mk3(albedo4);
 
                 bool shaded_out = false;
@@ -379,6 +414,10 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                     if (!(flags & F_TERMINATED)) {
                         pdfb = ms.pdf;
                         flags = (m.attrib & ATN_MTRL_ATTR_SINGULAR) ? (flags | F_SINGULAR) : (flags & ~F_SINGULAR);
+                        if (SVGF) {     // last_hit_mtrl_idx = mtrl.id (pathtracing_impl.h:739), read back at svgf.cpp:142-144
+                            const bool last_spec = m.id >= 0 && m.id < sc.n_materials && sc.materials[m.id].type == ATN_MTRL_SPECULAR;
+                            flags = last_spec ? (flags | F_LAST_SPECULAR) : (flags & ~F_LAST_SPECULAR);
+                        }
                         const f3 no = ray_offset(rec.p, ray_along_normal);
                         const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
                         pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);

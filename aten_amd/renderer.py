@@ -113,8 +113,56 @@ class PathTracing:
         return dict(closest_rays=int(s[0]), shadow_rays=int(s[1]), hits=int(s[2]),
                     closest_nodes=int(s[3]), closest_tris=int(s[4]), shadow_nodes=int(s[5]), shadow_tris=int(s[6]))
 
+    # ---- SVGF (aten::SVGFRenderer)
+    SVGF_BUFFERS = dict(normal_depth=0, albedo_meshid=1, color_variance=2, moment_temporalweight=3,
+                        prev_normal_depth=4, prev_albedo_meshid=5, prev_color_variance=6, prev_moment_temporalweight=7,
+                        temporary_color=8, motion_depth=9, primary_position=10, atrous0=11, atrous1=12, output=13,
+                        contribs=14)
+
+    def svgf_render(self, width, height, max_depth=5, rr_depth=3, spp=1, frame=0, compute_motion=False, stages=False,
+                    download=True, profile=False):
+        """SVGFRenderer::OnRender.  Returns the filtered frame [h, w, 4] (and the three intermediate puts)."""
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, 0, 1, 0, int(profile))
+        out = np.empty((height, width, 4), np.float32) if download else None
+        st = np.empty((3, height, width, 4), np.float32) if stages else None
+        self._check(self._l.atn_svgf_render(self._ctx, C.byref(d), 1 if compute_motion else 0,
+                                            out.ctypes.data if download else None, st.ctypes.data if stages else None))
+        self.width, self.height = width, height
+        return (out, st) if stages else out
+
+    def svgf_denoise(self, width, height, frame=0, compute_motion=False, stages=False, download=True, profile=False):
+        """The filter passes of OnRender on the buffers as they stand (svgf_upload / a previous path pass)."""
+        d = Destination(width, height, 1, 1, 1, frame, 0, 1, 0, int(profile))
+        out = np.empty((height, width, 4), np.float32) if download else None
+        st = np.empty((3, height, width, 4), np.float32) if stages else None
+        self._check(self._l.atn_svgf_denoise(self._ctx, C.byref(d), 1 if compute_motion else 0,
+                                             out.ctypes.data if download else None, st.ctypes.data if stages else None))
+        self.width, self.height = width, height
+        return (out, st) if stages else out
+
+    def svgf_upload(self, name, data):
+        data = np.ascontiguousarray(data, np.float32)
+        h, w = data.shape[:2]
+        self._check(self._l.atn_svgf_upload(self._ctx, self.SVGF_BUFFERS[name], w, h, data.ctypes.data))
+        self.width, self.height = w, h
+
+    def svgf_set_motion_depth(self, md):
+        md = np.ascontiguousarray(md, np.float32).reshape(-1, 4)
+        self._check(self._l.atn_svgf_set_motion_depth(self._ctx, md.ctypes.data, len(md)))
+
+    def svgf_reset(self):
+        self._check(self._l.atn_svgf_reset(self._ctx))
+
+    def svgf_set_atrous_iterations(self, n):
+        self._check(self._l.atn_svgf_set_atrous_iterations(self._ctx, n))
+
+    def svgf_buffer(self, name):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._l.atn_svgf_download(self._ctx, self.SVGF_BUFFERS[name], out.ctypes.data))
+        return out
+
     def kernel_times(self):
-        ms = np.zeros(6, np.float32); n = np.zeros(6, np.uint32)
+        ms = np.zeros(len(K_NAMES), np.float32); n = np.zeros(len(K_NAMES), np.uint32)
         self._check(self._l.atn_get_kernel_times(self._ctx, ms.ctypes.data, n.ctypes.data))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
 

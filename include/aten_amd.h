@@ -110,11 +110,49 @@ int atn_get_stats(atn_ctx* ctx, uint64_t out[8]);
 
 /* Kernel classes for atn_get_kernel_times. */
 enum { ATN_K_GEN = 0, ATN_K_TRACE_CLOSEST = 1, ATN_K_SHADE = 2, ATN_K_TRACE_SHADOW = 3,
-       ATN_K_ACCUM = 4, ATN_K_GATHER = 5, ATN_K_COUNT = 6 };
+       ATN_K_ACCUM = 4, ATN_K_GATHER = 5,
+       ATN_K_SVGF_PREPARE = 6, ATN_K_SVGF_TEMPORAL = 7, ATN_K_SVGF_VARIANCE = 8, ATN_K_SVGF_ATROUS = 9,
+       ATN_K_COUNT = 10 };
 /* HIP-event time (ms) and launch count per kernel class, accumulated over every atn_render with
  * profile = 1 since the last atn_reset_kernel_times. */
 int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT]);
 int atn_reset_kernel_times(atn_ctx* ctx);
+
+/* ---- SVGF (next tier, BASELINE config 5) -------------------------------------------------------
+ * ≙ aten::SVGFRenderer (src/libaten/renderer/svgf/svgf.{h,cpp}): the path pass with AOV outputs
+ * (SVGFRenderer::Shade / ShadeMiss with AOV spans) followed by the svgf_impl.h passes as HIP kernels --
+ * PrepareForDenoise, TemporalReprojection + AccumulateMoments (frame > 0), EstimateVariance,
+ * atrous_iter_cnt x (3x3 Gauss of the variance + ExecAtrousWaveletFilter + PostProcessForAtrousFilter),
+ * CopyFromTeporaryColorBufferToAov -- with the AOV / moment buffers of two frames resident in HBM.
+ * `dst->frame == 0` takes the first-frame path (svgf.cpp:519-525,543-551).  One GPU only.
+ *
+ * out_host (may be NULL): what dst.buffer holds when OnRender returns (the last a-trous iteration's
+ * albedo-multiplied colour), vec4[w*h], row 0 = bottom.  stages_host (may be NULL): 3 x vec4[w*h], the
+ * values OnRender puts after the path pass, the temporal pass and the variance pass.
+ * compute_motion != 0: the motion/depth buffer is computed from the primary hits and the current/previous
+ * camera matrices (MatricesForRendering, pt_params.h:150-185) -- the compute pass that stands in for the
+ * reference's GL raster pass (src/shader/ssrt_fs.glsl:31-47); 0: use atn_svgf_set_motion_depth's buffer. */
+int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion,
+                    atn_vec4* out_host, atn_vec4* stages_host);
+/* ≙ SVGFRenderer::SetMotionDepthBuffer (svgf.cpp:441-450): {motion.xy in screen fractions, depth, 1}. */
+int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n);
+/* Forget the frame history (AOV sets, moments, previous camera matrices). */
+int atn_svgf_reset(atn_ctx* ctx);
+/* SVGFParams::atrous_iter_cnt (svgf_types.h:72), default 5. */
+int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n);
+/* Parity probe.  which: 0-3 SVGFParams::GetCurrAovBuffer() as the state stands (OnRender toggles at its end, so
+ * this is the set the NEXT frame writes: normal+depth, albedo+meshid, colour+variance, moments+temporal weight),
+ * 4-7 GetPrevAovBuffer() (the set the last frame wrote), 8 temporary colour, 9 motion/depth, 10 primary hit
+ * position, 11/12 a-trous ping-pong buffers, 13 output, 14 contributions. */
+int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host);
+/* The filter passes alone (everything of OnRender after the sample loop, svgf.cpp:515-637) on whatever the
+ * path pass -- or atn_svgf_upload -- left in the buffers: contributions (which = 14: contrib.xyz, sample count),
+ * the current AOVs (0, 1), primary hit positions (10), motion/depth (9).  This is how a caller that already has a
+ * noisy frame and a G-buffer uses the denoiser, and how the parity tests feed both sides identical inputs. */
+int atn_svgf_denoise(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion,
+                     atn_vec4* out_host, atn_vec4* stages_host);
+int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, const atn_vec4* host);
+void* atn_svgf_output_device(atn_ctx* ctx);
 
 /* ---- stage entry points (parity tests; each mirrors one reference function) ---------------- */
 /* GeneratePath for every pixel (src/libaten/renderer/pathtracing/pathtracing_impl.h:65-110). */

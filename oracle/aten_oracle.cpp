@@ -6,6 +6,7 @@
  * Parity status: see orc_core.h header ("parity unpinned" except the three reference KATs).
  */
 #include "orc_pt.h"
+#include "orc_svgf.h"
 #include <cstdio>
 #include <omp.h>
 
@@ -195,5 +196,144 @@ void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
 }
 
 int orc_num_procs() { return omp_get_num_procs(); }
+
+// ---------------------------------------------------------------------------------------------------
+// SVGF (next tier): aten::SVGFRenderer, src/libaten/renderer/svgf/svgf.cpp:412-637
+// ---------------------------------------------------------------------------------------------------
+void* orc_svgf_create() { return new svgf::Params(); }
+void orc_svgf_destroy(void* h) { delete static_cast<svgf::Params*>(h); }
+void orc_svgf_set_atrous_iterations(void* h, int32_t n) { static_cast<svgf::Params*>(h)->atrous_iter_cnt = n; }
+
+// SVGFRenderer::SetMotionDepthBuffer (svgf.cpp:441-450): vec4 {motion.xy in screen fractions, depth, 1} per pixel
+void orc_svgf_set_motion_depth(void* h, const atn_vec4* md, uint32_t n)
+{
+    auto* p = static_cast<svgf::Params*>(h);
+    p->motion_depth_buffer.resize(n);
+    for (uint32_t i = 0; i < n; i++) p->motion_depth_buffer[i] = v4(md[i].x, md[i].y, md[i].z, md[i].w);
+}
+
+// which: 0-3 current AOVs, 4-7 previous AOVs, 8 temporary colour, 9 motion/depth, 10 primary hit position,
+// 11/12 the two a-trous ping-pong buffers
+int orc_svgf_get_buffer(void* h, int32_t which, atn_vec4* out)
+{
+    auto* p = static_cast<svgf::Params*>(h);
+    const std::vector<v4>* b = nullptr;
+    if (which >= 0 && which < 4) b = &p->cur(which);
+    else if (which < 8) b = &p->prev(which - 4);
+    else if (which == 8) b = &p->temporary_color_buffer;
+    else if (which == 9) b = &p->motion_depth_buffer;
+    else if (which == 10) b = &p->primary_position;
+    else if (which == 11 || which == 12) b = &p->atrous_clr_variance[which - 11];
+    if (!b) return -1;
+    for (size_t i = 0; i < b->size(); i++) { out[i].x = (*b)[i].x; out[i].y = (*b)[i].y; out[i].z = (*b)[i].z; out[i].w = (*b)[i].w; }
+    return (int)b->size();
+}
+
+// SVGFRenderer::OnRender (svgf.cpp:452-637).  `film` receives what dst.buffer holds when OnRender returns (Film::put,
+// film.cpp:33-45): the last a-trous iteration's albedo-multiplied colour.  `stage_out` (may be null): 3 x vec4[w*h] =
+// the values put after the path pass, after the temporal pass and after the variance pass.
+// compute_motion != 0: fill motion_depth_buffer from the primary hits (ComputeMotionDepth) instead of an external buffer.
+void orc_svgf_render(void* h, const atn_scene_desc* scene, const atn_camera_param* camera,
+    const uint32_t* seeds, uint32_t n_seeds, const orc_destination* dst, int32_t compute_motion,
+    atn_vec4* film, atn_vec4* stage_out)
+{
+    auto& P = *static_cast<svgf::Params*>(h);
+    Scene ctxt(scene);
+    const int32_t width = dst->width, height = dst->height;
+    const uint32_t samples = (uint32_t)dst->sample;
+    int32_t maxDepth = dst->maxDepth;
+    int32_t rrDepth = dst->russianRouletteDepth;
+    if (rrDepth > maxDepth) rrDepth = maxDepth - 1;         // svgf.cpp:423-425
+    P.InitBuffers(width, height);
+    P.mtxs.Reset(*camera);
+    const m4 W2C = P.mtxs.GetW2C();
+    const m4 prevW2C = svgf::mul(P.mtxs.V2C, P.mtxs.PrevW2V);
+    const size_t n = (size_t)width * height;
+    std::vector<v4> contribs(n);
+    auto put = [&](int stage, int32_t idx, const v4& v) {
+        if (stage_out && stage < 3) { atn_vec4& o = stage_out[(size_t)stage * n + idx]; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; }
+        atn_vec4& o = film[idx]; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+    };
+    if (dst->nthreads > 0) omp_set_num_threads(dst->nthreads);
+
+#pragma omp parallel for
+    for (int32_t y = 0; y < height; y++) {
+        for (int32_t x = 0; x < width; x++) {
+            int32_t idx = y * width + x;
+            PathState path;             // path_host_.Clear(): contrib/attrib/throughput zeroed every frame
+            path.samples = 0;
+            Ray ray; ShadowRay shadow_ray;
+            for (uint32_t i = 0; i < samples; i++) {
+                const uint32_t rnd = seeds[idx % n_seeds];
+                GeneratePath(ray, x, y, (int32_t)i, dst->frame, path, *camera, rnd);
+                path.contrib = v3(0);
+                svgf::ExecRendering(path, ray, shadow_ray, x, y, width, height, ctxt, *camera, maxDepth, rrDepth, W2C,
+                    P.cur(svgf::NormalDepth)[idx], P.cur(svgf::AlbedoMeshId)[idx], P.primary_position[idx], nullptr);
+                if (isInvalidColor(path.contrib)) continue;
+                if (path.is_terminated) break;
+            }
+            // PrepareForDenoise (svgf_impl.h:119-144)
+            const v4 c(path.contrib, path.samples);
+            v4 contrib = c;
+            svgf::operator/=(contrib, c.w);
+            if (dst->frame == 0) {
+                float lum = luminance(contrib.x, contrib.y, contrib.z);
+                v4& mt = P.cur(svgf::MomentTemporalWeight)[idx];
+                mt.x += lum * lum; mt.y += lum; mt.z += 1;
+                v4& cv = P.cur(svgf::ColorVariance)[idx];
+                cv = v4(contrib.x, contrib.y, contrib.z, cv.w);
+            }
+            P.temporary_color_buffer[idx] = c;
+            contribs[idx] = c;
+            put(0, idx, v4(path.contrib, 1));       // Film::put(x, y, vec3) -> vec4(v, 1)
+        }
+    }
+
+    if (compute_motion) {
+        P.motion_depth_buffer.resize(n);
+#pragma omp parallel for
+        for (int32_t i = 0; i < (int32_t)n; i++) P.motion_depth_buffer[i] = svgf::ComputeMotionDepth(P.primary_position[i], W2C, prevW2C);
+    }
+
+#pragma omp parallel for
+    for (int32_t y = 0; y < height; y++) {
+        for (int32_t x = 0; x < width; x++) {
+            int32_t idx = y * width + x;
+            v4 temporal_projected_clr;
+            if (dst->frame > 0) temporal_projected_clr = svgf::TemporalReprojection(x, y, width, height, 0.98f, 0.05f, contribs[idx], P);
+            else temporal_projected_clr = v4(contribs[idx].x, contribs[idx].y, contribs[idx].z, 1.0f);   // vec4() then operator=(vec3): w stays 1
+            put(1, idx, temporal_projected_clr);
+        }
+    }
+
+    // Camera::ComputeScreenDistance (camera.h:216-221): tan() of half the vertical fov IN DEGREES, as written
+    const float camera_distance = height / (2.0f * std::tan(0.5f * camera->vfov));
+    {
+        const std::vector<v4> cv_in = P.cur(svgf::ColorVariance);
+#pragma omp parallel for
+        for (int32_t y = 0; y < height; y++) {
+            for (int32_t x = 0; x < width; x++) {
+                put(2, y * width + x, svgf::EstimateVariance(x, y, width, height, camera_distance, cv_in, P));
+            }
+        }
+    }
+
+    for (int32_t i = 0; i < P.atrous_iter_cnt; i++) {
+#pragma omp parallel for
+        for (int32_t y = 0; y < height; y++) {
+            for (int32_t x = 0; x < width; x++) {
+                v4 out;
+                if (svgf::AtrousFilter(i, x, y, width, height, camera_distance, P, &out)) put(3, y * width + x, out);
+            }
+        }
+    }
+
+    // CopyFromTeporaryColorBufferToAov: CopyVectorBuffer<3> (svgf.cpp:402-410)
+    {
+        auto& cv = P.cur(svgf::ColorVariance);
+        for (size_t i = 0; i < n; i++) { cv[i].z = P.temporary_color_buffer[i].z; cv[i].y = P.temporary_color_buffer[i].y; cv[i].x = P.temporary_color_buffer[i].x; }
+    }
+    P.curr_aov_pos = 1 - P.curr_aov_pos;
+}
 
 } // extern "C"

@@ -108,3 +108,49 @@ def render(scene, cam, seeds, width, height, max_depth=5, rr_depth=3, spp=1, fra
     lib().orc_render(scene.ref(), C.c_void_p(cam.ctypes.data), C.c_void_p(seeds.ctypes.data), C.c_uint32(len(seeds)),
                      C.byref(d), C.c_void_p(film.ctypes.data), C.c_void_p(cnt.ctypes.data) if counters else None)
     return (film, cnt) if counters else film
+
+
+class Svgf:
+    """aten::SVGFRenderer on the CPU oracle (oracle/orc_svgf.h): frame-persistent AOV / moment buffers."""
+    BUFFERS = dict(normal_depth=0, albedo_meshid=1, color_variance=2, moment_temporalweight=3,
+                   prev_normal_depth=4, prev_albedo_meshid=5, prev_color_variance=6, prev_moment_temporalweight=7,
+                   temporary_color=8, motion_depth=9, primary_position=10, atrous0=11, atrous1=12)
+
+    def __init__(self):
+        l = lib()
+        l.orc_svgf_create.restype = C.c_void_p
+        l.orc_svgf_get_buffer.restype = C.c_int
+        self._h = C.c_void_p(l.orc_svgf_create())
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().orc_svgf_destroy(self._h)
+            self._h = None
+
+    def set_atrous_iterations(self, n):
+        lib().orc_svgf_set_atrous_iterations(self._h, C.c_int32(n))
+
+    def set_motion_depth(self, md):
+        md = np.ascontiguousarray(md, np.float32).reshape(-1, 4)
+        lib().orc_svgf_set_motion_depth(self._h, C.c_void_p(md.ctypes.data), C.c_uint32(len(md)))
+
+    def render(self, scene, cam, seeds, width, height, max_depth=5, rr_depth=3, spp=1, frame=0, compute_motion=False,
+               stages=False, nthreads=0):
+        """Returns the final film [h, w, 4] (and, with stages=True, the three intermediate puts [3, h, w, 4])."""
+        film = np.zeros((height, width, 4), np.float32)
+        st = np.zeros((3, height, width, 4), np.float32) if stages else None
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, 0, nthreads)
+        lib().orc_svgf_render(self._h, scene.ref(), C.c_void_p(cam.ctypes.data), C.c_void_p(seeds.ctypes.data),
+                              C.c_uint32(len(seeds)), C.byref(d), C.c_int32(1 if compute_motion else 0),
+                              C.c_void_p(film.ctypes.data), C.c_void_p(st.ctypes.data) if stages else None)
+        self.n = width * height
+        self.shape = (height, width, 4)
+        return (film, st) if stages else film
+
+    def buffer(self, name):
+        out = np.zeros(self.shape, np.float32)
+        r = lib().orc_svgf_get_buffer(self._h, C.c_int32(self.BUFFERS[name]), C.c_void_p(out.ctypes.data))
+        if r < 0:
+            raise ValueError(name)
+        return out

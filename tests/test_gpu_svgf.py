@@ -1,0 +1,170 @@
+"""GPU parity of the SVGF passes (next tier, BASELINE config 5) against oracle/orc_svgf.h through the C-ABI.
+
+Tolerances: the temporal pass has no transcendental and must agree to the last bit GIVEN EQUAL INPUTS; its inputs
+(path-traced colours, AOV depth) carry the path tracer's own tolerance, so the end-to-end comparison uses the frame
+tolerance of DESIGN.md (|gpu - cpu| <= 1e-3 * max(1, |cpu|) for >= 99.5 % of pixels); integer-valued planes
+(material id, frame count) are compared exactly where the path agrees.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def frac_within(a, b, rel=1e-3):
+    d = np.abs(a - b)
+    tol = rel * np.maximum(1.0, np.abs(b))
+    ok = np.all((d <= tol) | (np.isnan(a) & np.isnan(b)), axis=-1)
+    return ok.mean()
+
+
+def _setup(gpu, orc, scene, cam, w, h):
+    c = make_camera(orc, cam, w, h)
+    gpu.UpdateSceneData(scene)
+    gpu.updateCamera(c)
+    gpu.initSampler(w, h, 0)
+    gpu.setScreenShard(0, 1)
+    gpu.svgf_reset()
+    return c, orc.init_sampler(w, h, 0)
+
+
+@pytest.mark.parametrize("which", ["sponza", "cornell"])
+def test_svgf_filter_passes_on_equal_inputs(gpu, orc, sponza, cornell, which):
+    """The filter passes proper: both sides get the SAME noisy frame and G-buffer (the oracle's path pass, uploaded
+    through atn_svgf_upload), frame after frame, each side keeping its own history.  What differs is then only
+    powf/expf/sqrt rounding inside the passes."""
+    fs, cam = sponza if which == "sponza" else cornell
+    w, h = 192, 108
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    try:
+        for frame in range(5):
+            want, wst = sv.render(fs, c, seeds, w, h, 5, 3, frame=frame, compute_motion=True, stages=True)
+            contribs = wst[0].copy()
+            contribs[..., 3] = 1.0          # Path.contrib.samples with 1 spp
+            gpu.svgf_upload("contribs", contribs)
+            gpu.svgf_upload("normal_depth", sv.buffer("prev_normal_depth"))     # the set the oracle just wrote
+            gpu.svgf_upload("albedo_meshid", sv.buffer("prev_albedo_meshid"))
+            gpu.svgf_upload("primary_position", sv.buffer("primary_position"))
+            got, gst = gpu.svgf_denoise(w, h, frame=frame, compute_motion=True, stages=True)
+            assert frac_within(gpu.svgf_buffer("motion_depth"), sv.buffer("motion_depth"), 1e-5) == 1.0
+            assert np.array_equal(gst[0].view(np.uint32), wst[0].view(np.uint32))
+            for s_, name, need in ((1, "temporal", 0.9995), (2, "variance", 0.999)):
+                f = frac_within(gst[s_][..., :3], wst[s_][..., :3])
+                assert f >= need, (frame, name, f)
+            for name, need in (("prev_color_variance", 0.999), ("prev_moment_temporalweight", 0.9995), ("temporary_color", 0.999)):
+                f = frac_within(gpu.svgf_buffer(name), sv.buffer(name))
+                assert f >= need, (frame, name, f)
+            f = frac_within(got, want)
+            assert f >= 0.999, (frame, "filtered", f)
+            a, b = gpu.svgf_buffer("prev_moment_temporalweight"), sv.buffer("prev_moment_temporalweight")
+            assert (a[..., 2] == b[..., 2]).mean() >= 0.9995, frame        # accumulated frame counts
+        assert np.nanmax(got[..., :3]) > 0
+    finally:
+        sv.close()
+
+
+def test_svgf_end_to_end_vs_oracle(gpu, orc, sponza):
+    """Path pass + filter passes on the GPU against the oracle.  The path pass agrees for >= 99.5 % of the pixels
+    (DESIGN.md tolerance: sinf/cosf ulps occasionally send a path elsewhere); the filters then spread every such
+    pixel over their footprint (7x7, then 5 a-trous levels up to +-32 px), so the filtered frames are compared by
+    their statistics, and the AOVs / motion vectors, which are first-hit geometry, pixel by pixel."""
+    fs, cam = sponza
+    w, h = 192, 108
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    try:
+        for frame in range(3):
+            want, wst = sv.render(fs, c, seeds, w, h, 5, 3, frame=frame, compute_motion=True, stages=True)
+            got, gst = gpu.svgf_render(w, h, 5, 3, frame=frame, compute_motion=True, stages=True)
+            for name in ("prev_normal_depth", "prev_albedo_meshid"):
+                a, b = gpu.svgf_buffer(name), sv.buffer(name)
+                assert frac_within(a, b, 1e-4) >= 0.9995, (frame, name)
+            assert frac_within(gpu.svgf_buffer("primary_position"), sv.buffer("primary_position"), 1e-5) >= 0.9995
+            assert frac_within(gpu.svgf_buffer("motion_depth"), sv.buffer("motion_depth"), 1e-4) >= 0.9995
+            assert frac_within(gst[0][..., :3], wst[0][..., :3]) >= 0.995, frame
+            ma, mb = np.nanmean(got[..., :3]), np.nanmean(want[..., :3])
+            assert abs(ma - mb) <= 3e-2 * max(abs(mb), 1e-6), (frame, ma, mb)
+            assert frac_within(got[..., :3], want[..., :3], rel=5e-2) >= 0.9, frame
+    finally:
+        sv.close()
+
+
+def test_svgf_temporal_pass_bit_exact(gpu, orc, cornell):
+    """TemporalReprojection + AccumulateMoments contain no transcendental: with the same inputs AND the same history
+    (the oracle's previous AOV set uploaded as the GPU's) every pixel must agree to the last bit."""
+    fs, cam = cornell
+    w, h = 96, 64
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    try:
+        def feed(wst):
+            contribs = wst[0].copy()
+            contribs[..., 3] = 1.0
+            gpu.svgf_upload("contribs", contribs)
+            gpu.svgf_upload("normal_depth", sv.buffer("prev_normal_depth"))
+            gpu.svgf_upload("albedo_meshid", sv.buffer("prev_albedo_meshid"))
+            gpu.svgf_upload("primary_position", sv.buffer("primary_position"))
+        _, wst = sv.render(fs, c, seeds, w, h, 3, 3, frame=0, compute_motion=True, stages=True)
+        feed(wst)
+        gpu.svgf_denoise(w, h, frame=0, compute_motion=True)
+        for frame in (1, 2):
+            # make the GPU's history the oracle's
+            for name in ("prev_normal_depth", "prev_albedo_meshid", "prev_color_variance", "prev_moment_temporalweight"):
+                gpu.svgf_upload(name, sv.buffer(name))
+            _, wst = sv.render(fs, c, seeds, w, h, 3, 3, frame=frame, compute_motion=True, stages=True)
+            feed(wst)
+            _, gst = gpu.svgf_denoise(w, h, frame=frame, compute_motion=True, stages=True)
+            assert np.array_equal(gst[1].view(np.uint32), wst[1].view(np.uint32)), frame
+            a, b = gpu.svgf_buffer("prev_moment_temporalweight"), sv.buffer("prev_moment_temporalweight")
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), frame
+    finally:
+        sv.close()
+
+
+def test_svgf_external_motion_buffer_and_camera_move(gpu, orc, sponza):
+    """SetMotionDepthBuffer path (the reference's own interface) and a moving camera through the compute pass."""
+    fs, cam = sponza
+    w, h = 160, 90
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    try:
+        md = np.zeros((h, w, 4), np.float32)
+        md[..., 0] = 1.5 / w      # a uniform 1.5-pixel shift: exercises the int cast and the clamp
+        md[..., 3] = 1.0
+        sv.set_motion_depth(md)
+        gpu.svgf_set_motion_depth(md)
+        for frame in range(3):
+            want = sv.render(fs, c, seeds, w, h, 5, 3, frame=frame)
+            got = gpu.svgf_render(w, h, 5, 3, frame=frame)
+            assert frac_within(got[..., :3], want[..., :3], rel=5e-2) >= 0.9, frame
+        # camera move, motion from the compute pass
+        cam2 = dict(cam)
+        cam2["pos"] = (cam["pos"][0] + 0.05, cam["pos"][1], cam["pos"][2])
+        c2 = make_camera(orc, cam2, w, h)
+        gpu.updateCamera(c2)
+        want = sv.render(fs, c2, seeds, w, h, 5, 3, frame=3, compute_motion=True)
+        got = gpu.svgf_render(w, h, 5, 3, frame=3, compute_motion=True)
+        a, b = gpu.svgf_buffer("motion_depth"), sv.buffer("motion_depth")
+        assert np.abs(b[..., :2]).max() > 0
+        assert frac_within(a, b, 1e-3) >= 0.999
+        assert frac_within(got[..., :3], want[..., :3], rel=5e-2) >= 0.9
+    finally:
+        sv.close()
+
+
+def test_svgf_needs_motion_buffer_or_compute_pass(gpu, orc, cornell):
+    from aten_amd.renderer import AtenAmdError
+    fs, cam = cornell
+    _setup(gpu, orc, fs, cam, 64, 64)
+    gpu.svgf_reset()
+    gpu2_err = None
+    try:
+        # fresh history and no motion buffer of this size
+        gpu.svgf_render(72, 40, 3, 3, frame=0)
+    except AtenAmdError as e:
+        gpu2_err = str(e)
+    # a motion buffer set by an earlier test may satisfy the size; either outcome must be explicit
+    assert gpu2_err is None or "motion" in gpu2_err

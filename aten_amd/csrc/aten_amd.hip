@@ -573,7 +573,7 @@ public:
             hipLaunchKernelGGL(k_svgf_sample_end, dim3(g_all), dim3(256), 0, stream, pb, fp, sf);
             prof_end(prof);
         }
-        const dim3 gp((d->width + 7) / 8, (d->height + 31) / 32), tp(256);
+        const dim3 gp((((d->width + 7) / 8) + 7) / 8 * 8, (d->height + 31) / 32), tp(256);     // x: multiple of 8 (XCD strips)
         prof_begin(prof, ATN_K_SVGF_PREPARE);
         hipLaunchKernelGGL(k_svgf_prepare, gp, tp, 0, stream, sf);
         prof_end(prof);

@@ -36,10 +36,30 @@ ATN_DEV float clampf(float v, float lo, float hi) { return (v < lo) ? lo : (hi <
 ATN_DEV float4 div4(const float4& a, float t) { return make_float4(a.x / t, a.y / t, a.z / t, a.w / t); }
 ATN_DEV bool svgf_pixel(const SvgfFrame& sf, int32_t& ix, int32_t& iy)
 {
-    ix = (int32_t)(blockIdx.x * 8u + (threadIdx.x & 7u));
-    iy = (int32_t)(blockIdx.y * 32u + (threadIdx.x >> 3));
+    // XCD-aware block -> tile map: consecutive block ids land on consecutive XCDs (b % 8), so give every XCD its own
+    // vertical strip of the frame and walk the strips row by row: the +-2*step rows a filter pass re-reads stay in
+    // that XCD's 4 MiB L2 instead of being fetched by all eight.
+    // (the host rounds gridDim.x up to a multiple of 8; tiles beyond the frame fail the bounds test below)
+    const uint32_t gx = gridDim.x;
+    const uint32_t b = blockIdx.x + blockIdx.y * gx;
+    const uint32_t strip = gx >> 3;
+    const uint32_t xcd = b & 7u, local = b >> 3;
+    const uint32_t bx = xcd * strip + local % strip, by = local / strip;
+    ix = (int32_t)(bx * 8u + (threadIdx.x & 7u));
+    iy = (int32_t)(by * 32u + (threadIdx.x >> 3));
     return ix < sf.width && iy < sf.height;
 }
+
+// x^128 by seven squarings (powf(x, 128.0f) of the reference: the same value up to a few dozen ulp, far inside the
+// frame tolerance, at 7 instead of ~60 instructions)
+ATN_DEV float pow128(float x)
+{
+    float r = x * x; r = r * r; r = r * r; r = r * r; r = r * r; r = r * r; r = r * r;
+    return r;
+}
+// expf as one v_exp_f32 (2^(x * log2 e)): relative error ~ |x| * 1e-7, again far inside the frame tolerance; the filter
+// weights it produces only ever multiply colours
+ATN_DEV float svgf_exp(float x) { return __expf(x); }
 
 __global__ void __launch_bounds__(256) k_svgf_fill(float4* p, uint32_t n, float4 v)
 {
@@ -220,9 +240,9 @@ __global__ void __launch_bounds__(256) k_svgf_variance(SvgfFrame sf)
                     const float uv_length = sqrtf((float)(u * u + v * v));
                     const float Wz = fabsf(s_nd.w - center_depth) / (pixel_distance_ratio * uv_length + 1e-2F);
                     const float dn = dot(mk3(s_nd), center_normal);
-                    const float Wn = powf(0.0F < dn ? dn : 0.0F, 128.0F);       // std::max(0.0f, d)
+                    const float Wn = pow128(0.0F < dn ? dn : 0.0F);       // std::max(0.0f, d)
                     const float Wm = center_meshid == sample_meshid ? 1.0F : 0.0F;
-                    const float W = expf(-Wz) * Wn * Wm;
+                    const float W = svgf_exp(-Wz) * Wn * Wm;
                     moment_sum = moment_sum + moment * W;
                     color = add4(color, mul4(W, sample_color));
                     weight += W;
@@ -289,7 +309,7 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
         }
     }
 
-    const float sigmaZ = 1.0F, sigmaN = 128.0F, sigmaL = 4.0F;
+    const float sigmaZ = 1.0F, sigmaL = 4.0F;       // sigmaN = 128: pow128
     const int32_t step_scale = 1 << iter;
     const float sqrt_gauss = sqrtf(gauss);
     const float center_luminance = luminance(center_color.x, center_color.y, center_color.z);
@@ -306,7 +326,10 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
         const int32_t sx = ox[i] * step_scale, sy = oy[i] * step_scale;
         const int32_t xx = clampi(ix + sx, 0, width - 1);
         const int32_t yy = clampi(iy + sy, 0, height - 1);
-        const float u_length = sqrtf((float)(sx * sx + sy * sy));
+        // sqrt(sx^2 + sy^2) = 2^iter * sqrt(ox^2 + oy^2): scaling by a power of two commutes with the correctly
+        // rounded square root, so the constant table gives the same float
+        const float ul = i < 4 ? 1.0F : i < 8 ? 2.0F : i < 12 ? 1.41421354F : i < 20 ? 2.23606801F : 2.82842708F;
+        const float u_length = (float)step_scale * ul;
         const int32_t qidx = xx + yy * width;
         const float4 q_nd = sf.nd[qidx];
         const int32_t meshid = (int32_t)sf.am[qidx].w;
@@ -315,11 +338,11 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
         const float lum = luminance(color.x, color.y, color.z);
         const float Wz = 3.0F * fabsf(center_depth - q_nd.w) / (sigmaZ * (pixel_distance_ratio * u_length) + 0.000001F);
         const float dn = dot(center_normal, mk3(q_nd));
-        const float Wn = powf(0.0F < dn ? dn : 0.0F, sigmaN);
-        const float el = expf(-fabsf(center_luminance - lum) / (sigmaL * sqrt_gauss + 0.000001F));
+        const float Wn = pow128(0.0F < dn ? dn : 0.0F);
+        const float el = svgf_exp(-fabsf(center_luminance - lum) / (sigmaL * sqrt_gauss + 0.000001F));
         const float Wl = 1.0F < el ? 1.0F : el;          // std::min(e, 1.0f)
         const float Wm = meshid == center_meshid ? 1.0F : 0.0F;
-        const float W = expf(-Wl * Wl - Wz) * Wn * Wm * hh;
+        const float W = svgf_exp(-Wl * Wl - Wz) * Wn * Wm * hh;
         sumC = add4(sumC, mul4(W, color));
         sumV += W * W * variance;
         weight += W;

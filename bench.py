@@ -58,9 +58,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="sponza", choices=["sponza", "cornell", "atrium"])
-    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config shortcuts: c2 = Cornell 1080p 1spp 5-bounce, c3 = Sponza 1080p 1spp 5-bounce "
-                         "(default), c4 = 4K 8spp 8-bounce Disney + textures on the procedural atrium stand-in")
+                         "(default), c4 = 4K 8spp 8-bounce Disney + textures on the procedural atrium stand-in, "
+                         "c5 = c3 + SVGF temporal/variance/a-trous passes (1 GPU)")
+    ap.add_argument("--svgf", action="store_true", help="a step = SVGFRenderer::OnRender (path pass with AOVs + filter passes)")
     ap.add_argument("--all-samples", action="store_true",
                     help="with spp > 1: trace every sample (the CPU reference stops a pixel's sample loop at the first "
                          "terminated path, pathtracing.cpp:350-352; default reproduces that)")
@@ -77,6 +79,8 @@ def main():
         args.scene = "cornell"
     elif args.config == "c4":
         args.scene, args.width, args.height, args.spp, args.depth, args.all_samples = "atrium", 3840, 2160, 8, 8, True
+    elif args.config == "c5":
+        args.svgf = True
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +130,15 @@ def main():
     full = None
     ext_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=dev) if use_dist else None
 
+    if args.svgf:
+        if world != 1:
+            raise SystemExit("--svgf / --config c5 is a 1-GPU configuration (filter footprints cross screen tiles)")
+        workload += " + SVGF (temporal reprojection, variance estimate, 5 a-trous iterations; motion from the compute pass)"
+
     def step(frame, profile):
+        if args.svgf:
+            r.svgf_render(W, H, depth, rr, spp=spp, frame=frame, compute_motion=True, download=False, profile=profile)
+            return
         r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
                  profile=profile)
         if use_dist:
@@ -200,7 +212,21 @@ def main():
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),
     }
-    kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items()}
+    kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
+    svgf_info = None
+    if args.svgf:
+        # compulsory HBM bytes per pixel and launch (every input plane read once, every output written once; the
+        # filter taps themselves are L2 hits): a-trous reads normal+depth, albedo+id, colour+variance and writes one
+        # plane (+ the temporary colour on the first and the output on the last iteration)
+        px = W * H
+        at_ms, at_n = ktimes["svgf_atrous"]
+        at_bytes = px * (48 + 16) + px * 32 / max(at_n / max(frames_prof, 1), 1)
+        at_launch_ms = at_ms / max(at_n, 1)
+        svgf_info = {"passes_ms_per_frame": {k: kernel_ms_per_frame[k] for k in kernel_ms_per_frame if k.startswith("svgf")},
+                     "atrous": {"bound": "hbm", "compulsory_bytes_per_launch": int(at_bytes), "avg_launch_ms": round(at_launch_ms, 5),
+                                "achieved": round(at_bytes / (at_launch_ms * 1e-3) / 1e9, 1) if at_n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(at_bytes / (at_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if at_n else None},
+                     "filter_ms_per_frame": round(sum(v for k, v in kernel_ms_per_frame.items() if k.startswith("svgf")), 4)}
     ray_segments = per_frame["closest_rays"] + per_frame["shadow_rays"]
 
     cpu_baseline = None
@@ -212,8 +238,12 @@ def main():
         ccam = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], cw, ch)
         cseeds = orc.init_sampler(cw, ch, 0)
 
+        cpu_svgf = orc.Svgf() if args.svgf else None
+
         def cpu_frame(f, nthreads=0):
-            if brk or spp == 1:
+            if cpu_svgf is not None:
+                cpu_svgf.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, compute_motion=True, nthreads=nthreads)
+            elif brk or spp == 1:
                 orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, nthreads=nthreads)
             else:       # every sample traced: spp passes of one sample (same work as the GPU's all-samples mode)
                 for i in range(spp):
@@ -241,7 +271,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5))
+            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5) and not args.svgf)
             else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -253,6 +283,7 @@ def main():
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},
             "kernel_ms_per_frame": kernel_ms_per_frame,
             "roofline": roofline,
+            "svgf": svgf_info,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

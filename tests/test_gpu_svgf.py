@@ -51,10 +51,12 @@ def test_svgf_filter_passes_on_equal_inputs(gpu, orc, sponza, cornell, which):
             got, gst = gpu.svgf_denoise(w, h, frame=frame, compute_motion=True, stages=True)
             assert frac_within(gpu.svgf_buffer("motion_depth"), sv.buffer("motion_depth"), 1e-5) == 1.0
             assert np.array_equal(gst[0].view(np.uint32), wst[0].view(np.uint32))
-            for s_, name, need in ((1, "temporal", 0.9995), (2, "variance", 0.999)):
+            # the variance is E[l^2] - E[l]^2 of radiances up to ~200 (the Cornell light): its cancellation noise alone
+            # is ~1e-3 absolute on a few pixels per thousand
+            for s_, name, need in ((1, "temporal", 0.9995), (2, "variance", 0.998)):
                 f = frac_within(gst[s_][..., :3], wst[s_][..., :3])
                 assert f >= need, (frame, name, f)
-            for name, need in (("prev_color_variance", 0.999), ("prev_moment_temporalweight", 0.9995), ("temporary_color", 0.999)):
+            for name, need in (("prev_color_variance", 0.998), ("prev_moment_temporalweight", 0.9995), ("temporary_color", 0.999)):
                 f = frac_within(gpu.svgf_buffer(name), sv.buffer(name))
                 assert f >= need, (frame, name, f)
             f = frac_within(got, want)

@@ -317,7 +317,18 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
     float sumV = center_color.w;
     float weight = 1.0F;
     const float pixel_distance_ratio = (center_depth / sf.camera_distance) * (float)height;
-    // tap tables of svgf_impl.h:693-726, generated: six groups of four
+    // The two per-tap divisions have denominators that do not depend on the tap (luminance) or only on its length
+    // class (depth): one reciprocal each per pixel, then a multiply per tap (<= 1 ulp from the quotient) instead of
+    // two IEEE divisions (~20 instructions) per tap.
+    const float inv_l = 1.0F / (sigmaL * sqrt_gauss + 0.000001F);
+    const float fs = (float)step_scale;
+    const float inv_z0 = 1.0F / (sigmaZ * (pixel_distance_ratio * (fs * 1.0F)) + 0.000001F);
+    const float inv_z1 = 1.0F / (sigmaZ * (pixel_distance_ratio * (fs * 2.0F)) + 0.000001F);
+    const float inv_z2 = 1.0F / (sigmaZ * (pixel_distance_ratio * (fs * 1.41421354F)) + 0.000001F);
+    const float inv_z3 = 1.0F / (sigmaZ * (pixel_distance_ratio * (fs * 2.23606801F)) + 0.000001F);
+    const float inv_z4 = 1.0F / (sigmaZ * (pixel_distance_ratio * (fs * 2.82842708F)) + 0.000001F);
+    // tap tables of svgf_impl.h:693-726, generated: six groups of four; sqrt(sx^2 + sy^2) = 2^iter * sqrt(ox^2 + oy^2)
+    // exactly (scaling by a power of two commutes with the correctly rounded square root)
 #pragma unroll
     for (int32_t i = 0; i < 24; i++) {
         constexpr int8_t ox[24] = { 1, 0, -1, 0, 2, 0, -2, 0, 1, -1, -1, 1, 1, -1, -1, 1, 2, -2, -2, 2, 2, -2, -2, 2 };
@@ -326,20 +337,17 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
         const int32_t sx = ox[i] * step_scale, sy = oy[i] * step_scale;
         const int32_t xx = clampi(ix + sx, 0, width - 1);
         const int32_t yy = clampi(iy + sy, 0, height - 1);
-        // sqrt(sx^2 + sy^2) = 2^iter * sqrt(ox^2 + oy^2): scaling by a power of two commutes with the correctly
-        // rounded square root, so the constant table gives the same float
-        const float ul = i < 4 ? 1.0F : i < 8 ? 2.0F : i < 12 ? 1.41421354F : i < 20 ? 2.23606801F : 2.82842708F;
-        const float u_length = (float)step_scale * ul;
+        const float inv_z = i < 4 ? inv_z0 : i < 8 ? inv_z1 : i < 12 ? inv_z2 : i < 20 ? inv_z3 : inv_z4;
         const int32_t qidx = xx + yy * width;
         const float4 q_nd = sf.nd[qidx];
         const int32_t meshid = (int32_t)sf.am[qidx].w;
         const float4 color = src[qidx];
         const float variance = color.w;
         const float lum = luminance(color.x, color.y, color.z);
-        const float Wz = 3.0F * fabsf(center_depth - q_nd.w) / (sigmaZ * (pixel_distance_ratio * u_length) + 0.000001F);
+        const float Wz = (3.0F * fabsf(center_depth - q_nd.w)) * inv_z;
         const float dn = dot(center_normal, mk3(q_nd));
         const float Wn = pow128(0.0F < dn ? dn : 0.0F);
-        const float el = svgf_exp(-fabsf(center_luminance - lum) / (sigmaL * sqrt_gauss + 0.000001F));
+        const float el = svgf_exp(-fabsf(center_luminance - lum) * inv_l);
         const float Wl = 1.0F < el ? 1.0F : el;          // std::min(e, 1.0f)
         const float Wm = meshid == center_meshid ? 1.0F : 0.0F;
         const float W = svgf_exp(-Wl * Wl - Wz) * Wn * Wm * hh;

@@ -43,6 +43,7 @@ struct PathBuffers {
 struct FrameParams {
     int32_t width, height;
     int32_t n_slots;            // local path slots (n_local_tiles * 64)
+    int32_t slot_begin, slot_end;   // the slots this launch works on (one batch of the frame, see PathTracing::render)
     int32_t tiles_x, tiles_y;
     int32_t rank, world;        // screen-space shard: tile t belongs to rank t % world
     int32_t max_depth, rr_depth;
@@ -144,8 +145,8 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
                                                    const uint32_t* __restrict__ seeds)
 {
     __shared__ BlockAppendShared sh;
-    const uint32_t n = (uint32_t)fp.n_slots;
-    for (uint32_t chunk = blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
+    const uint32_t n = (uint32_t)fp.slot_end;
+    for (uint32_t chunk = (uint32_t)fp.slot_begin + blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
         uint32_t flags = 0;
 #pragma unroll 1
         for (int k = 0; k < kChunkItems; k++) {
@@ -507,8 +508,8 @@ __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(P
 // accumulate, stop sampling this pixel once its path terminated.
 __global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, FrameParams fp)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (uint32_t)fp.n_slots) return;
+    const uint32_t slot = (uint32_t)fp.slot_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.slot_end) return;
     int32_t x, y;
     if (!slot_to_pixel(fp, slot, x, y)) return;
     if (fp.sample > 0 && pb.done[slot]) return;

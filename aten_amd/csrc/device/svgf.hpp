@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(256) k_svgf_fill(float4* p, uint32_t n, float4
 // skip the termination test.
 __global__ void __launch_bounds__(256) k_svgf_sample_end(PathBuffers pb, FrameParams fp, SvgfFrame sf)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (uint32_t)fp.n_slots) return;
+    const uint32_t slot = (uint32_t)fp.slot_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.slot_end) return;
     int32_t x, y;
     if (!slot_to_pixel(fp, slot, x, y)) return;
     if (fp.sample > 0 && pb.done[slot]) return;

@@ -80,6 +80,9 @@ class PathTracing:
         self.width, self.height = width, height
         return out
 
+    def set_path_batches(self, n):
+        self._check(self._l.atn_set_path_batches(self._ctx, n))
+
     def reset(self):
         self._check(self._l.atn_reset(self._ctx))
 

@@ -196,6 +196,21 @@ def main():
             tot[k] += s[k]
     per_frame = {k: v / n_count for k, v in tot.items()}
 
+    # the same frames once more with one kernel in flight at a time: per-kernel durations of isolated kernels
+    # (in the timed region up to three batches of the frame overlap on separate streams, so a launch shares the GPU)
+    r.set_path_batches(1)
+    r.reset()
+    r.reset_kernel_times()
+    n_excl = min(args.steps, 10)
+    for i in range(n_excl):
+        if args.svgf:
+            r.svgf_render(W, H, depth, rr, spp=spp, frame=i, compute_motion=True, download=False, profile=True)
+        else:
+            r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False, profile=True)
+    r.synchronize()
+    ktimes_excl = r.kernel_times()
+    r.set_path_batches(3)
+
     tc_ms, tc_n = ktimes["trace_closest"]
     frames_prof = args.steps
     bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"])
@@ -212,6 +227,16 @@ def main():
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),
     }
+    te_ms, te_n = ktimes_excl["trace_closest"]
+    excl_launch_ms = te_ms / max(te_n, 1)
+    excl_bytes = bytes_per_frame / max(te_n / max(n_excl, 1), 1)
+    roofline["isolated"] = {"avg_launch_ms": round(excl_launch_ms, 5), "launches": te_n,
+                            "algorithmic_bytes_per_launch": round(excl_bytes),
+                            "achieved": round(excl_bytes / (excl_launch_ms * 1e-3) / 1e9, 2) if te_n else None,
+                            "frac": round(excl_bytes / (excl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if te_n else None,
+                            "note": "same frames, atn_set_path_batches(1): one kernel in flight at a time"}
+    roofline["note"] += "; in the timed region up to 3 batches of the frame run on separate streams, so avg_launch_ms is the duration of a launch that shares the GPU with other kernels"
+    kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
     kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
     svgf_info = None
     if args.svgf:
@@ -282,6 +307,7 @@ def main():
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / args.steps), 2),
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},
             "kernel_ms_per_frame": kernel_ms_per_frame,
+            "kernel_ms_per_frame_isolated": kernel_ms_per_frame_isolated,
             "roofline": roofline,
             "svgf": svgf_info,
             "cpu_baseline": cpu_baseline,

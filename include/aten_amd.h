@@ -118,6 +118,12 @@ enum { ATN_K_GEN = 0, ATN_K_TRACE_CLOSEST = 1, ATN_K_SHADE = 2, ATN_K_TRACE_SHAD
 int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT]);
 int atn_reset_kernel_times(atn_ctx* ctx);
 
+/* Execution knob, no effect on results: the frame's paths are processed as up to `n` independent batches on
+ * `n` HIP streams so that one batch's kernels fill the GPU during another's launch tails (default 3, automatically
+ * fewer for small frames / shards; 1 = strictly one kernel at a time, which is what per-kernel timings of an
+ * isolated kernel need). */
+int atn_set_path_batches(atn_ctx* ctx, int32_t n);
+
 /* ---- SVGF (next tier, BASELINE config 5) -------------------------------------------------------
  * ≙ aten::SVGFRenderer (src/libaten/renderer/svgf/svgf.{h,cpp}): the path pass with AOV outputs
  * (SVGFRenderer::Shade / ShadeMiss with AOV spans) followed by the svgf_impl.h passes as HIP kernels --

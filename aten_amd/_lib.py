@@ -11,7 +11,7 @@ from . import build
 _lib = None
 
 K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sample", "gather",
-           "svgf_prepare", "svgf_temporal", "svgf_variance", "svgf_atrous"]
+           "svgf_prepare", "svgf_temporal", "svgf_variance", "svgf_atrous", "trace_fused"]
 
 SYMBOLS = [
     "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera", "atn_update_tlas",

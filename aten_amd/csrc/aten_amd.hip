@@ -64,6 +64,8 @@ public:
     hipStream_t bstream[kMaxBatches] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {};
     int n_batches = 3;
+    bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
+    bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
 
     // scene (HBM-resident after UpdateSceneData)
     DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels;
@@ -119,8 +121,10 @@ public:
             ATN_HIP(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
         }
         ATN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
         if (const char* e = std::getenv("ATEN_AMD_BATCHES")) {
             n_batches = std::atoi(e);
+            batches_forced = true;
             if (n_batches < 1) n_batches = 1;
             if (n_batches > kMaxBatches) n_batches = kMaxBatches;
         }
@@ -378,9 +382,14 @@ public:
     template <bool SVGF>
     int run_paths(const atn_destination* d, FrameParams fp, bool count, bool prof, const SvgfShade& sv, const SvgfFrame& sf)
     {
+        // Measured policy (sponza_lod / Cornell 1080p and its 2-, 4-, 8-way shards): overlap pays
+        // while launches are latency-bound (<= ~1 M paths in flight); on a full 1080p frame the concurrent shade kernel
+        // streams path state through the L2 that the walk wants for its nodes and the deep-tree walk loses more than
+        // the overlap wins (6.13 vs 6.59 ms), the shallow-tree walk still gains with two batches.
         int nb = n_batches;
-        const uint32_t min_batch = 200u * 1000u;            // measured: smaller batches lose more to launch floors than the overlap wins
+        const uint32_t min_batch = 200u * 1000u;
         while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
+        if (!batches_forced && n_slots >= 1500u * 1000u) nb = use_refill ? 1 : (nb < 2 ? nb : 2);
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
         per = (per + kChunk - 1u) / kChunk * kChunk;        // whole 1024-slot chunks (16 screen tiles)
         ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * 4 * counters_depth * 4, stream));
@@ -401,16 +410,34 @@ public:
                 prof_begin(prof, ATN_K_GEN, st);
                 hipLaunchKernelGGL(k_gen_path, dim3(g_slots), dim3(256), 0, st, pb, fp, camera, (const uint32_t*)seeds.p);
                 prof_end(prof);
-                for (int32_t b = 0; b < d->maxDepth; b++) {
-                    prof_begin(prof, ATN_K_TRACE_CLOSEST, st);
-                    launch_trace<false>(pb, g_trace, count, b, st);
-                    prof_end(prof);
-                    prof_begin(prof, ATN_K_SHADE, st);
-                    hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_slots), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
-                    prof_end(prof);
-                    prof_begin(prof, ATN_K_TRACE_SHADOW, st);
-                    launch_trace<true>(pb, g_trace, count, b, st);
-                    prof_end(prof);
+                if (count || !fuse_traces) {
+                    for (int32_t b = 0; b < d->maxDepth; b++) {
+                        prof_begin(prof, ATN_K_TRACE_CLOSEST, st);
+                        launch_trace<false>(pb, g_trace, count, b, st);
+                        prof_end(prof);
+                        prof_begin(prof, ATN_K_SHADE, st);
+                        hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_slots), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                        prof_end(prof);
+                        prof_begin(prof, ATN_K_TRACE_SHADOW, st);
+                        launch_trace<true>(pb, g_trace, count, b, st);
+                        prof_end(prof);
+                    }
+                }
+                else {
+                    // depth + 1 trace launches: [closest 0], [shadow b + closest b+1] ..., [shadow depth-1]
+                    const uint32_t g_fused = trace_grid(2u * n);
+                    for (int32_t b = 0; b <= d->maxDepth; b++) {
+                        const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
+                        prof_begin(prof, ATN_K_TRACE_FUSED, st);
+                        if (use_refill) hipLaunchKernelGGL((k_trace_fused<true>), dim3(g_fused), dim3(kTraceBlock), 0, st, pb, scene, bs, bc, b);
+                        else hipLaunchKernelGGL((k_trace_fused<false>), dim3(g_fused), dim3(kTraceBlock), 0, st, pb, scene, bs, bc, b);
+                        prof_end(prof);
+                        if (b < d->maxDepth) {
+                            prof_begin(prof, ATN_K_SHADE, st);
+                            hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_slots), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                            prof_end(prof);
+                        }
+                    }
                 }
                 prof_begin(prof, ATN_K_ACCUM, st);
                 if (SVGF) hipLaunchKernelGGL(k_svgf_sample_end, dim3(g_all), dim3(256), 0, st, pb, fp, sf);
@@ -729,6 +756,7 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n)
     CTX_OR_FAIL(ctx);
     if (n < 1 || n > PathTracing::kMaxBatches) return ctx->r.fail(ATN_ERR_INVALID_ARG, "batch count out of range");
     ctx->r.n_batches = n;
+    ctx->r.batches_forced = n == 1;     // 1 = strictly serial; larger values stay subject to the size policy
     return ATN_OK;
 }
 

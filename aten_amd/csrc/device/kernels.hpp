@@ -504,6 +504,43 @@ __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(P
     }
 }
 
+// One launch for the shadow rays of bounce `bs` AND the closest-hit rays of bounce `bc` (both are products of
+// shade(bs); bc = bs + 1): every trace launch carries a size-independent ~0.13 ms (the dependent-load chain of its
+// longest ray), so a frame pays it depth + 1 times instead of 2 * depth times, and each launch has twice the rays to
+// fill the machine with.  The two job kinds touch disjoint state (shadow: contrib; closest: isect).  bs < 0 or
+// bc < 0 = that half is absent (first / last launch of a sample).
+struct FusedJob {
+    ShadowJob s;
+    ClosestJob c;
+    uint32_t n_shadow;
+    float t_min;
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    {
+        if (j < n_shadow) {
+            s.fetch(j, a, b);
+            b.w = __uint_as_float(__float_as_uint(b.w) | 0x80000000u);
+        }
+        else {
+            c.fetch(j - n_shadow, a, b);
+        }
+    }
+    ATN_DEV void finish(uint32_t payload, const Hit& h, bool is_hit) const
+    {
+        if (payload & 0x80000000u) s.finish(payload & 0x7fffffffu, h, is_hit);
+        else c.finish(payload, h, is_hit);
+    }
+};
+
+template <bool REFILL>
+__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
+{
+    const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
+    const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
+    const FusedJob job{ ShadowJob{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
+    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    trace_dispatch<false, REFILL>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
+}
+
 // Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,
 // accumulate, stop sampling this pixel once its path terminated.
 __global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, FrameParams fp)

@@ -36,7 +36,7 @@ def algorithmic_bytes(nodes, tris, rays):
     return 48 * nodes + 80 * tris + 56 * rays
 
 
-def measured_traffic(scene, w, h):
+def measured_traffic(scene, w, h, kernel="k_trace_closest"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*traffic.json,
     written from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); None when
     no profile matches the workload."""
@@ -47,7 +47,7 @@ def measured_traffic(scene, w, h):
             d = json.load(open(f))
         except Exception:
             continue
-        if scene in d.get("workload", "") and ("%dx%d" % (w, h)) in d.get("workload", ""):
+        if scene in d.get("workload", "") and ("%dx%d" % (w, h)) in d.get("workload", "") and d.get("kernel", "").startswith(kernel):
             best = d
     return best
 
@@ -211,15 +211,24 @@ def main():
     ktimes_excl = r.kernel_times()
     r.set_path_batches(3)
 
-    tc_ms, tc_n = ktimes["trace_closest"]
     frames_prof = args.steps
-    bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"])
+    if ktimes["trace_fused"][1]:
+        # the frame's trace work runs as depth + 1 launches of k_trace_fused (shadow rays of bounce b + closest-hit
+        # rays of bounce b + 1): that kernel is the dominant one
+        dominant, tkey = "k_trace_fused", "trace_fused"
+        bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"] + per_frame["shadow_nodes"],
+                                            per_frame["closest_tris"] + per_frame["shadow_tris"],
+                                            per_frame["closest_rays"] + per_frame["shadow_rays"])
+    else:
+        dominant, tkey = "k_trace_closest", "trace_closest"
+        bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"])
+    tc_ms, tc_n = ktimes[tkey]
     launches_per_frame = tc_n / max(frames_prof, 1)
     avg_launch_ms = tc_ms / max(tc_n, 1)
     achieved = (bytes_per_frame / max(launches_per_frame, 1)) / (avg_launch_ms * 1e-3) / 1e9 if tc_n else 0.0
-    tr = measured_traffic({"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene], W, H) if world == 1 else None
+    tr = measured_traffic({"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene], W, H, dominant) if world == 1 else None
     roofline = {
-        "kernel": "k_trace_closest", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
         "traffic_source": tr["source"] if tr else None,
@@ -227,7 +236,7 @@ def main():
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),
     }
-    te_ms, te_n = ktimes_excl["trace_closest"]
+    te_ms, te_n = ktimes_excl[tkey]
     excl_launch_ms = te_ms / max(te_n, 1)
     excl_bytes = bytes_per_frame / max(te_n / max(n_excl, 1), 1)
     roofline["isolated"] = {"avg_launch_ms": round(excl_launch_ms, 5), "launches": te_n,

@@ -112,7 +112,8 @@ int atn_get_stats(atn_ctx* ctx, uint64_t out[8]);
 enum { ATN_K_GEN = 0, ATN_K_TRACE_CLOSEST = 1, ATN_K_SHADE = 2, ATN_K_TRACE_SHADOW = 3,
        ATN_K_ACCUM = 4, ATN_K_GATHER = 5,
        ATN_K_SVGF_PREPARE = 6, ATN_K_SVGF_TEMPORAL = 7, ATN_K_SVGF_VARIANCE = 8, ATN_K_SVGF_ATROUS = 9,
-       ATN_K_COUNT = 10 };
+       ATN_K_TRACE_FUSED = 10,      /* shadow rays of bounce b + closest-hit rays of bounce b+1 in one launch */
+       ATN_K_COUNT = 11 };
 /* HIP-event time (ms) and launch count per kernel class, accumulated over every atn_render with
  * profile = 1 since the last atn_reset_kernel_times. */
 int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT]);

@@ -299,6 +299,37 @@ def test_atrium_instanced_disney_textured(gpu, orc):
                 assert np.array_equal(np.isnan(got[..., :3]).any(-1), np.isnan(want[..., :3]).any(-1))
 
 
+def test_launch_schedules_give_identical_frames(orc, sponza, monkeypatch):
+    """How the frame's work is cut into launches is an execution detail: unfused trace launches, fused ones
+    (shadow b + closest b+1), 1 / 2 / 3 batches on separate streams must all give the same bytes, and the work
+    counters of a counted frame must not depend on it either."""
+    from aten_amd.renderer import PathTracing
+    fs, cam = sponza
+    w, h = 640, 360     # 230 K slots: enough for the policy to allow batches when forced
+    c = make_camera(orc, cam, w, h)
+    frames, stats = [], []
+    for fuse, batches in (("0", "1"), ("1", "1"), ("1", "2"), ("0", "3"), ("1", "3")):
+        monkeypatch.setenv("ATEN_AMD_FUSE", fuse)
+        monkeypatch.setenv("ATEN_AMD_BATCHES", batches)
+        g = PathTracing(0)
+        try:
+            g.UpdateSceneData(fs)
+            g.updateCamera(c)
+            g.initSampler(w, h, 0)
+            g.setScreenShard(0, 1)
+            g.reset()
+            img = g.render(w, h, 5, 3, spp=2, frame=3, break_on_terminate=False)
+            g.reset()
+            g.render(w, h, 5, 3, frame=3, count_stats=True)
+            frames.append(img)
+            stats.append(g.stats())
+        finally:
+            g.close()
+    for img, st in zip(frames[1:], stats[1:]):
+        assert img.tobytes() == frames[0].tobytes()
+        assert st == stats[0]
+
+
 def test_update_top_layer_equals_full_upload(gpu, orc):
     """atn_update_tlas (idaten::Renderer::updateBVH, renderer.cpp:133-153): moving the instanced boxes through
     an object/matrix/top-layer update gives the same bytes as uploading the moved scene from scratch, also

@@ -821,12 +821,18 @@ int atn_synchronize(atn_ctx* ctx)
 
 int atn_assemble_tiles(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out)
 {
+    return atn_assemble_tiles_on(ctx, gathered_dev, world, film_dev_out, nullptr);
+}
+
+int atn_assemble_tiles_on(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out, void* hip_stream)
+{
     CTX_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r.stream;
     if (!gathered_dev || world <= 0 || r.film_w <= 0) return r.fail(ATN_ERR_INVALID_ARG, "atn_assemble_tiles: nothing rendered yet");
     float4* dst = film_dev_out ? (float4*)film_dev_out : r.film.p;
     const uint32_t total = (uint32_t)world * r.n_slots;
-    hipLaunchKernelGGL(atn::k_assemble_tiles, dim3((total + 255) / 256), dim3(256), 0, r.stream,
+    hipLaunchKernelGGL(atn::k_assemble_tiles, dim3((total + 255) / 256), dim3(256), 0, st,
                        (const float4*)gathered_dev, dst, r.film_w, r.film_h, (r.film_w + 7) / 8, (r.film_h + 7) / 8,
                        world, (int32_t)r.n_slots);
     C_HIP(r, hipGetLastError());

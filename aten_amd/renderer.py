@@ -102,8 +102,8 @@ class PathTracing:
     def stream_ptr(self):
         return self._l.atn_stream(self._ctx)
 
-    def assemble_tiles(self, gathered_dev_ptr, world, out_dev_ptr=None):
-        self._check(self._l.atn_assemble_tiles(self._ctx, gathered_dev_ptr, world, out_dev_ptr))
+    def assemble_tiles(self, gathered_dev_ptr, world, out_dev_ptr=None, stream_ptr=None):
+        self._check(self._l.atn_assemble_tiles_on(self._ctx, gathered_dev_ptr, world, out_dev_ptr, stream_ptr))
 
     def download_film(self):
         out = np.empty((self.height, self.width, 4), np.float32)

@@ -10,8 +10,9 @@ GGX materials, textures and a synthetic IBL (aten_amd/scene/scenedefs.py:sponza_
 A step = one frame (one pass of the radiance loop over every pixel).  The scene, seeds and path
 state are resident in HBM before the timed region.  With N > 1 the screen is sharded in 8x8 tiles
 (tile t -> rank t % N), every rank renders its tiles and the tile buffers are all-gathered over
-RCCL and assembled into the full frame on every rank inside the timed step ("strong" scaling:
-the image is fixed).
+RCCL and assembled into the full frame on every rank ("strong" scaling: the image is fixed).  The
+exchange of frame f runs on a communication stream while the renderer's stream traces frame f + 1;
+the timed region ends only when the last frame is assembled on every rank.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scene sponza|cornell] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -126,34 +127,41 @@ def main():
     r.initSampler(W, H, 0)
     r.setScreenShard(rank, world)
 
-    gathered = None
-    full = None
+    # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
+    # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
+    # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
     ext_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=dev) if use_dist else None
-
-    if args.svgf:
-        if world != 1:
-            raise SystemExit("--svgf / --config c5 is a 1-GPU configuration (filter footprints cross screen tiles)")
-        workload += " + SVGF (temporal reprojection, variance estimate, 5 a-trous iterations; motion from the compute pass)"
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
+    full = None
 
     def step(frame, profile):
+        nonlocal full
         if args.svgf:
             r.svgf_render(W, H, depth, rr, spp=spp, frame=frame, compute_motion=True, download=False, profile=profile)
             return
         r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
                  profile=profile)
         if use_dist:
-            # Exchange step: every rank contributes its tile buffer; no host synchronisation -- the collective
-            # is issued from the renderer's own HIP stream (torch orders RCCL's stream against it with events),
-            # and the assemble kernel follows on that stream.
-            nonlocal gathered, full
             n = r.tile_slots()
-            if gathered is None:
-                gathered = torch.empty((world * n, 4), dtype=torch.float32, device=dev)
+            k = frame & 1
+            if stage[k] is None:
+                stage[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+                gathered[k] = torch.empty((world * n, 4), dtype=torch.float32, device=dev)
+                ev_ready[k] = torch.cuda.Event()
+                ev_free[k] = torch.cuda.Event()
+                ev_free[k].record(comm_stream)
+            if full is None:
                 full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
             with torch.cuda.stream(ext_stream):
-                mine = tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev)
-                dist.all_gather_into_tensor(gathered, mine)
-            r.assemble_tiles(gathered.data_ptr(), world, full.data_ptr())
+                ext_stream.wait_event(ev_free[k])           # the exchange of frame f - 2 has read stage[k]
+                stage[k].copy_(tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev))
+                ev_ready[k].record(ext_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev_ready[k])
+                dist.all_gather_into_tensor(gathered[k], stage[k])
+                r.assemble_tiles(gathered[k].data_ptr(), world, full.data_ptr(), comm_stream.cuda_stream)
+                ev_free[k].record(comm_stream)
 
     def sync_all():
         r.synchronize()

@@ -101,6 +101,9 @@ int atn_synchronize(atn_ctx* ctx);
 /* Scatter an all-gathered tile buffer (rank-major, world * atn_tile_slots float4, device memory)
  * into film_dev_out (float4[width*height], device memory; NULL = the context's own film). */
 int atn_assemble_tiles(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out);
+/* Same, on a caller's HIP stream (hipStream_t; NULL = the context's): lets the exchange + assembly of frame f run
+ * on a communication stream while the context's stream already renders frame f + 1. */
+int atn_assemble_tiles_on(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out, void* hip_stream);
 int atn_download_film(atn_ctx* ctx, atn_vec4* out_host);
 
 /* Counters of the last atn_render with count_stats = 1:

@@ -35,6 +35,8 @@ constexpr uint32_t kNodeBytes = 48;
 constexpr int32_t kTagDead = 8;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
+constexpr uint32_t kAttrIdealRefraction = 0x10000u;   // MaterialParameter::isIdealRefraction, folded into attrib at upload
+
 struct DevMaterial {
     float4 baseColor;
     int32_t type;

@@ -388,6 +388,131 @@ ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, c
     res.dir = wo;
 }
 
+// Refraction, material/refraction.cpp:62-161 + material::ComputeRefractVector (material.h:549-576)
+ATN_DEV f3 refract_vector(float ni, float nt, const f3& wi, const f3& n)
+{
+    const f3 w = -wi;
+    f3 N = n;
+    float costheta = dot(w, n);
+    if (costheta < 0.0F) { const float t = ni; ni = nt; nt = t; costheta = -costheta; N = -N; }
+    const float sintheta_2 = 1.0F - costheta * costheta;
+    const float ni_nt = ni / nt;
+    const float ni_nt_2 = ni_nt * ni_nt;
+    const f3 wo = (ni_nt * costheta - sqrtf(1.0F - ni_nt_2 * sintheta_2)) * N - ni_nt * w;
+    return normalize(wo);
+}
+ATN_DEV f3 refraction_brdf(float ni, float nt, const f3& wo, const f3& n, float transmittance)
+{
+    const float c = fabsf(dot(wo, n));
+    const float nt_ni = nt / ni;
+    return mk3(c == 0.0F ? 0.0F : ((nt_ni * nt_ni) * transmittance) / c);
+}
+ATN_DEV void refraction_sample(MtrlSample& r, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp)
+{
+    float ni = 1.0F, nt = m.ior;
+    const f3 V = -wi;
+    f3 N = n;
+    if (!(dot(V, N) >= 0.0F)) { N = -n; const float t = ni; ni = nt; nt = t; }
+    const float ni_nt = ni / nt;
+    const float cos_i = dot(V, N);
+    const float cos_t_2 = 1.0F - ((ni_nt * ni_nt) * (1.0F - cos_i * cos_i));
+    if (cos_t_2 < 0.0F) { const float t = ni; ni = nt; nt = t; N = -N; }
+    f3 wo = refract_vector(ni, nt, wi, N);
+    const float R = schlick_fresnel(ni, nt, wo, N);
+    const float T = 1 - R;
+    if (m.attrib & kAttrIdealRefraction) {
+        r.pdf = 1.0F; r.dir = wo; r.bsdf = refraction_brdf(ni, nt, wo, N, T);
+        return;
+    }
+    const float prob = 0.25F + 0.5F * R;
+    const float u = cmj_next(smp);
+    if (u < prob) {
+        wo = reflect_vector(wi, N);
+        const float c = fabsf(dot(wo, N));
+        r.pdf = prob; r.dir = wo; r.bsdf = mk3(c == 0.0F ? 0.0F : R / c);
+    }
+    else {
+        r.pdf = 1.0F - prob; r.dir = wo; r.bsdf = refraction_brdf(ni, nt, wo, N, T);
+    }
+}
+
+// MicrofacetBeckman, material/beckman.cpp:103-255
+ATN_DEV float beckman_D(const f3& m, const f3& n, float roughness)
+{
+    const float costheta = fabsf(dot(m, n));
+    if (costheta <= 0) return 0;
+    const float cos2 = costheta * costheta;
+    const float cos4 = cos2 * cos2;
+    const float sintheta = sqrtf(1 - cos2);
+    const float tantheta = sintheta / costheta;
+    const float tan2 = tantheta * tantheta;
+    const float a2 = roughness * roughness;
+    float D = 1.0f / ((kPi * a2) * cos4);
+    D *= expf(-tan2 / a2);
+    return D;
+}
+ATN_DEV float beckman_pdf(float roughness, const f3& n, const f3& wi, const f3& wo)
+{
+    const f3 wh = normalize(-wi + wo);
+    const float costheta = fabsf(dot(wh, n));
+    const float D = beckman_D(wh, n, roughness);
+    const float denom = 4 * fabsf(dot(wo, wh));
+    return denom > 0 ? (D * costheta) / denom : 0;
+}
+ATN_DEV f3 beckman_sample_m(float roughness, const f3& n, float r1, float r2)
+{
+    const float a2 = roughness * roughness;
+    const float theta = atanf(sqrtf(-a2 * logf(1.0F - r1 * 0.99F)));
+    const float phi = kPi2 * r2;
+    const float costheta = cosf(theta), sintheta = sinf(theta);
+    const float cosphi = cosf(phi), sinphi = sinf(phi);
+    f3 t, b;
+    tangent_coordinate(n, t, b);
+    const f3 m = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + n * costheta;
+    return normalize(m);
+}
+ATN_DEV float beckman_G1(float roughness, const f3& v, const f3& n)
+{
+    const float costheta = sclamp(fabsf(dot(v, n)), 0.0F, 1.0F);
+    const float sintheta = sqrtf(1.0F - costheta * costheta);
+    const float tantheta = sintheta / costheta;
+    const float a = 1.0F / (roughness * tantheta);
+    const float a2 = a * a;
+    if (a < 1.6F) return (3.535F * a + 2.181F * a2) / ((1.0F + 2.276F * a) + 2.577F * a2);
+    return 1.0F;
+}
+ATN_DEV f3 beckman_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo)
+{
+    const f3 V = -wi, L = wo;
+    const f3 H = normalize(L + V);
+    const float NL = fabsf(dot(N, L));
+    const float NV = fabsf(dot(N, V));
+    const float D = beckman_D(H, N, roughness);
+    const float G2 = beckman_G1(roughness, V, N) * beckman_G1(roughness, L, N);
+    const float F = schlick_fresnel(1.0F, ior, L, H);
+    const float denom = (4 * NL) * NV;
+    return mk3(denom > kEps ? ((F * G2) * D) / denom : 0.0f);
+}
+
+// OrenNayar, material/oren_nayar.cpp:8-140
+ATN_DEV float oren_nayar_pdf(const f3& normal, const f3& wo)
+{
+    const float NL = dot(normal, wo);
+    return NL > 0 ? NL / kPi : 0.0F;
+}
+ATN_DEV f3 oren_nayar_brdf(float roughness, const f3& normal, const f3& wi, const f3& wo)
+{
+    const float NL = dot(normal, wo);
+    const float NV = dot(normal, -wi);
+    const float a2 = roughness * roughness;
+    const float A = 1.0F - 0.5F * (a2 / (a2 + 0.33F));
+    const float B = 0.45F * (a2 / (a2 + 0.09F));
+    const float LV = dot(wo, -wi);
+    const float s = LV - NL * NV;
+    const float t = s <= 0 ? 1.0F : s / smax(NL, NV);
+    return mk3((1.0F / kPi) * (A + B * smax(0.0F, s / t)));
+}
+
 // material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
 ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
                              const f3& wi, Cmj& smp, float u, float v)
@@ -411,6 +536,24 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
     case ATN_MTRL_DISNEY:
         disney_sample(r, m, normal, wi, smp);
         break;
+    case ATN_MTRL_REFRACTION:
+        refraction_sample(r, m, normal, wi, smp);
+        break;
+    case ATN_MTRL_BECKMAN: {
+        const float rough = ggx_roughness(sc, m, u, v);
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        r.dir = reflect_vector(wi, beckman_sample_m(rough, normal, r1, r2));
+        r.pdf = beckman_pdf(rough, normal, wi, r.dir);
+        r.bsdf = beckman_brdf(rough, m.ior, normal, wi, r.dir);
+        break;
+    }
+    case ATN_MTRL_OREN_NAYAR: {
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        r.dir = diffuse_dir(normal, r1, r2);
+        r.pdf = oren_nayar_pdf(normal, r.dir);
+        r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+        break;
+    }
     default: {  // Diffuse, Emissive (emissive.h:70-83) and the reference's fallback
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
         r.dir = diffuse_dir(normal, r1, r2);
@@ -424,6 +567,9 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
 {
     switch (m.type) {
     case ATN_MTRL_SPECULAR: return 1.0F;
+    case ATN_MTRL_REFRACTION: return 1.0F;
+    case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
+    case ATN_MTRL_OREN_NAYAR: return oren_nayar_pdf(normal, wo);
     case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
     default: return diffuse_pdf(normal, wo);
@@ -435,6 +581,9 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     switch (m.type) {
     case ATN_MTRL_SPECULAR: { const float c = dot(normal, wo); r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c); break; }
     case ATN_MTRL_GGX: r.bsdf = ggx_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
+    case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); break;
+    case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
+    case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
     case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
     default: r.bsdf = diffuse_brdf(); break;
     }

@@ -186,7 +186,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         const atn_material_param& m = s->materials[i];
         DevMaterial& d = img.materials[i];
         d.baseColor = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, m.baseColor.w);
-        d.type = m.type; d.attrib = m.attrib; d.id = m.id;
+        d.type = m.type; d.attrib = (m.attrib & 0xFu) | (m.isIdealRefraction ? kAttrIdealRefraction : 0u); d.id = m.id;
         d.albedoMap = m.albedoMap; d.normalMap = m.normalMap; d.roughnessMap = m.roughnessMap;
         const atn_standard_mtrl& st = m.u.standard;
         d.ior = st.ior; d.roughness = st.roughness; d.subsurface = st.subsurface; d.metallic = st.metallic;

@@ -83,6 +83,9 @@ MTRL_ATTRIB = {
     MTRL_DIFFUSE: 0,
     MTRL_SPECULAR: ATTR_SINGULAR | ATTR_GLOSSY,
     MTRL_GGX: ATTR_GLOSSY,
+    MTRL_BECKMAN: ATTR_GLOSSY,
+    MTRL_OREN_NAYAR: 0,
+    MTRL_REFRACTION: ATTR_SINGULAR | ATTR_TRANSLUCENT | ATTR_GLOSSY,
     MTRL_DISNEY: ATTR_GLOSSY,
 }
 LIGHT_AREA, LIGHT_IBL, LIGHT_DIRECTION, LIGHT_POINT, LIGHT_SPOT = range(5)

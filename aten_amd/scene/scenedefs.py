@@ -105,7 +105,7 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
     return b.build(), cam
 
 
-def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
+def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None, extra_materials=False):
     """Parity-test variant of the Cornell box (not a reference scene): the two boxes are instanced with
     non-identity matrices (translation / rotation about y, so the W2L ray transform, the L2W hit transform
     and the instance area ratio are exercised) and the light set is selectable:
@@ -123,6 +123,12 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None):
                                   specular=0.6, clearcoat=0.4, clearcoatGloss=0.7, sheen=0.3)
         if name == "floor":
             return b.add_material(name, L.MTRL_GGX, (0.7, 0.6, 0.5), roughness=0.1, ior=0.01)
+        if extra_materials and name == "tallBox":       # glass (refraction.cpp), like the reference's glass spheres
+            return b.add_material(name, L.MTRL_REFRACTION, (0.9, 0.9, 0.9), ior=1.5)
+        if extra_materials and name == "leftWall":
+            return b.add_material(name, L.MTRL_OREN_NAYAR, clr, roughness=0.6)
+        if extra_materials and name == "backWall":
+            return b.add_material(name, L.MTRL_BECKMAN, (0.7, 0.7, 0.7), roughness=0.25, ior=0.2)
         return b.add_material(name, mtype, clr)
 
     objs = b.load_obj(os.path.join(asset_dir, "orig.obj"), create_mtrl=create_mtrl,

@@ -391,6 +391,169 @@ inline void sample(MaterialSampling& result, const atn_material_param& mtrl, con
 }
 }
 
+// ---- Refraction: material/refraction.cpp:62-161, material.h:549-576 (ComputeRefractVector) ------
+namespace Refraction {
+inline v3 ComputeRefractVector(float ni, float nt, const v3& wi, const v3& n)
+{
+    const v3 w = -wi;
+    v3 N = n;
+    float costheta = dot(w, n);
+    if (costheta < 0.0F) { std::swap(ni, nt); costheta = -costheta; N = -N; }
+    const float sintheta_2 = 1.0F - costheta * costheta;
+    const float ni_nt = ni / nt;
+    const float ni_nt_2 = ni_nt * ni_nt;
+    v3 wo = (ni_nt * costheta - std::sqrt(1.0F - ni_nt_2 * sintheta_2)) * N - ni_nt * w;
+    return normalize(wo);
+}
+inline v3 ComputeBRDF(float ni, float nt, const v3& wo, const v3& n, float fresnel_transmittance)
+{
+    const float c = std::abs(dot(wo, n));
+    const float nt_ni = nt / ni;
+    const float bsdf = c == 0.0F ? 0.0F : (nt_ni * nt_ni) * fresnel_transmittance / c;
+    return v3(bsdf);
+}
+inline void sample(MaterialSampling& result, CMJ* sampler, const atn_material_param& param, const v3& n, const v3& wi)
+{
+    float ni = 1.0F;
+    float nt = param.u.standard.ior;
+    const v3 V = -wi;
+    v3 N = n;
+    const bool is_enter = dot(V, N) >= 0.0F;
+    if (!is_enter) { N = -n; std::swap(ni, nt); }
+    const float ni_nt = ni / nt;
+    const float cos_i = dot(V, N);
+    const float cos_t_2 = 1.0F - (ni_nt * ni_nt * (1.0F - cos_i * cos_i));
+    if (cos_t_2 < 0.0F) { std::swap(ni, nt); N = -N; }
+    v3 wo = ComputeRefractVector(ni, nt, wi, N);
+    const float F = ComputeSchlickFresnel(ni, nt, wo, N);
+    const float R = F;
+    const float T = 1 - R;
+    if (param.isIdealRefraction) {
+        result.pdf = 1.0F; result.dir = wo; result.bsdf = ComputeBRDF(ni, nt, wo, N, T);
+        return;
+    }
+    const float prob = 0.25F + 0.5F * R;
+    const float u = sampler->nextSample();
+    if (u < prob) {
+        wo = ComputeReflectVector(wi, N);
+        const float c = std::abs(dot(wo, N));
+        const float bsdf = c == 0.0F ? 0.0F : R / c;
+        result.pdf = prob; result.dir = wo; result.bsdf = v3(bsdf);
+    }
+    else {
+        result.pdf = 1.0F - prob; result.dir = wo; result.bsdf = ComputeBRDF(ni, nt, wo, N, T);
+    }
+}
+} // namespace Refraction
+
+// ---- MicrofacetBeckman: material/beckman.cpp:103-255 ---------------------------------------------
+namespace Beckman {
+inline float ComputeDistribution(const v3& m, const v3& n, float roughness)
+{
+    const float costheta = std::abs(dot(m, n));
+    if (costheta <= 0) return 0;
+    const float cos2 = costheta * costheta;
+    const float cos4 = cos2 * cos2;
+    const float sintheta = std::sqrt(1 - cos2);
+    const float tantheta = sintheta / costheta;
+    const float tan2 = tantheta * tantheta;
+    const float a = roughness;
+    const float a2 = a * a;
+    float D = 1.0f / (PI * a2 * cos4);
+    D *= std::exp(-tan2 / a2);
+    return D;
+}
+inline float ComputePDF(float roughness, const v3& n, const v3& wi, const v3& wo)
+{
+    const v3 wh = normalize(-wi + wo);
+    const float costheta = std::abs(dot(wh, n));
+    const float D = ComputeDistribution(wh, n, roughness);
+    const float denom = 4 * std::abs(dot(wo, wh));
+    return denom > 0 ? (D * costheta) / denom : 0;
+}
+inline v3 SampleMicrosurfaceNormal(float roughness, const v3& n, float r1, float r2)
+{
+    const float a = roughness;
+    const float a2 = a * a;
+    const float theta = std::atan(std::sqrt(-a2 * std::log(1.0F - r1 * 0.99F)));
+    const float phi = PI_2 * r2;
+    const float costheta = std::cos(theta);
+    const float sintheta = std::sin(theta);
+    const float cosphi = std::cos(phi);
+    const float sinphi = std::sin(phi);
+    v3 t, b;
+    GetTangentCoordinate(n, t, b);
+    v3 m = t * sintheta * cosphi + b * sintheta * sinphi + n * costheta;
+    return normalize(m);
+}
+inline float ComputeG1(float roughness, const v3& v, const v3& n)
+{
+    const float costheta = saturate_(std::abs(dot(v, n)));
+    const float sintheta = std::sqrt(1.0F - costheta * costheta);
+    const float tantheta = sintheta / costheta;
+    const float a = 1.0F / (roughness * tantheta);
+    const float a2 = a * a;
+    if (a < 1.6F) return (3.535F * a + 2.181F * a2) / (1.0F + 2.276F * a + 2.577F * a2);
+    return 1.0F;
+}
+inline v3 ComputeBRDF(float roughness, float ior, const v3& n, const v3& wi, const v3& wo)
+{
+    const v3 V = -wi, L = wo, N = n;
+    const v3 H = normalize(L + V);
+    const float NL = std::abs(dot(N, L));
+    const float NV = std::abs(dot(N, V));
+    const float D = ComputeDistribution(H, N, roughness);
+    const float G2 = ComputeG1(roughness, V, N) * ComputeG1(roughness, L, N);
+    const float F = ComputeSchlickFresnel(1.0F, ior, L, H);
+    const float denom = 4 * NL * NV;
+    const float bsdf = denom > EPS ? F * G2 * D / denom : 0.0f;
+    return v3(bsdf);
+}
+inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_param& p, const v3& normal, const v3& wi,
+    CMJ* sampler, float u, float v)
+{
+    const float roughness = GGX::roughness_of(ctxt, p, u, v);     // same sampleTexture(roughnessMap, vec4(roughness)).r
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    const v3 m = SampleMicrosurfaceNormal(roughness, normal, r1, r2);
+    res->dir = ComputeReflectVector(wi, m);
+    res->pdf = ComputePDF(roughness, normal, wi, res->dir);
+    res->bsdf = ComputeBRDF(roughness, p.u.standard.ior, normal, wi, res->dir);
+}
+} // namespace Beckman
+
+// ---- OrenNayar: material/oren_nayar.cpp:8-140 ------------------------------------------------------
+namespace OrenNayar {
+inline float pdf(const v3& normal, const v3& wo)
+{
+    const float NL = dot(normal, wo);
+    return NL > 0 ? NL / PI : 0.0F;
+}
+inline v3 computeBsdf(float roughness, const v3& normal, const v3& wi, const v3& wo)
+{
+    const float NL = dot(normal, wo);
+    const float NV = dot(normal, -wi);
+    const float a = roughness;
+    const float a2 = a * a;
+    const float A = float(1) - float(0.5) * (a2 / (a2 + float(0.33)));
+    const float B = float(0.45) * (a2 / (a2 + float(0.09)));
+    const float LV = dot(wo, -wi);
+    const float s = LV - NL * NV;
+    const float t = s <= 0 ? float(1) : s / std::max(NL, NV);
+    const float bsdf = (1.0F / PI) * (A + B * std::max(float(0), s / t));
+    return v3(bsdf);
+}
+inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_param& p, const v3& normal, const v3& wi,
+    CMJ* sampler, float u, float v)
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    res->dir = Diffuse::SampleDirection(normal, r1, r2);
+    res->pdf = pdf(normal, res->dir);
+    res->bsdf = computeBsdf(GGX::roughness_of(ctxt, p, u, v), normal, wi, res->dir);
+}
+} // namespace OrenNayar
+
 // ---- dispatch: material/material_impl.h:24-206 (types outside the BASELINE configs fall
 //      to the reference's own default branch: Diffuse) --------------------------------------
 inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const atn_material_param* mtrl,
@@ -398,6 +561,9 @@ inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const at
 {
     switch (mtrl->type) {
     case ATN_MTRL_SPECULAR: Specular::sample(result, normal, wi); break;
+    case ATN_MTRL_REFRACTION: Refraction::sample(*result, sampler, *mtrl, normal, wi); break;
+    case ATN_MTRL_BECKMAN: Beckman::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
+    case ATN_MTRL_OREN_NAYAR: OrenNayar::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_GGX: GGX::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_DISNEY: Disney::sample(*result, *mtrl, normal, wi, sampler); break;
     case ATN_MTRL_EMISSIVE:     // emissive::sample == Diffuse (material/emissive.h:70-83)
@@ -409,6 +575,9 @@ inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const 
 {
     switch (mtrl->type) {
     case ATN_MTRL_SPECULAR: return 1.0F;
+    case ATN_MTRL_REFRACTION: return 1.0F;        // refraction::pdf asserts and returns 1 (refraction.cpp:8-17); never reached: NEE skips singular materials
+    case ATN_MTRL_BECKMAN: return Beckman::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
+    case ATN_MTRL_OREN_NAYAR: return OrenNayar::pdf(normal, wo);
     case ATN_MTRL_GGX: return GGX::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
     default: return Diffuse::ComputePDF(normal, wo);
@@ -419,6 +588,9 @@ inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* 
     MaterialSampling r;     // pdf = 0 unless the BSDF returns its own (Disney)
     switch (mtrl->type) {
     case ATN_MTRL_SPECULAR: r.bsdf = Specular::ComputeBRDF(wo, normal); break;
+    case ATN_MTRL_REFRACTION: r.bsdf = v3(0.0F); break;     // refraction::bsdf asserts and returns vec3() (refraction.cpp:30-39)
+    case ATN_MTRL_BECKMAN: r.bsdf = Beckman::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
+    case ATN_MTRL_OREN_NAYAR: r.bsdf = OrenNayar::computeBsdf(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo); break;
     case ATN_MTRL_GGX: r.bsdf = GGX::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
     case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
     default: r.bsdf = Diffuse::ComputeBRDF(); break;

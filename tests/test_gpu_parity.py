@@ -181,6 +181,59 @@ def test_material_tables(gpu, orc, cornell, sponza_disney, which):
           % (which, relerr(gs[:, :3], ws[:, :3]), relerr(gs[:, 3:], ws[:, 3:]), relerr(ge, we)))
 
 
+@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar"])
+def test_material_tables_next_tier(gpu, orc, which):
+    """BSDFs beyond the BASELINE set: refraction.cpp, beckman.cpp, oren_nayar.cpp."""
+    from aten_amd import layout as L
+    from aten_amd.scene import scenedefs
+    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=False, extra_materials=True)
+    fs, c, _ = _setup(gpu, orc, scene, 64, 64)
+    want_type = {"refraction": L.MTRL_REFRACTION, "beckman": L.MTRL_BECKMAN, "oren_nayar": L.MTRL_OREN_NAYAR}[which]
+    mid = int(np.nonzero(fs.arrays["materials"]["type"] == want_type)[0][0])
+    rng = np.random.default_rng(11)
+    n = 512
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    wi = rng.normal(size=(n, 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    if which != "refraction":           # glass is entered and left: both signs of dot(wi, n), incl. total internal reflection
+        flip = np.einsum("ij,ij->i", wi, nrm) > 0
+        wi[flip] = -wi[flip]
+    idx = rng.integers(0, 256, n).astype(np.uint32)
+    scr = rng.integers(0, 2**32, n).astype(np.uint32)
+    uv = rng.random((n, 2)).astype(np.float32)
+    ws, we = orc.material_table(fs, mid, nrm, wi, idx, scr, uv)
+    gs, ge = gpu.material_table(mid, nrm, wi, idx, scr, uv)
+
+    def relerr(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+    if which == "refraction":           # + - * / sqrt and one CMJ draw only: bit exact
+        # (total internal reflection takes sqrt of a negative number in the reference: NaN on both sides, whose sign
+        # bit differs between sqrtss and v_sqrt_f32)
+        nan = np.isnan(ws)
+        assert np.array_equal(np.isnan(gs), nan)
+        assert np.array_equal(gs.view(np.uint32)[~nan], ws.view(np.uint32)[~nan])
+        assert 0 < nan.any(axis=1).sum() < n // 2
+        return
+    assert relerr(gs[:, :3], ws[:, :3]) <= 2e-5
+    assert relerr(gs[:, 3:], ws[:, 3:]) <= 1e-3
+    assert relerr(ge, we) <= 1e-3
+
+
+def test_next_tier_materials_frames(gpu, orc):
+    from aten_amd.scene import scenedefs
+    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials=True)
+    fs, c, seeds = _setup(gpu, orc, scene, 96, 96)
+    for frame in (0, 4):
+        gpu.reset()
+        got = gpu.render(96, 96, 6, 3, frame=frame)
+        want = orc.render(fs, c, seeds, 96, 96, 6, 3, frame=frame)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.995, (frame, frac)
+        assert mean_err <= 5e-3, (frame, mean_err)
+    assert np.nanmax(got[..., :3]) > 0.0
+
+
 # ---- whole frames --------------------------------------------------------------------------------
 def test_cornell_frames_vs_oracle_and_golden(gpu, orc, cornell, golden):
     fs, c, seeds = _setup(gpu, orc, cornell, 64, 64)

@@ -86,7 +86,6 @@ public:
 
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
-    DevBuf<uint4> smp;
     DevBuf<int2> isect2;
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
     DevBuf<unsigned long long> stats;
@@ -262,7 +261,7 @@ public:
             ATN_HIP(ray_o.resize(slots)); ATN_HIP(ray_d.resize(slots)); ATN_HIP(thr.resize(slots));
             ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots)); ATN_HIP(isect2.resize(slots));
             ATN_HIP(sh_o.resize(slots)); ATN_HIP(sh_d.resize(slots)); ATN_HIP(sh_c.resize(slots));
-            ATN_HIP(accum.resize(slots)); ATN_HIP(smp.resize(slots)); ATN_HIP(done.resize(slots));
+            ATN_HIP(accum.resize(slots)); ATN_HIP(done.resize(slots));
             ATN_HIP(queue0.resize(slots)); ATN_HIP(queue1.resize(slots)); ATN_HIP(shadow_q.resize(slots));
             ATN_HIP(tile_out.resize(slots));
             ATN_HIP(film.resize((size_t)w * h));
@@ -285,7 +284,7 @@ public:
     PathBuffers buffers(bool count, int batch = 0, uint32_t slot_begin = 0)
     {
         PathBuffers pb{};
-        pb.ray_o = ray_o.p; pb.ray_d = ray_d.p; pb.thr = thr.p; pb.contrib = contrib.p; pb.smp = smp.p;
+        pb.ray_o = ray_o.p; pb.ray_d = ray_d.p; pb.thr = thr.p; pb.contrib = contrib.p; pb.seeds = seeds.p;
         pb.isect = isect.p; pb.isect2 = isect2.p; pb.sh_o = sh_o.p; pb.sh_d = sh_d.p; pb.sh_c = sh_c.p;
         pb.accum = accum.p; pb.done = done.p; pb.queue[0] = queue0.p + slot_begin; pb.queue[1] = queue1.p + slot_begin;
         pb.shadow_q = shadow_q.p + slot_begin;

@@ -21,9 +21,10 @@ constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.la
 struct PathBuffers {
     float4* ray_o;      // org.xyz, pdfb
     float4* ray_d;      // dir.xyz, flags (bit pattern)
-    float4* thr;        // throughput.xyz, -
+    float4* thr;        // throughput.xyz, CMJ dimension counter (bit pattern)
     float4* contrib;    // contrib.xyz, -
-    uint4* smp;         // cmj idx, dim, scramble ; global pixel index
+    const uint32_t* seeds;  // aten::getRandom(): the CMJ scramble is recomputed from seed + frame + sample instead of being
+                            // carried through HBM (32 B of traffic per path and bounce); only the dimension counter is state
     float4* isect;      // t, a, b, triangle id (bit pattern)
     int2* isect2;       // instance object id, TLAS mesh id
     float4* sh_o;       // shadow org.xyz, distToLight
@@ -168,9 +169,8 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
             pinhole_sample(cam, s, t, org, dir);
             pb.ray_o[slot] = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
             pb.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(0u));     // flags cleared
-            pb.thr[slot] = make_float4(1.0F, 1.0F, 1.0F, 0.0F);
+            pb.thr[slot] = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(smp.dim));
             pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
-            pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, idx);
             if (fp.sample == 0) { pb.accum[slot] = make_float4(0, 0, 0, 0); pb.done[slot] = 0; }
             flags |= 1u << k;
         }
@@ -267,9 +267,22 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
             uint32_t flags = __float_as_uint(rd4.w);
             const float4 is4 = pb.isect[slot];
             const int2 is2 = pb.isect2[slot];
-            f3 throughput = mk3(pb.thr[slot]);
-            f3 contrib = mk3(pb.contrib[slot]);
-            uint4 s4 = pb.smp[slot];
+            const float4 thr4 = pb.thr[slot];
+            f3 throughput = mk3(thr4);
+            f3 contrib_add = mk3(0.0F);         // contrib is read-modify-written only by the paths that add to it
+            bool contrib_changed = false;
+            // sampler state: GeneratePath's scramble (pathtracing_impl.h:75-81) from the pixel's seed
+            uint4 s4;
+            {
+                int32_t px = 0, py = 0;
+                slot_to_pixel(fp, slot, px, py);
+                s4.w = (uint32_t)(py * fp.width + px);
+                const uint32_t rnd = pb.seeds[s4.w % fp.n_seeds];
+                const uint32_t fs = fp.frame + (uint32_t)fp.sample;
+                s4.x = fs % 256u;
+                s4.y = __float_as_uint(thr4.w);
+                s4.z = rnd * 0x1fe3434fu * ((fs + 133u * rnd) / 256u);
+            }
             Cmj smp; smp.idx = s4.x; smp.dim = s4.y; smp.scramble = s4.z;
 
             flags &= ~F_HIT;
@@ -302,7 +315,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                     }
                     f3 c = 1.0F * mk3(mul4(misW, emit)) + mk3(0.0F);   // ApplyAlphaBlend (transmission 1, throughput 0)
                     c = c * throughput;
-                    contrib = contrib + c;
+                    contrib_add = c; contrib_changed = true;
                     flags |= F_TERMINATED;
                 }
             }
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                             weight = pdfb / (pdfb + pdfLight);
                         }
                     }
-                    contrib = contrib + (throughput * weight) * light_color;
+                    contrib_add = (throughput * weight) * light_color; contrib_changed = true;
                     flags |= F_TERMINATED;
                     shaded_out = true;
                 }
@@ -434,9 +447,11 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 const float4 d = pb.ray_d[slot];
                 pb.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(flags));
             }
-            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0F);
-            pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
-            pb.smp[slot] = make_uint4(smp.idx, smp.dim, smp.scramble, s4.w);
+            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+            if (contrib_changed) {
+                const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
+                pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
+            }
         }
         if (push_next) flags_next |= 1u << k;
         if (push_shadow) flags_shadow |= 1u << k;

@@ -1,0 +1,149 @@
+"""Error behaviour of the C-ABI (negative status + message, nothing thrown across the boundary, context stays usable)
+and edge-case inputs: 1x1 and ragged frames, rays that all miss, a scene without lights, corrupted BVH links."""
+import numpy as np
+import pytest
+
+from conftest import make_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh():
+    from aten_amd.renderer import PathTracing
+    return PathTracing(0)
+
+
+def test_calls_out_of_order_report_status(orc, cornell):
+    from aten_amd.renderer import AtenAmdError
+    fs, cam = cornell
+    g = _fresh()
+    try:
+        with pytest.raises(AtenAmdError, match=r"atn_upload_scene.*status -4"):
+            g.render(16, 16)
+        g.UpdateSceneData(fs)
+        with pytest.raises(AtenAmdError, match="atn_update_camera"):
+            g.render(16, 16)
+        g.updateCamera(make_camera(orc, cam, 16, 16))
+        with pytest.raises(AtenAmdError, match="atn_init_sampler"):
+            g.render(16, 16)
+        g.initSampler(16, 16, 0)
+        with pytest.raises(AtenAmdError, match="bad destination"):
+            g.render(16, 0)
+        with pytest.raises(AtenAmdError, match="bad destination"):
+            g.render(16, 16, max_depth=0)
+        g.setScreenShard(1, 2)
+        with pytest.raises(AtenAmdError, match="one GPU"):
+            g.svgf_render(16, 16, compute_motion=True)
+        with pytest.raises(AtenAmdError):
+            g.setScreenShard(2, 2)
+        g.setScreenShard(0, 1)
+        with pytest.raises(AtenAmdError, match="out of range"):
+            g.set_path_batches(0)
+        img = g.render(16, 16)          # the context survived all of that
+        assert np.isfinite(img[..., :3]).all()
+    finally:
+        g.close()
+
+
+def test_corrupted_bvh_is_rejected(orc, cornell):
+    from aten_amd.renderer import AtenAmdError
+    fs, cam = cornell
+    g = _fresh()
+    try:
+        def broken(edit):
+            import ctypes as C
+            from aten_amd import layout as L
+            from aten_amd.scene.builder import FlatScene
+            lists = [a.copy() for a in fs.arrays["bvh_lists"]]
+            edit(lists)
+            arr = (L.BvhList * len(lists))()
+            for i, n in enumerate(lists):
+                arr[i].nodes = n.ctypes.data
+                arr[i].count = len(n)
+            b = FlatScene()
+            C.memmove(C.byref(b.desc), C.byref(fs.desc), C.sizeof(fs.desc))
+            b.desc.bvh_lists = C.addressof(arr)
+            b.arrays = dict(fs.arrays)
+            b.arrays["bvh_lists"] = lists
+            b.keep = [fs, arr, lists]
+            return b
+
+        def cycle(lists):
+            lists[1]["hit"][1] = 0.0        # second node links back to the root
+        with pytest.raises(AtenAmdError, match="cycle|walk order"):
+            g.UpdateSceneData(broken(cycle))
+
+        def out_of_range(lists):
+            lists[1]["miss"][0] = 1e6
+        with pytest.raises(AtenAmdError, match="unreachable|out of range"):
+            g.UpdateSceneData(broken(out_of_range))
+
+        def bad_tri(lists):
+            leaf = np.nonzero(lists[1]["f1"] >= 0)[0][0]
+            lists[1]["f1"][leaf] = 1e6
+        with pytest.raises(AtenAmdError, match="triangle id out of range"):
+            g.UpdateSceneData(broken(bad_tri))
+
+        def bad_blas(lists):
+            leaf = np.nonzero(lists[0]["f2"] >= 0)[0][0]
+            lists[0]["f2"][leaf] = np.int32(99).view(np.float32)
+        with pytest.raises(AtenAmdError, match="missing BLAS"):
+            g.UpdateSceneData(broken(bad_blas))
+        g.UpdateSceneData(fs)               # a good scene still uploads afterwards
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (9, 65), (130, 1)])
+def test_tiny_and_ragged_frames(gpu, orc, cornell, size):
+    fs, cam = cornell
+    w, h = size
+    c = make_camera(orc, cam, w, h)
+    gpu.UpdateSceneData(fs)
+    gpu.updateCamera(c)
+    gpu.initSampler(w, h, 0)
+    gpu.setScreenShard(0, 1)
+    gpu.reset()
+    seeds = orc.init_sampler(w, h, 0)
+    got = gpu.render(w, h, 5, 3, frame=1)
+    want = orc.render(fs, c, seeds, w, h, 5, 3, frame=1)
+    assert got.shape == (h, w, 4)
+    d = np.abs(got[..., :3] - want[..., :3])
+    assert np.all((d <= 1e-3 * np.maximum(1.0, np.abs(want[..., :3]))) | (np.isnan(got[..., :3]) & np.isnan(want[..., :3])))
+    rays = orc.generate_paths(c, seeds, w, h, 0, 1)
+    assert gpu.generate_paths(w, h, 0, 1).tobytes() == rays.tobytes()
+
+
+def test_all_rays_miss_and_no_lights(gpu, orc, cornell):
+    """Camera looking away from the scene: every path ends in ShadeMiss at bounce 0 (background colour); and a scene
+    without any light: NEE is skipped (lightnum <= 0, pathtracing_impl.h:199-203), only emissive hits contribute."""
+    from aten_amd.scene import scenedefs
+    fs, cam = cornell
+    away = dict(cam)
+    away["pos"], away["at"] = (0.0, 1.0, 8.0), (0.0, 1.0, 20.0)
+    w, h = 48, 32
+    c = make_camera(orc, away, w, h)
+    gpu.UpdateSceneData(fs)
+    gpu.updateCamera(c)
+    gpu.initSampler(w, h, 0)
+    gpu.setScreenShard(0, 1)
+    gpu.reset()
+    seeds = orc.init_sampler(w, h, 0)
+    got = gpu.render(w, h, 5, 3, count_stats=True)
+    st = gpu.stats()
+    want = orc.render(fs, c, seeds, w, h, 5, 3)
+    assert got.tobytes() == want.tobytes()
+    assert st["hits"] == 0 and st["shadow_rays"] == 0 and st["closest_rays"] == w * h
+
+    nolight = scenedefs.cornell_box_variant(lights="none", move_boxes=False)
+    fs2, cam2 = nolight
+    assert len(fs2.arrays["lights"]) == 0
+    c2 = make_camera(orc, cam2, w, h)
+    gpu.UpdateSceneData(fs2)
+    gpu.updateCamera(c2)
+    gpu.reset()
+    got = gpu.render(w, h, 5, 3, count_stats=True)
+    assert gpu.stats()["shadow_rays"] == 0
+    want = orc.render(fs2, c2, seeds, w, h, 5, 3)
+    d = np.abs(got[..., :3] - want[..., :3])
+    assert np.all(d <= 1e-3 * np.maximum(1.0, np.abs(want[..., :3])))

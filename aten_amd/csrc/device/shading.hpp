@@ -513,6 +513,96 @@ ATN_DEV f3 oren_nayar_brdf(float roughness, const f3& normal, const f3& wi, cons
     return mk3((1.0F / kPi) * (A + B * smax(0.0F, s / t)));
 }
 
+// MicrofacetVelvet, material/velvet.cpp:57-212
+ATN_DEV float velvet_param(int idx, float f)
+{
+    const float p0[5] = { 25.3245F, 3.32435F, 0.16801F, -1.27393F, -4.85967F };
+    const float p1[5] = { 21.5473F, 3.82987F, 0.19823F, -1.97760F, -4.32054F };
+    return (f * p0[idx] + (1 - f)) + p1[idx];          // "+ p1" as the reference writes it (velvet.cpp:82)
+}
+ATN_DEV float velvet_L(float x, float roughness)
+{
+    const float f = powf(1.0F - roughness, 2.0F);
+    const float a = velvet_param(0, f), b = velvet_param(1, f), c = velvet_param(2, f), d = velvet_param(3, f), e = velvet_param(4, f);
+    return (a / (1 + b * powf(x, c)) + d * x) + e;
+}
+ATN_DEV float velvet_lambda(float roughness, const f3& w, const f3& m)
+{
+    const float cos_theta = sclamp(fabsf(dot(w, m)), 0.0F, 1.0F);
+    if (cos_theta < 0.5F) return expf(velvet_L(cos_theta, roughness));
+    return expf(2.0F * velvet_L(0.5F, roughness) - velvet_L(1 - cos_theta, roughness));
+}
+ATN_DEV f3 velvet_brdf(float roughness, const f3& N, const f3& wi, const f3& wo)
+{
+    const f3 V = -wi, L = wo;
+    const f3 H = normalize(L + V);
+    const float NL = fabsf(dot(N, L)), NV = fabsf(dot(N, V));
+    // ComputeDistribution
+    const float cos_theta = fabsf(dot(H, N));
+    const float inv_r = 1.0F / roughness;
+    const float sin_theta = sqrtf(sclamp(1 - cos_theta * cos_theta, 0.0F, 1.0F));
+    const float D = ((2.0F + inv_r) * powf(sin_theta, inv_r)) / kPi2;
+    // ComputeShadowingMaskingFunction
+    float lambda_wi = velvet_lambda(roughness, V, N);
+    const float lambda_wo = velvet_lambda(roughness, L, N);
+    const float cos_theta_wi = sclamp(fabsf(dot(V, N)), 0.0F, 1.0F);
+    lambda_wi = powf(lambda_wi, 1.0F + 2.0F * powf(1.0F - cos_theta_wi, 8.0F));
+    const float G = 1.0F / ((1.0F + lambda_wi) + lambda_wo);
+    const float denom = (4 * NL) * NV;
+    return mk3(denom > kEps ? ((1.0F * G) * D) / denom : 0.0F);
+}
+
+// MicrofacetRefraction, material/microfacet_refraction.cpp:69-171
+ATN_DEV void microfacet_refraction_sample(MtrlSample& r, const DevScene& sc, const DevMaterial& mt, const f3& n, const f3& wi,
+                                          Cmj& smp, float tu, float tv)
+{
+    const float roughness = ggx_roughness(sc, mt, tu, tv);
+    const float ior = mt.ior;
+    float ni = 1.0F, nt = ior;
+    const f3 V = -wi;
+    f3 N = n;
+    if (!(dot(V, N) >= 0.0F)) { N = -n; const float t = ni; ni = nt; nt = t; }
+    const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+    const f3 m = ggx_sample_m(roughness, N, r1, r2);
+    const float R = schlick_fresnel(ni, nt, wi, m);
+    const float T = 1 - R;
+    const float prob = R;
+    const float u = cmj_next(smp);
+    if (u < prob) {
+        const f3 wo = reflect_vector(wi, m);
+        const float VN = dot(V, N), LN = dot(wo, N);
+        if (VN * LN < 0) {
+            r.dir = reflect_vector(wi, N); r.pdf = 1.0f; r.bsdf = mk3(0.0F);
+            return;
+        }
+        r.dir = wo;
+        r.pdf = ggx_pdf_h(roughness, N, m, wo);
+        r.pdf *= prob;
+        r.bsdf = ggx_brdf(roughness, ior, N, wi, wo);
+    }
+    else {
+        const f3 wo = refract_vector(ni, nt, wi, m);
+        const float D = ggx_D(m, N, roughness);
+        const float G = ggx_G2(roughness, V, wo, N);
+        const float LH = fabsf(dot(wo, m));
+        const float VH = fabsf(dot(V, m));
+        const float denom = ni * dot(V, m) + nt * dot(wo, m);
+        const float denom2 = denom * denom;
+        const float costheta = fabsf(dot(m, n));
+        const float nt2 = nt * nt;
+        r.pdf = denom2 > 0 ? (D * costheta) * ((nt2 * LH) / denom2) : 1.0F;
+        r.pdf *= 1.0F - prob;
+        r.dir = wo;
+        float VN = dot(V, N), LN = dot(wo, N);
+        if (VN * LN > 0) {
+            r.dir = refract_vector(ni, nt, wi, N); r.pdf = 1.0f; r.bsdf = mk3(0.0F);
+            return;
+        }
+        VN = fabsf(VN); LN = fabsf(LN);
+        r.bsdf = mk3(denom2 > 0 ? ((VH * LH) / (VN * LN)) * ((((nt2 * T) * D) * G) / denom2) : 0.0F);
+    }
+}
+
 // material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
 ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
                              const f3& wi, Cmj& smp, float u, float v)
@@ -547,6 +637,16 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
         r.bsdf = beckman_brdf(rough, m.ior, normal, wi, r.dir);
         break;
     }
+    case ATN_MTRL_VELVET: {
+        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        r.dir = diffuse_dir(normal, r1, r2);
+        r.pdf = diffuse_pdf(normal, r.dir);
+        r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+        break;
+    }
+    case ATN_MTRL_MICROFACET_REFRACTION:
+        microfacet_refraction_sample(r, sc, m, normal, wi, smp, u, v);
+        break;
     case ATN_MTRL_OREN_NAYAR: {
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
         r.dir = diffuse_dir(normal, r1, r2);
@@ -570,6 +670,8 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
     case ATN_MTRL_REFRACTION: return 1.0F;
     case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_OREN_NAYAR: return oren_nayar_pdf(normal, wo);
+    case ATN_MTRL_VELVET: return diffuse_pdf(normal, wo);
+    case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;
     case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
     default: return diffuse_pdf(normal, wo);
@@ -584,6 +686,8 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); break;
     case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
     case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
+    case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
+    case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = mk3(0.0F); break;
     case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
     default: r.bsdf = diffuse_brdf(); break;
     }

@@ -85,6 +85,8 @@ MTRL_ATTRIB = {
     MTRL_GGX: ATTR_GLOSSY,
     MTRL_BECKMAN: ATTR_GLOSSY,
     MTRL_OREN_NAYAR: 0,
+    MTRL_VELVET: ATTR_GLOSSY,
+    MTRL_MICROFACET_REFRACTION: ATTR_SINGULAR | ATTR_TRANSLUCENT | ATTR_GLOSSY,
     MTRL_REFRACTION: ATTR_SINGULAR | ATTR_TRANSLUCENT | ATTR_GLOSSY,
     MTRL_DISNEY: ATTR_GLOSSY,
 }

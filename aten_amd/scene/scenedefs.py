@@ -123,10 +123,14 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None, extra_ma
                                   specular=0.6, clearcoat=0.4, clearcoatGloss=0.7, sheen=0.3)
         if name == "floor":
             return b.add_material(name, L.MTRL_GGX, (0.7, 0.6, 0.5), roughness=0.1, ior=0.01)
-        if extra_materials and name == "tallBox":       # glass (refraction.cpp), like the reference's glass spheres
+        if extra_materials is True and name == "tallBox":       # glass (refraction.cpp), like the reference's glass spheres
             return b.add_material(name, L.MTRL_REFRACTION, (0.9, 0.9, 0.9), ior=1.5)
         if extra_materials and name == "leftWall":
             return b.add_material(name, L.MTRL_OREN_NAYAR, clr, roughness=0.6)
+        if extra_materials == "rough" and name == "tallBox":     # frosted glass (microfacet_refraction.cpp)
+            return b.add_material(name, L.MTRL_MICROFACET_REFRACTION, (0.9, 0.9, 0.9), ior=1.5, roughness=0.2)
+        if extra_materials == "rough" and name == "rightWall":
+            return b.add_material(name, L.MTRL_VELVET, clr, roughness=0.4)
         if extra_materials and name == "backWall":
             return b.add_material(name, L.MTRL_BECKMAN, (0.7, 0.7, 0.7), roughness=0.25, ior=0.2)
         return b.add_material(name, mtype, clr)

@@ -554,6 +554,125 @@ inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_
 }
 } // namespace OrenNayar
 
+// ---- MicrofacetVelvet: material/velvet.cpp:57-212 ----------------------------------------------------
+namespace Velvet {
+inline float ComputeDistribution(const v3& m, const v3& n, float roughness)
+{
+    const float cos_theta = std::abs(dot(m, n));
+    const float inv_r = 1.0F / roughness;
+    const float sin_theta = std::sqrt(saturate_(1 - cos_theta * cos_theta));
+    return ((2.0F + inv_r) * std::pow(sin_theta, inv_r)) / (PI_2);
+}
+inline float InterpolateVelvetParam(int idx, float interp_factor)
+{
+    constexpr float p0[] = { 25.3245F, 3.32435F, 0.16801F, -1.27393F, -4.85967F };
+    constexpr float p1[] = { 21.5473F, 3.82987F, 0.19823F, -1.97760F, -4.32054F };
+    // as written in the reference (velvet.cpp:82): "+ p1", not "* p1"
+    return interp_factor * p0[idx] + (1 - interp_factor) + p1[idx];
+}
+inline float ComputeVelvetLForLambda(float x, float roughness)
+{
+    const float interp_factor = std::pow(float(1) - roughness, float(2));
+    const float a = InterpolateVelvetParam(0, interp_factor);
+    const float b = InterpolateVelvetParam(1, interp_factor);
+    const float c = InterpolateVelvetParam(2, interp_factor);
+    const float d = InterpolateVelvetParam(3, interp_factor);
+    const float e = InterpolateVelvetParam(4, interp_factor);
+    return a / (1 + b * std::pow(x, c)) + d * x + e;
+}
+inline float ComputeVelvetLambda(float roughness, const v3& w, const v3& m)
+{
+    const float cos_theta = saturate_(std::abs(dot(w, m)));
+    if (cos_theta < 0.5F) return std::exp(ComputeVelvetLForLambda(cos_theta, roughness));
+    return std::exp(2.0F * ComputeVelvetLForLambda(0.5F, roughness) - ComputeVelvetLForLambda(1 - cos_theta, roughness));
+}
+inline float ComputeShadowingMaskingFunction(float roughness, const v3& view, const v3& light, const v3& n)
+{
+    float lambda_wi = ComputeVelvetLambda(roughness, view, n);
+    const float lambda_wo = ComputeVelvetLambda(roughness, light, n);
+    const float cos_theta_wi = saturate_(std::abs(dot(view, n)));
+    lambda_wi = std::pow(lambda_wi, 1.0F + 2.0F * std::pow(1.0F - cos_theta_wi, 8.0F));
+    return 1.0F / (1.0F + lambda_wi + lambda_wo);
+}
+inline v3 ComputeBRDF(float roughness, const v3& n, const v3& wi, const v3& wo)
+{
+    const v3 V = -wi, L = wo, N = n;
+    const v3 H = normalize(L + V);
+    const float NL = std::abs(dot(N, L));
+    const float NV = std::abs(dot(N, V));
+    const float D = ComputeDistribution(H, N, roughness);
+    const float G = ComputeShadowingMaskingFunction(roughness, V, L, N);
+    constexpr float F = 1.0F;
+    const float denom = 4 * NL * NV;
+    const float bsdf = denom > EPS ? F * G * D / denom : 0.0F;
+    return v3(bsdf);
+}
+inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_param& p, const v3& normal, const v3& wi,
+    CMJ* sampler, float u, float v)
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    res->dir = Diffuse::SampleDirection(normal, r1, r2);
+    res->pdf = Diffuse::ComputePDF(normal, res->dir);
+    res->bsdf = ComputeBRDF(GGX::roughness_of(ctxt, p, u, v), normal, wi, res->dir);
+}
+} // namespace Velvet
+
+// ---- MicrofacetRefraction: material/microfacet_refraction.cpp:69-171 -----------------------------------
+namespace MicrofacetRefraction {
+inline void sample(MaterialSampling& result, const Scene& ctxt, const atn_material_param& p, const v3& n, const v3& wi,
+    CMJ* sampler, float tu, float tv)
+{
+    const float roughness = GGX::roughness_of(ctxt, p, tu, tv);
+    const float ior = p.u.standard.ior;
+    float ni = 1.0F, nt = ior;
+    const v3 V = -wi;
+    v3 N = n;
+    if (!(dot(V, N) >= 0.0F)) { N = -n; std::swap(ni, nt); }
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    const v3 m = GGX::SampleMicrosurfaceNormal(roughness, N, r1, r2);
+    const float F = ComputeSchlickFresnel(ni, nt, wi, m);
+    const float R = F, T = 1 - R;
+    const float prob = R;
+    const float u = sampler->nextSample();
+    if (u < prob) {
+        const v3 wo = ComputeReflectVector(wi, m);
+        const float VN = dot(V, N), LN = dot(wo, N);
+        if (VN * LN < 0) {
+            result.dir = ComputeReflectVector(wi, N); result.pdf = 1.0f; result.bsdf = v3(0);
+            return;
+        }
+        result.dir = wo;
+        result.pdf = GGX::ComputePDFWithHalfVector(roughness, N, m, wo);
+        result.pdf *= prob;
+        result.bsdf = GGX::ComputeBRDF(roughness, ior, N, wi, wo);
+    }
+    else {
+        const v3 wo = Refraction::ComputeRefractVector(ni, nt, wi, m);
+        const float D = GGX::ComputeDistribution(m, N, roughness);
+        const float G = GGX::ComputeG2Smith(roughness, V, wo, N);
+        const float LH = std::abs(dot(wo, m));
+        const float VH = std::abs(dot(V, m));
+        const float denom = ni * dot(V, m) + nt * dot(wo, m);
+        const float denom2 = denom * denom;
+        const float costheta = std::abs(dot(m, n));
+        const float nt2 = nt * nt;
+        result.pdf = denom2 > 0 ? D * costheta * (nt2 * LH / denom2) : 1.0F;
+        result.pdf *= 1.0F - prob;
+        result.dir = wo;
+        float VN = dot(V, N), LN = dot(wo, N);
+        if (VN * LN > 0) {
+            result.dir = Refraction::ComputeRefractVector(ni, nt, wi, N); result.pdf = 1.0f; result.bsdf = v3(0);
+            return;
+        }
+        VN = std::abs(VN); LN = std::abs(LN);
+        const float bsdf = denom2 > 0 ? ((VH * LH) / (VN * LN)) * (nt2 * T * D * G / denom2) : 0.0F;
+        result.bsdf = v3(bsdf);
+    }
+}
+} // namespace MicrofacetRefraction
+
 // ---- dispatch: material/material_impl.h:24-206 (types outside the BASELINE configs fall
 //      to the reference's own default branch: Diffuse) --------------------------------------
 inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const atn_material_param* mtrl,
@@ -564,6 +683,8 @@ inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const at
     case ATN_MTRL_REFRACTION: Refraction::sample(*result, sampler, *mtrl, normal, wi); break;
     case ATN_MTRL_BECKMAN: Beckman::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_OREN_NAYAR: OrenNayar::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
+    case ATN_MTRL_VELVET: Velvet::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
+    case ATN_MTRL_MICROFACET_REFRACTION: MicrofacetRefraction::sample(*result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_GGX: GGX::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_DISNEY: Disney::sample(*result, *mtrl, normal, wi, sampler); break;
     case ATN_MTRL_EMISSIVE:     // emissive::sample == Diffuse (material/emissive.h:70-83)
@@ -578,6 +699,8 @@ inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const 
     case ATN_MTRL_REFRACTION: return 1.0F;        // refraction::pdf asserts and returns 1 (refraction.cpp:8-17); never reached: NEE skips singular materials
     case ATN_MTRL_BECKMAN: return Beckman::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
     case ATN_MTRL_OREN_NAYAR: return OrenNayar::pdf(normal, wo);
+    case ATN_MTRL_VELVET: return Diffuse::ComputePDF(normal, wo);
+    case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;     // asserts and returns 1 (microfacet_refraction.cpp:13-22); singular: NEE never asks
     case ATN_MTRL_GGX: return GGX::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
     default: return Diffuse::ComputePDF(normal, wo);
@@ -591,6 +714,8 @@ inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* 
     case ATN_MTRL_REFRACTION: r.bsdf = v3(0.0F); break;     // refraction::bsdf asserts and returns vec3() (refraction.cpp:30-39)
     case ATN_MTRL_BECKMAN: r.bsdf = Beckman::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
     case ATN_MTRL_OREN_NAYAR: r.bsdf = OrenNayar::computeBsdf(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo); break;
+    case ATN_MTRL_VELVET: r.bsdf = Velvet::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo); break;
+    case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = v3(0.0F); break;
     case ATN_MTRL_GGX: r.bsdf = GGX::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
     case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
     default: r.bsdf = Diffuse::ComputeBRDF(); break;

@@ -181,14 +181,16 @@ def test_material_tables(gpu, orc, cornell, sponza_disney, which):
           % (which, relerr(gs[:, :3], ws[:, :3]), relerr(gs[:, 3:], ws[:, 3:]), relerr(ge, we)))
 
 
-@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar"])
+@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar", "velvet", "microfacet_refraction"])
 def test_material_tables_next_tier(gpu, orc, which):
     """BSDFs beyond the BASELINE set: refraction.cpp, beckman.cpp, oren_nayar.cpp."""
     from aten_amd import layout as L
     from aten_amd.scene import scenedefs
-    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=False, extra_materials=True)
+    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=False,
+                                          extra_materials="rough" if which in ("velvet", "microfacet_refraction") else True)
     fs, c, _ = _setup(gpu, orc, scene, 64, 64)
-    want_type = {"refraction": L.MTRL_REFRACTION, "beckman": L.MTRL_BECKMAN, "oren_nayar": L.MTRL_OREN_NAYAR}[which]
+    want_type = {"refraction": L.MTRL_REFRACTION, "beckman": L.MTRL_BECKMAN, "oren_nayar": L.MTRL_OREN_NAYAR,
+                 "velvet": L.MTRL_VELVET, "microfacet_refraction": L.MTRL_MICROFACET_REFRACTION}[which]
     mid = int(np.nonzero(fs.arrays["materials"]["type"] == want_type)[0][0])
     rng = np.random.default_rng(11)
     n = 512
@@ -196,7 +198,7 @@ def test_material_tables_next_tier(gpu, orc, which):
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     wi = rng.normal(size=(n, 3)).astype(np.float32)
     wi /= np.linalg.norm(wi, axis=1, keepdims=True)
-    if which != "refraction":           # glass is entered and left: both signs of dot(wi, n), incl. total internal reflection
+    if which not in ("refraction", "microfacet_refraction"):           # glass is entered and left: both signs of dot(wi, n), incl. total internal reflection
         flip = np.einsum("ij,ij->i", wi, nrm) > 0
         wi[flip] = -wi[flip]
     idx = rng.integers(0, 256, n).astype(np.uint32)
@@ -215,14 +217,18 @@ def test_material_tables_next_tier(gpu, orc, which):
         assert np.array_equal(gs.view(np.uint32)[~nan], ws.view(np.uint32)[~nan])
         assert 0 < nan.any(axis=1).sum() < n // 2
         return
-    assert relerr(gs[:, :3], ws[:, :3]) <= 2e-5
-    assert relerr(gs[:, 3:], ws[:, 3:]) <= 1e-3
-    assert relerr(ge, we) <= 1e-3
+    nan = np.isnan(ws)
+    assert np.array_equal(np.isnan(gs), nan)            # rough glass past the critical angle: NaN on both sides
+    gs, ws = np.nan_to_num(gs), np.nan_to_num(ws)
+    assert relerr(gs[:, :3], ws[:, :3]) <= 5e-5
+    assert relerr(gs[:, 3:], ws[:, 3:]) <= 2e-3
+    assert relerr(ge, we) <= 2e-3
 
 
-def test_next_tier_materials_frames(gpu, orc):
+@pytest.mark.parametrize("extra", [True, "rough"])
+def test_next_tier_materials_frames(gpu, orc, extra):
     from aten_amd.scene import scenedefs
-    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials=True)
+    scene = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials=extra)
     fs, c, seeds = _setup(gpu, orc, scene, 96, 96)
     for frame in (0, 4):
         gpu.reset()

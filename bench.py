@@ -53,6 +53,26 @@ def measured_traffic(scene, w, h, kernel="k_trace_closest"):
     return best
 
 
+def usable_cpus():
+    """Host threads this process can really run at once: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes report 256 logical CPUs but run the container under `cpu.max = 1600000 100000`, i.e. 16 CPUs; an OpenMP
+    team wider than the quota is throttled and gets SLOWER: 64 threads 2.1, 256 threads 0.8 Mrays/s on sponza_lod)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,10 +321,11 @@ def main():
                 ts.append(time.perf_counter() - t1)
             return float(np.median(ts)), len(ts)
 
-        med, nfr = cpu_median(0, 5, 20.0)
+        n_cpu = usable_cpus()
+        med, nfr = cpu_median(n_cpu, 5, 20.0)
         med8, nfr8 = cpu_median(8, 2, 10.0)     # the reference app's own setting (host_renderer/main.cpp:18-23,271)
-        cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": orc.lib().orc_num_procs(),
-                        "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305" % (cw, ch, nfr),
+        cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": n_cpu, "logical_cpus": orc.lib().orc_num_procs(),
+                        "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
                         "ms_per_frame_sample": round(1e3 * med, 2),
                         "value_8_threads": round(cw * ch * spp / 1e6 / med8, 4), "frames_8_threads": nfr8}
 

@@ -492,6 +492,20 @@ struct ShadowJob {
         const uint32_t lattr = lp->attrib;
         const int32_t lightobj = (ltype == ATN_LIGHT_AREA && lobj >= 0) ? lobj : -1;
         const int32_t hitobj = isHit ? h.objid : lightobj;
+        if (sc.any_alpha && isHit && h.objid == lightobj) {
+            // (every other hit already means "not visible", whatever its alpha)
+            // material::isTranslucentByAlpha hit (material.cpp:193-210): "ignored", and with a lookup budget of one
+            // (no alpha blending / stencil) the shadow ray then counts as blocked (pathtracing_impl.h:295-336).
+            // Only materials flagged at upload can have alpha < 1.
+            const int32_t mid = sc.tris[h.tri].mtrlid;
+            if (mid >= 0 && (sc.materials[mid].attrib & kAttrMaybeAlpha)) {
+                HitRec rec;
+                evaluate_hit(rec, sc, h.objid, h.tri, h.a, h.b);
+                const DevMaterial& hm = sc.materials[mid];
+                const float4 albedo = sample_texture(sc, hm.albedoMap, rec.u, rec.v, make_float4(1.0F, 1.0F, 1.0F, 1.0F));
+                if (albedo.w * hm.baseColor.w < 1.0F) return;
+            }
+        }
         bool visible;
         if (hitobj == lightobj) visible = true;
         else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;

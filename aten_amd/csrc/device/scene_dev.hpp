@@ -36,6 +36,8 @@ constexpr int32_t kTagDead = 8;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
 constexpr uint32_t kAttrIdealRefraction = 0x10000u;   // MaterialParameter::isIdealRefraction, folded into attrib at upload
+constexpr uint32_t kAttrMaybeAlpha = 0x20000u;        // baseColor.a < 1 or an albedo texel with a < 1 exists: material::isTranslucentByAlpha
+                                                      // can be true, so shadow-ray hits on it must evaluate it (set at upload)
 
 struct DevMaterial {
     float4 baseColor;
@@ -78,6 +80,7 @@ struct DevScene {
     float avgIllum;
     float multiplyer;
     int32_t enable_env_map;
+    int32_t any_alpha;          // some material carries kAttrMaybeAlpha
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
 };

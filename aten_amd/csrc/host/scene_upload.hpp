@@ -181,12 +181,19 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     for (uint32_t i = 0; i < s->n_matrices; i++)
         for (int r = 0; r < 4; r++)
             img.matrices[4 * (size_t)i + r] = make_float4(s->matrices[i].m[r][0], s->matrices[i].m[r][1], s->matrices[i].m[r][2], s->matrices[i].m[r][3]);
+    std::vector<uint8_t> tex_has_alpha(s->n_textures, 0);
+    for (uint32_t i = 0; i < s->n_textures; i++) {
+        const atn_texture_desc& t = s->textures[i];
+        const size_t n = (size_t)t.width * t.height;
+        for (size_t j = 0; j < n; j++) if (t.texels[j].w < 1.0F) { tex_has_alpha[i] = 1; break; }
+    }
     img.materials.resize(s->n_materials);
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const atn_material_param& m = s->materials[i];
         DevMaterial& d = img.materials[i];
         d.baseColor = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, m.baseColor.w);
         d.type = m.type; d.attrib = (m.attrib & 0xFu) | (m.isIdealRefraction ? kAttrIdealRefraction : 0u); d.id = m.id;
+        if (m.baseColor.w < 1.0F || (m.albedoMap >= 0 && (uint32_t)m.albedoMap < s->n_textures && tex_has_alpha[m.albedoMap])) d.attrib |= kAttrMaybeAlpha;
         d.albedoMap = m.albedoMap; d.normalMap = m.normalMap; d.roughnessMap = m.roughnessMap;
         const atn_standard_mtrl& st = m.u.standard;
         d.ior = st.ior; d.roughness = st.roughness; d.subsurface = st.subsurface; d.metallic = st.metallic;
@@ -224,6 +231,8 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     p.avgIllum = s->config.bg.avgIllum;
     p.multiplyer = s->config.bg.multiplyer;
     p.enable_env_map = s->config.bg.enable_env_map;
+    p.any_alpha = 0;
+    for (const DevMaterial& dm : img.materials) if (dm.attrib & kAttrMaybeAlpha) p.any_alpha = 1;
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /
     // ComputeDistanceToCoverBoundingSphere, math/aabb.h:176-180,231-234,346-362), evaluated once on the host.
     {

@@ -1056,7 +1056,21 @@ inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& sh
     Isect isect;
     if (cnt) cnt->shadow_rays++;
     bool isHit = TraverseClosest(isect, ctxt, r, EPS, distToLight - EPS, cnt ? &cnt->trav : nullptr);
-    if (isHit) hitobj = isect.objid;
+    if (isHit) {
+        hitobj = isect.objid;
+        // material::isTranslucentByAlpha (material.cpp:193-210): such a hit is "ignored" and the lookup loop, whose
+        // budget is one iteration without alpha blending / stencil, ends with is_hit_to_light still false
+        // (pathtracing_impl.h:295-336)
+        const auto& hobj = ctxt.GetObject(static_cast<uint32_t>(isect.objid));
+        HitRec rec;
+        evaluate_hit_result(rec, hobj, ctxt, r, isect);
+        if (isect.mtrlid >= 0) {        // (the reference indexes unconditionally)
+            const auto& hm = ctxt.GetMaterial(isect.mtrlid);
+            v4 albedo = sampleTexture(ctxt, hm.albedoMap, rec.u, rec.v, v4(1.0F));
+            const float alpha = albedo.w * hm.baseColor.w;
+            if (alpha < 1.0F) return false;
+        }
+    }
 
     bool is_hit_to_light;
     if (hitobj == lightobj) is_hit_to_light = true;

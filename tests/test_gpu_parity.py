@@ -358,6 +358,33 @@ def test_atrium_instanced_disney_textured(gpu, orc):
                 assert np.array_equal(np.isnan(got[..., :3]).any(-1), np.isnan(want[..., :3]).any(-1))
 
 
+def test_alpha_translucent_blocker_rule(gpu, orc):
+    """material::isTranslucentByAlpha in HitTestToTargetLight (pathtracing_impl.h:295-336): a shadow-ray hit on a
+    material with alpha < 1 is "ignored", and with the lookup budget of one the ray then counts as blocked -- even when
+    the hit object is the light itself.  Give the Cornell light alpha 0.5: next-event estimation must vanish on both
+    sides (the light still shows through implicit hits)."""
+    from aten_amd.scene import scenedefs
+    from aten_amd import layout as L
+    scene = scenedefs.cornell_box()
+    fs, cam = scene
+    mats = fs.arrays["materials"]
+    light = int(np.nonzero(mats["type"] == L.MTRL_EMISSIVE)[0][0])
+    w = h = 64
+    opaque = None
+    for alpha in (1.0, 0.5):
+        mats["baseColor"][light][3] = alpha
+        fs_, c, seeds = _setup(gpu, orc, scene, w, h)
+        got = gpu.render(w, h, 3, 3, frame=1)
+        want = orc.render(fs, c, seeds, w, h, 3, 3, frame=1)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.995 and mean_err <= 2e-3, (alpha, frac, mean_err)
+        if alpha == 1.0:
+            opaque = np.nanmean(got[..., :3])
+        else:
+            assert np.nanmean(got[..., :3]) < 0.9 * opaque      # the direct-light term is gone
+    mats["baseColor"][light][3] = 1.0
+
+
 def test_launch_schedules_give_identical_frames(orc, sponza, monkeypatch):
     """How the frame's work is cut into launches is an execution detail: unfused trace launches, fused ones
     (shadow b + closest b+1), 1 / 2 / 3 batches on separate streams must all give the same bytes, and the work

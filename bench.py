@@ -260,6 +260,7 @@ def main():
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
         "traffic_source": tr["source"] if tr else None,
+        "pmc": tr.get("pmc") if tr else None,
         "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),

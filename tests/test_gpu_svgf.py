@@ -170,3 +170,57 @@ def test_svgf_needs_motion_buffer_or_compute_pass(gpu, orc, cornell):
         gpu2_err = str(e)
     # a motion buffer set by an earlier test may satisfy the size; either outcome must be explicit
     assert gpu2_err is None or "motion" in gpu2_err
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_svgf_atrous_iteration_count(gpu, orc, cornell, iters):
+    """SVGFParams::atrous_iter_cnt other than 5: first == final iteration (1) and an odd ping-pong length (3)."""
+    fs, cam = cornell
+    w, h = 96, 64
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    sv.set_atrous_iterations(iters)
+    gpu.svgf_set_atrous_iterations(iters)
+    try:
+        for frame in range(3):
+            want, wst = sv.render(fs, c, seeds, w, h, 3, 3, frame=frame, compute_motion=True, stages=True)
+            contribs = wst[0].copy()
+            contribs[..., 3] = 1.0
+            gpu.svgf_upload("contribs", contribs)
+            gpu.svgf_upload("normal_depth", sv.buffer("prev_normal_depth"))
+            gpu.svgf_upload("albedo_meshid", sv.buffer("prev_albedo_meshid"))
+            gpu.svgf_upload("primary_position", sv.buffer("primary_position"))
+            got = gpu.svgf_denoise(w, h, frame=frame, compute_motion=True)
+            assert frac_within(got, want) >= 0.998, (iters, frame)
+    finally:
+        gpu.svgf_set_atrous_iterations(5)
+        sv.close()
+
+
+def test_svgf_full_size_properties_1080p(gpu, orc, sponza):
+    """Config-5 size, no oracle: a static camera gives zero motion, so every pixel that stays on its surface
+    accumulates one frame per render (moments.z == frames rendered) and the temporal weight saturates; the output is
+    finite wherever the path-traced input is, and it is smoother than its input."""
+    fs, cam = sponza
+    w, h = 1920, 1080
+    _setup(gpu, orc, fs, cam, w, h)
+    n = 4
+    for frame in range(n):
+        out, st = gpu.svgf_render(w, h, 5, 3, frame=frame, compute_motion=True, stages=True)
+    md = gpu.svgf_buffer("motion_depth")
+    assert np.all(md[..., :2] == 0.0)
+    mt = gpu.svgf_buffer("prev_moment_temporalweight")
+    ids = gpu.svgf_buffer("prev_albedo_meshid")[..., 3]
+    surf = ids >= 0
+    assert mt[..., 2].max() == n
+    assert (mt[..., 2][surf] == n).mean() > 0.9            # the rest was disoccluded by sub-pixel jitter at silhouettes
+    assert np.all(mt[..., 2][~surf] == 1.0)
+    assert (mt[..., 3][surf] > 0.5).mean() > 0.9           # temporal weight ~1 where reprojection succeeded
+    raw = st[0][..., :3] * gpu.svgf_buffer("prev_albedo_meshid")[..., :3]
+    ok = np.isfinite(raw).all(-1)
+    assert np.isfinite(out[..., :3][ok]).mean() > 0.999
+
+    def rough(a):
+        a = np.nan_to_num(a)
+        return np.abs(4 * a[1:-1, 1:-1] - a[:-2, 1:-1] - a[2:, 1:-1] - a[1:-1, :-2] - a[1:-1, 2:]).mean()
+    assert rough(out[..., :3]) < 0.5 * rough(raw)

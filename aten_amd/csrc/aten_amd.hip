@@ -438,10 +438,12 @@ public:
                         }
                     }
                 }
-                prof_begin(prof, ATN_K_ACCUM, st);
-                if (SVGF) hipLaunchKernelGGL(k_svgf_sample_end, dim3(g_all), dim3(256), 0, st, pb, fp, sf);
-                else hipLaunchKernelGGL(k_accumulate_sample, dim3(g_all), dim3(256), 0, st, pb, fp);
-                prof_end(prof);
+                if (SVGF || d->sample > 1) {     // with one sample per pixel k_gather<true> does the epilogue itself
+                    prof_begin(prof, ATN_K_ACCUM, st);
+                    if (SVGF) hipLaunchKernelGGL(k_svgf_sample_end, dim3(g_all), dim3(256), 0, st, pb, fp, sf);
+                    else hipLaunchKernelGGL(k_accumulate_sample, dim3(g_all), dim3(256), 0, st, pb, fp);
+                    prof_end(prof);
+                }
             }
             if (nb > 1) {
                 ATN_HIP(hipEventRecord(ev_join[k], st));
@@ -473,7 +475,8 @@ public:
         if (rc) return rc;
         fp.slot_begin = 0; fp.slot_end = (int32_t)n_slots;
         prof_begin(prof, ATN_K_GATHER);
-        hipLaunchKernelGGL(k_gather, dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
+        if (d->sample == 1) hipLaunchKernelGGL((k_gather<true>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
+        else hipLaunchKernelGGL((k_gather<false>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
 

@@ -593,6 +593,9 @@ __global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, Frame
 // col / cnt -> Film::put / FilmProgressive::put (renderer/film.cpp:33-45,61-71).
 // film: full-frame vec4[w*h] (row 0 = bottom); tile_out: this GPU's pixels in slot order
 // (the buffer that is all-gathered over RCCL when the screen is sharded).
+// ONE_SAMPLE: the frame has a single sample per pixel, so the per-sample epilogue (k_accumulate_sample) is folded in:
+// col = valid ? contrib : 0, cnt = valid ? 1 : 0 -- the same values the two kernels produce, without the accum round trip.
+template <bool ONE_SAMPLE>
 __global__ void __launch_bounds__(256) k_gather(PathBuffers pb, FrameParams fp, float4* film, float4* tile_out)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,7 +603,16 @@ __global__ void __launch_bounds__(256) k_gather(PathBuffers pb, FrameParams fp, 
     int32_t x, y;
     float4 out = make_float4(0, 0, 0, 0);
     if (slot_to_pixel(fp, slot, x, y)) {
-        const float4 a = pb.accum[slot];
+        float4 a;
+        if (ONE_SAMPLE) {
+            const float4 c = pb.contrib[slot];
+            const bool invalid = isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z)
+                || c.x < 0 || c.y < 0 || c.z < 0;                     // Renderer::isInvalidColor, renderer.h:58-68
+            a = invalid ? make_float4(0.0F, 0.0F, 0.0F, 0.0F) : make_float4(0.0F + c.x, 0.0F + c.y, 0.0F + c.z, 1.0F);
+        }
+        else {
+            a = pb.accum[slot];
+        }
         const float cnt = a.w;      // (float)cnt of an integer counter
         const float4 v = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
         const uint32_t idx = (uint32_t)(y * fp.width + x);

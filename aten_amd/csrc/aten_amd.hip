@@ -386,7 +386,8 @@ public:
         // streams path state through the L2 that the walk wants for its nodes and the deep-tree walk loses more than
         // the overlap wins (6.13 vs 6.59 ms), the shallow-tree walk still gains with two batches.
         int nb = n_batches;
-        const uint32_t min_batch = 200u * 1000u;
+        uint32_t min_batch = 200u * 1000u;
+        if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) min_batch = (uint32_t)std::atoi(e);     // experiments
         while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
         if (!batches_forced && n_slots >= 1500u * 1000u) nb = use_refill ? 1 : (nb < 2 ? nb : 2);
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;

@@ -167,8 +167,10 @@ public:
         list_root_link = img.list_root_link;
         top_base = img.list_root[0];
         n_host_matrices = s->n_matrices;
-        use_refill = img.nodes.size() / 3 >= kRefillMinNodes;
-        if (const char* e = std::getenv("ATEN_AMD_TRACE")) use_refill = (e[0] == 'r');   // 'r'efill / 's'imple: experiments
+        tree_is_deep = img.nodes.size() / 3 >= kRefillMinNodes;
+        use_refill = tree_is_deep;
+        flavour_forced = false;
+        if (const char* e = std::getenv("ATEN_AMD_TRACE")) { use_refill = (e[0] == 'r'); flavour_forced = true; }   // 'r'efill / 's'imple: experiments
         return ATN_OK;
     }
 
@@ -321,8 +323,12 @@ public:
     // Traversal flavour.  Measured on MI355X: the persistent lane-refilling walk wins
     // on sponza_lod (38 K nodes, ~56 node visits per ray: trace 3.25 -> 2.90 ms, shadow 4.40 -> 3.60 ms per
     // 1080p frame) and loses on the Cornell box (71 nodes, ~20 visits per ray: 0.83 -> 1.18 ms).
-    bool use_refill = false;
+    // Since the trace launches are fused (r01-g) the refill walk only pays when a launch carries >= ~1.5 M paths as
+    // well: on the 2-, 4- and 8-way shards of the 1080p frame the plain walk is 12-16 % faster (3.28 / 2.10 / 1.48 ms
+    // against 3.71 / 2.39 / 1.77), so the flavour is picked per frame from tree size AND frame size.
+    bool use_refill = false, tree_is_deep = false, flavour_forced = false;
     static constexpr size_t kRefillMinNodes = 2048;
+    static constexpr uint32_t kRefillMinPaths = 1500u * 1000u;
 
     uint32_t trace_grid(uint32_t n_jobs) const
     {
@@ -385,11 +391,19 @@ public:
         // while launches are latency-bound (<= ~1 M paths in flight); on a full 1080p frame the concurrent shade kernel
         // streams path state through the L2 that the walk wants for its nodes and the deep-tree walk loses more than
         // the overlap wins (6.13 vs 6.59 ms), the shallow-tree walk still gains with two batches.
-        int nb = n_batches;
-        uint32_t min_batch = 200u * 1000u;
-        if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) min_batch = (uint32_t)std::atoi(e);     // experiments
-        while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
-        if (!batches_forced && n_slots >= 1500u * 1000u) nb = use_refill ? 1 : (nb < 2 ? nb : 2);
+        if (!flavour_forced) use_refill = tree_is_deep && n_slots >= kRefillMinPaths;
+        int nb;
+        if (batches_forced) {
+            nb = n_batches;
+            uint32_t min_batch = 200u * 1000u;
+            if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) min_batch = (uint32_t)std::atoi(e);     // experiments
+            while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
+        }
+        else {
+            // the refill walk wants the machine to itself; the plain walk gains from a second batch down to ~0.8 M paths
+            nb = use_refill ? 1 : (n_slots >= 800u * 1000u ? 2 : 1);
+            if (nb > n_batches) nb = n_batches;
+        }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
         per = (per + kChunk - 1u) / kChunk * kChunk;        // whole 1024-slot chunks (16 screen tiles)
         ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * 4 * counters_depth * 4, stream));
@@ -919,14 +933,17 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
     C_HIP(r, hipMemcpyAsync(rays.p, rays_host, (size_t)n * sizeof(atn_ray), hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipMemsetAsync(st.p, 0, 64, r.stream));
     {
+        // the probe exercises the walk the scene's tree calls for (or the forced one), whatever n is
+        const bool probe_refill = r.flavour_forced ? r.use_refill : r.tree_is_deep;
+        r.use_refill = probe_refill;        // trace_grid sizes the launch for it
         const dim3 g(r.trace_grid(n)), t(atn::kTraceBlock);
         const atn_ray* rp = rays.p;
         if (stats_out) {
-            if (r.use_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
             else hipLaunchKernelGGL((atn::k_trace_batch<true, false>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
         }
         else {
-            if (r.use_refill) hipLaunchKernelGGL((atn::k_trace_batch<false, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<false, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
             else hipLaunchKernelGGL((atn::k_trace_batch<false, false>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
         }
     }

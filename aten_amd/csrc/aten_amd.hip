@@ -121,6 +121,7 @@ public:
         }
         ATN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
+        if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
         if (const char* e = std::getenv("ATEN_AMD_BATCHES")) {
             n_batches = std::atoi(e);
             batches_forced = true;
@@ -327,6 +328,7 @@ public:
     // well: on the 2-, 4- and 8-way shards of the 1080p frame the plain walk is 12-16 % faster (3.28 / 2.10 / 1.48 ms
     // against 3.71 / 2.39 / 1.77), so the flavour is picked per frame from tree size AND frame size.
     bool use_refill = false, tree_is_deep = false, flavour_forced = false;
+    uint32_t simple_block = 64;     // threads per block of the plain walk's fused launches: one wave per block retires on its own (1-2 % over 256)
     static constexpr size_t kRefillMinNodes = 2048;
     static constexpr uint32_t kRefillMinPaths = 1900u * 1000u;      // measured crossover on sponza_lod: 1.74 M paths plain 5.19 vs refill 5.25 ms, 2.07 M 6.11 vs 5.96
 
@@ -444,7 +446,7 @@ public:
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
                         prof_begin(prof, ATN_K_TRACE_FUSED, st);
                         if (use_refill) hipLaunchKernelGGL((k_trace_fused<true>), dim3(g_fused), dim3(kTraceBlock), 0, st, pb, scene, bs, bc, b);
-                        else hipLaunchKernelGGL((k_trace_fused<false>), dim3(g_fused), dim3(kTraceBlock), 0, st, pb, scene, bs, bc, b);
+                        else hipLaunchKernelGGL((k_trace_fused<false>), dim3(g_fused * (kTraceBlock / simple_block)), dim3(simple_block), 0, st, pb, scene, bs, bc, b);
                         prof_end(prof);
                         if (b < d->maxDepth) {
                             prof_begin(prof, ATN_K_SHADE, st);

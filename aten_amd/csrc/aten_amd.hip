@@ -308,6 +308,7 @@ public:
         fp.rr_depth = d.russianRouletteDepth;
         if (fp.rr_depth > fp.max_depth) fp.rr_depth = fp.max_depth - 1;    // pathtracing.cpp:282-284
         fp.slot_begin = 0; fp.slot_end = (int32_t)n_slots;
+        fp.chunk_items = kChunkItems;
         fp.sample = 0; fp.frame = d.frame; fp.n_seeds = n_seeds;
         fp.break_on_terminate = d.break_on_terminate; fp.progressive = d.progressive;
         return fp;
@@ -419,6 +420,13 @@ public:
             PathBuffers pb = buffers(count, k, begin);
             fp.slot_begin = (int32_t)begin; fp.slot_end = (int32_t)end;
             const uint32_t n = end - begin;
+            // k_shade works on chunks of `items` x 256 queue entries per block (one queue atomic per chunk): 4 on full
+            // frames; below ~0.4 M paths a launch has too few such blocks to fill 256 CUs (measured on the 8-way
+            // shard: 2 -> 1.38 ms, 4 -> 1.46 ms, 1 -> 1.41 ms per frame)
+            int items = n >= 400u * 1000u ? kChunkItems : 2;
+            if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) items = v; }   // experiments
+            fp.chunk_items = items;
+            const uint32_t g_shade = grid_for((n + (uint32_t)items - 1u) / (uint32_t)items);
             const uint32_t g_slots = grid_for(n), g_trace = trace_grid(n), g_all = (n + 255u) / 256u;
             for (int32_t s = 0; s < d->sample; s++) {
                 fp.sample = s;
@@ -432,7 +440,7 @@ public:
                         launch_trace<false>(pb, g_trace, count, b, st);
                         prof_end(prof);
                         prof_begin(prof, ATN_K_SHADE, st);
-                        hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_slots), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                        hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_shade), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
                         prof_end(prof);
                         prof_begin(prof, ATN_K_TRACE_SHADOW, st);
                         launch_trace<true>(pb, g_trace, count, b, st);
@@ -450,7 +458,7 @@ public:
                         prof_end(prof);
                         if (b < d->maxDepth) {
                             prof_begin(prof, ATN_K_SHADE, st);
-                            hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_slots), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                            hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_shade), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
                             prof_end(prof);
                         }
                     }

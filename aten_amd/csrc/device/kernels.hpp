@@ -45,6 +45,8 @@ struct FrameParams {
     int32_t width, height;
     int32_t n_slots;            // local path slots (n_local_tiles * 64)
     int32_t slot_begin, slot_end;   // the slots this launch works on (one batch of the frame, see PathTracing::render)
+    int32_t chunk_items;            // 1..kChunkItems queue entries per thread and chunk in k_shade: 4 keeps the queue atomics
+                                    // rare on full frames, fewer give small launches enough blocks to fill the chip
     int32_t tiles_x, tiles_y;
     int32_t rank, world;        // screen-space shard: tile t belongs to rank t % world
     int32_t max_depth, rr_depth;
@@ -250,10 +252,12 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
     uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
     uint32_t nhits = 0;
 
-    for (uint32_t chunk = blockIdx.x * kChunk; chunk < count; chunk += gridDim.x * kChunk) {
+    const int items = fp.chunk_items;
+    const uint32_t chunk_size = 256u * (uint32_t)items;
+    for (uint32_t chunk = blockIdx.x * chunk_size; chunk < count; chunk += gridDim.x * chunk_size) {
       uint32_t flags_next = 0, flags_shadow = 0;
 #pragma unroll 1
-      for (int k = 0; k < kChunkItems; k++) {
+      for (int k = 0; k < items; k++) {
         const uint32_t j = chunk + (uint32_t)k * 256u + threadIdx.x;
         const bool valid = j < count;
         bool push_next = false, push_shadow = false;

@@ -339,7 +339,9 @@ public:
             // persistent waves pulling kFetchChunk-job chunks: about as many waves as fit on the chip
             uint32_t blocks = ((n_jobs + atn::kFetchChunk - 1u) / atn::kFetchChunk + 3u) / 4u;
             if (blocks < 1u) blocks = 1u;
-            return blocks < 256u * 8u ? blocks : 256u * 8u;
+            uint32_t cap = 256u * 8u;
+            if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) cap = (uint32_t)std::atoi(e);     // experiments
+            return blocks < cap ? blocks : cap;
         }
         return grid_for(n_jobs);
     }

@@ -358,6 +358,25 @@ def test_atrium_instanced_disney_textured(gpu, orc):
                 assert np.array_equal(np.isnan(got[..., :3]).any(-1), np.isnan(want[..., :3]).any(-1))
 
 
+def test_constant_background_no_lights(gpu, orc):
+    """Background::SampleFromRay without an environment map (bg_color, renderer/background.h:34-62) and a scene whose
+    only light is that background: no light list -> no NEE, every contribution comes from ShadeMiss."""
+    from aten_amd.scene import scenedefs
+    scene = scenedefs.sponza_lod(ibl=False, textures=False)
+    fs, cam = scene
+    assert len(fs.arrays["lights"]) == 0
+    w, h = 128, 72
+    fs, c, seeds = _setup(gpu, orc, scene, w, h)
+    for frame in (0, 2):
+        gpu.reset()
+        got = gpu.render(w, h, 5, 3, frame=frame, count_stats=True)
+        assert gpu.stats()["shadow_rays"] == 0
+        want = orc.render(fs, c, seeds, w, h, 5, 3, frame=frame)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.995 and mean_err <= 5e-3, (frame, frac, mean_err)
+    assert np.nanmean(got[..., :3]) > 0.001      # light only enters through the roof openings
+
+
 def test_alpha_translucent_blocker_rule(gpu, orc):
     """material::isTranslucentByAlpha in HitTestToTargetLight (pathtracing_impl.h:295-336): a shadow-ray hit on a
     material with alpha < 1 is "ignored", and with the lookup budget of one the ray then counts as blocked -- even when

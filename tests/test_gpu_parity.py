@@ -523,3 +523,24 @@ def test_full_size_properties_1080p(gpu, orc, cornell):
     want = orc.render(fs, c, seeds, W, H, 5, 3, frame=0)
     frac, mean_err = frame_tolerance_report(a[rows], want[rows])
     assert frac >= 0.999 and mean_err <= 1e-3
+
+
+def test_headline_config_full_size_vs_oracle(gpu, orc, sponza):
+    """BASELINE config 3 at its full size (sponza_lod 1080p, 5 bounces), every pixel against the oracle: the primary
+    rays and their Intersection records + visit counters bit-for-bit (2 M rays through both walks' common probe), two
+    frames within the frame tolerance."""
+    W, H = 1920, 1080
+    fs, c, seeds = _setup(gpu, orc, sponza, W, H)
+    rays = orc.generate_paths(c, seeds, W, H, 0, 0)
+    assert gpu.generate_paths(W, H, 0, 0).tobytes() == rays.tobytes()
+    want_i, wst = orc.trace_closest(fs, rays)
+    got_i, gst = gpu.trace_closest(rays, stats=True)
+    assert got_i.tobytes() == want_i.tobytes()
+    assert np.array_equal(gst, wst)
+    for frame in (0, 9):
+        gpu.reset()
+        got = gpu.render(W, H, 5, 3, frame=frame)
+        want = orc.render(fs, c, seeds, W, H, 5, 3, frame=frame)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.998, (frame, frac)
+        assert mean_err <= 2e-3, (frame, mean_err)

@@ -25,5 +25,8 @@ def hostlib():
         lib.atns_free.restype = None
         lib.atns_validate_nodes.argtypes = [C.c_void_p, C.c_uint32]
         lib.atns_validate_nodes.restype = C.c_int64
+        lib.atns_create_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                           C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]
+        lib.atns_create_camera.restype = C.c_int
         _lib = lib
     return _lib

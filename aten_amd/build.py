@@ -44,10 +44,10 @@ def _run(cmd):
 
 
 def build_host(force=False):
-    srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp")]
+    srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp"), os.path.join(CSRC, "host", "camera.cpp")]
     deps = srcs + _walk(os.path.join(ROOT, "include"), (".h",))
     if force or not _newer(HOST_LIB, deps):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", HOST_LIB] + srcs)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", HOST_LIB] + srcs)
     return HOST_LIB
 
 

@@ -6,6 +6,7 @@
 // with the CPU renderer's semantics (frame passed in, CMJ seeded once per sample).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,8 @@ public:
     int n_batches = 3;
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
+    uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 256u * 8u;
+    int env_shade_items = 0, env_flavour = -1;
 
     // scene (HBM-resident after UpdateSceneData)
     DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels;
@@ -99,6 +102,7 @@ public:
     uint32_t k_launches[ATN_K_COUNT] = {};
     std::vector<hipEvent_t> ev_pool;
     struct Span { int kind; size_t e0, e1; };
+    static constexpr size_t kMaxSpans = 8192;
     std::vector<Span> spans;
     size_t ev_used = 0;
     hipStream_t prof_stream = nullptr;
@@ -120,7 +124,12 @@ public:
             ATN_HIP(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
         }
         ATN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        // experiment knobs (tools/variants.sh): read once here, never inside a frame
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
+        if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
+        if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
         if (const char* e = std::getenv("ATEN_AMD_BATCHES")) {
             n_batches = std::atoi(e);
@@ -171,7 +180,7 @@ public:
         tree_is_deep = img.nodes.size() / 3 >= kRefillMinNodes;
         use_refill = tree_is_deep;
         flavour_forced = false;
-        if (const char* e = std::getenv("ATEN_AMD_TRACE")) { use_refill = (e[0] == 'r'); flavour_forced = true; }   // 'r'efill / 's'imple: experiments
+        if (env_flavour >= 0) { use_refill = env_flavour == 1; flavour_forced = true; }
         return ATN_OK;
     }
 
@@ -183,7 +192,14 @@ public:
         if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
         if (!objs || n_objs == 0 || !top || n_top == 0) return fail(ATN_ERR_INVALID_ARG, "empty object or top-layer array");
         ATN_HIP(hipSetDevice(device));
-        if ((uint64_t)(top_base + n_top) * kNodeBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
+        if (((uint64_t)top_base + (uint64_t)n_top) * kNodeBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
+        if (n_mtxs && !mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
+        {
+            std::string rerr;
+            if (!validate_ranges(objs, n_objs, n_mtxs ? n_mtxs : n_host_matrices, nullptr, rerr)) return fail(ATN_ERR_UNSUPPORTED, rerr);
+            for (uint32_t i = 0; i < n_objs; i++)
+                if (objs[i].light_id >= scene.n_lights) return fail(ATN_ERR_UNSUPPORTED, "object light id out of range");
+        }
         ListEmitCtx c;
         c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
         c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
@@ -209,7 +225,6 @@ public:
         ATN_HIP(objects.upload(ov, stream));
         std::vector<float4> mv;
         if (n_mtxs) {
-            if (!mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
             mv.resize((size_t)n_mtxs * 4);
             for (uint32_t i = 0; i < n_mtxs; i++)
                 for (int r = 0; r < 4; r++)
@@ -221,6 +236,8 @@ public:
         list_root_link[0] = root;
         scene.root_link = root;
         scene.nodes = nodes.p; scene.objects = objects.p; scene.matrices = matrices.p;
+        tree_is_deep = (size_t)top_base + n_top >= kRefillMinNodes;
+        if (!flavour_forced) use_refill = tree_is_deep;
         return ATN_OK;
     }
 
@@ -260,16 +277,19 @@ public:
         const uint32_t n_tiles = (uint32_t)tx * ty;
         const uint32_t tiles_per_rank = (n_tiles + world - 1) / world;
         const uint32_t slots = tiles_per_rank * 64;
-        if (w != film_w || h != film_h || slots != n_slots) {
+        if (slots != n_slots) {
             ATN_HIP(ray_o.resize(slots)); ATN_HIP(ray_d.resize(slots)); ATN_HIP(thr.resize(slots));
             ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots)); ATN_HIP(isect2.resize(slots));
             ATN_HIP(sh_o.resize(slots)); ATN_HIP(sh_d.resize(slots)); ATN_HIP(sh_c.resize(slots));
             ATN_HIP(accum.resize(slots)); ATN_HIP(done.resize(slots));
             ATN_HIP(queue0.resize(slots)); ATN_HIP(queue1.resize(slots)); ATN_HIP(shadow_q.resize(slots));
             ATN_HIP(tile_out.resize(slots));
+            n_slots = slots;
+        }
+        if (w != film_w || h != film_h) {
             ATN_HIP(film.resize((size_t)w * h));
             ATN_HIP(hipMemsetAsync(film.p, 0, (size_t)w * h * sizeof(float4), stream));
-            film_w = w; film_h = h; n_slots = slots;
+            film_w = w; film_h = h;
         }
         if (max_depth + 2 > counters_depth) {
             ATN_HIP(counters.resize((size_t)kMaxBatches * 4 * (max_depth + 2)));
@@ -339,8 +359,7 @@ public:
             // persistent waves pulling kFetchChunk-job chunks: about as many waves as fit on the chip
             uint32_t blocks = ((n_jobs + atn::kFetchChunk - 1u) / atn::kFetchChunk + 3u) / 4u;
             if (blocks < 1u) blocks = 1u;
-            uint32_t cap = 256u * 8u;
-            if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) cap = (uint32_t)std::atoi(e);     // experiments
+            const uint32_t cap = env_trace_blocks;
             return blocks < cap ? blocks : cap;
         }
         return grid_for(n_jobs);
@@ -365,6 +384,11 @@ public:
         if (!st) st = stream;
         prof_stream = st;
         if (!on) return;
+        if (spans.size() >= kMaxSpans) {    // nobody collected for thousands of launches: resolve them now (bounded pool)
+            (void)hipStreamSynchronize(stream);
+            for (int k = 0; k < kMaxBatches; k++) (void)hipStreamSynchronize(bstream[k]);
+            prof_collect();
+        }
         if (ev_used + 2 > ev_pool.size()) {
             for (int i = 0; i < 64; i++) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
         }
@@ -400,8 +424,7 @@ public:
         int nb;
         if (batches_forced) {
             nb = n_batches;
-            uint32_t min_batch = 200u * 1000u;
-            if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) min_batch = (uint32_t)std::atoi(e);     // experiments
+            const uint32_t min_batch = env_min_batch;
             while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
         }
         else {
@@ -426,7 +449,7 @@ public:
             // frames; below ~0.4 M paths a launch has too few such blocks to fill 256 CUs (measured on the 8-way
             // shard: 2 -> 1.38 ms, 4 -> 1.46 ms, 1 -> 1.41 ms per frame)
             int items = n >= 400u * 1000u ? kChunkItems : 2;
-            if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) items = v; }   // experiments
+            if (env_shade_items) items = env_shade_items;
             fp.chunk_items = items;
             const uint32_t g_shade = grid_for((n + (uint32_t)items - 1u) / (uint32_t)items);
             const uint32_t g_slots = grid_for(n), g_trace = trace_grid(n), g_all = (n + 255u) / 256u;
@@ -526,6 +549,7 @@ public:
     float4* sv_spare = nullptr;
     int32_t sv_w = 0, sv_h = 0, sv_curr = 0, sv_atrous_iters = 5;
     bool sv_motion_set = false;
+    size_t sv_motion_count = 0;     // elements of the last atn_svgf_set_motion_depth / upload (sv_motion.n is the capacity)
     float sv_W2V[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
     float sv_V2C[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
     float sv_prevW2V[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
@@ -590,7 +614,7 @@ public:
             ATN_HIP(sv_tmp.resize(n)); svgf_fill(sv_tmp.p, n, init);
             ATN_HIP(sv_primary.resize(n)); svgf_fill(sv_primary.p, n, make_float4(0, 0, 0, 0));
             ATN_HIP(sv_contribs.resize(n)); ATN_HIP(sv_out.resize(n));
-            if (!sv_motion_set || sv_motion.n < n) { ATN_HIP(sv_motion.resize(n)); sv_motion_set = false; }
+            if (!sv_motion_set || sv_motion_count < n) { ATN_HIP(sv_motion.resize(n)); sv_motion_set = false; sv_motion_count = 0; }
             sv_cv[0] = sv_aov[0][2].p; sv_cv[1] = sv_aov[1][2].p; sv_spare = sv_scratch.p;
             sv_w = w; sv_h = h; sv_curr = 0;
         }
@@ -607,6 +631,7 @@ public:
         ATN_HIP(hipMemcpyAsync(sv_motion.p, md, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, stream));
         ATN_HIP(hipStreamSynchronize(stream));
         sv_motion_set = true;
+        sv_motion_count = n;
         return ATN_OK;
     }
 
@@ -644,7 +669,7 @@ public:
         if (rc) return rc;
         rc = svgf_ensure(d->width, d->height, stages_host != nullptr);
         if (rc) return rc;
-        if (!compute_motion && (!sv_motion_set || sv_motion.n < (size_t)d->width * d->height))
+        if (!compute_motion && (!sv_motion_set || sv_motion_count < (size_t)d->width * d->height))
             return fail(ATN_ERR_INVALID_ARG, "no motion/depth buffer: call atn_svgf_set_motion_depth or pass compute_motion = 1");
         const bool prof = d->profile != 0;
         PathBuffers pb = buffers(false);
@@ -728,6 +753,20 @@ struct atn_ctx { atn::PathTracing r; };
 using atn::PathTracing;
 
 #define CTX_OR_FAIL(ctx) do { if (!(ctx)) return ATN_ERR_INVALID_ARG; } while (0)
+
+// No exception may cross the C boundary (std::vector growth in the upload paths can throw std::bad_alloc).
+template <class F>
+static int guarded(atn_ctx* ctx, F&& f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) {
+        try { return ctx->r.fail(ATN_ERR_OUT_OF_MEMORY, "out of host memory"); } catch (...) { return ATN_ERR_OUT_OF_MEMORY; }
+    }
+    catch (const std::exception& e) {
+        try { return ctx->r.fail(ATN_ERR_INVALID_ARG, std::string("unexpected exception: ") + e.what()); } catch (...) { return ATN_ERR_INVALID_ARG; }
+    }
+    catch (...) { return ATN_ERR_INVALID_ARG; }
+}
 #define C_HIP(r, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (r).fail(ATN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 extern "C" {
@@ -756,19 +795,19 @@ int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene)
 {
     CTX_OR_FAIL(ctx);
     if (!scene) return ctx->r.fail(ATN_ERR_INVALID_ARG, "null scene");
-    return ctx->r.UpdateSceneData(scene);
+    return guarded(ctx, [&] { return ctx->r.UpdateSceneData(scene); });
 }
 
-int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAIL(ctx); return ctx->r.updateCamera(camera); }
+int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.updateCamera(camera); }); }
 
 int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
                     const atn_bvh_node* top_nodes, uint32_t n_top_nodes)
 {
     CTX_OR_FAIL(ctx);
-    return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes);
+    return guarded(ctx, [&] { return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); });
 }
-int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_OR_FAIL(ctx); return ctx->r.initSampler(w, h, seed); }
-int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_OR_FAIL(ctx); return ctx->r.setRandom(seeds, n); }
+int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.initSampler(w, h, seed); }); }
+int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.setRandom(seeds, n); }); }
 
 int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
 {
@@ -778,7 +817,7 @@ int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
     return ATN_OK;
 }
 
-int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return ctx->r.render(dst, out_host); }
+int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.render(dst, out_host); }); }
 int atn_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.reset(); }
 int atn_set_path_batches(atn_ctx* ctx, int32_t n)
 {
@@ -792,9 +831,9 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n)
 int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
 {
     CTX_OR_FAIL(ctx);
-    return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host);
+    return guarded(ctx, [&] { return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host); });
 }
-int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_OR_FAIL(ctx); return ctx->r.svgf_set_motion_depth(motion_depth, n); }
+int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.svgf_set_motion_depth(motion_depth, n); }); }
 int atn_svgf_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.svgf_reset(); }
 int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n)
 {
@@ -817,7 +856,7 @@ int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host)
 int atn_svgf_denoise(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
 {
     CTX_OR_FAIL(ctx);
-    return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host, false);
+    return guarded(ctx, [&] { return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host, false); });
 }
 int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, const atn_vec4* host)
 {
@@ -831,7 +870,7 @@ int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, 
     if (!p) return r.fail(ATN_ERR_INVALID_ARG, "no such SVGF buffer");
     C_HIP(r, hipMemcpyAsync(p, host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipStreamSynchronize(r.stream));
-    if (which == 9) r.sv_motion_set = true;
+    if (which == 9) { r.sv_motion_set = true; r.sv_motion_count = (size_t)width * height; }
     return ATN_OK;
 }
 void* atn_svgf_output_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.sv_out.p : nullptr; }
@@ -926,8 +965,7 @@ int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t samp
     hipLaunchKernelGGL(atn::k_export_rays, dim3((r.n_slots + 255) / 256), dim3(256), 0, r.stream, pb, fp, out.p);
     C_HIP(r, hipMemcpyAsync(out_host, out.p, (size_t)width * height * sizeof(atn_ray), hipMemcpyDeviceToHost, r.stream));
     C_HIP(r, hipStreamSynchronize(r.stream));
-    r.rank = sr; r.world = sw;
-    r.film_w = 0; r.film_h = 0;     // force re-validation of frame buffers for the caller's shard
+    r.rank = sr; r.world = sw;      // (the next render re-validates its path buffers against its own shard's slot count)
     return ATN_OK;
 }
 
@@ -1008,26 +1046,52 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
     return ATN_OK;
 }
 
-int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* out_idx_host, uint32_t* out_count)
+int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
+                 int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
 {
     CTX_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
-    if (!flags_host || !out_idx_host || !out_count) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
-    *out_count = 0;
+    if (!flags_a_host || !out_a_host || !out_count_a) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
+    if (flags_b_host && (!out_b_host || !out_count_b)) return r.fail(ATN_ERR_INVALID_ARG, "null output for the second queue");
+    *out_count_a = 0;
+    if (out_count_b) *out_count_b = 0;
     if (n == 0) return ATN_OK;
-    C_HIP(r, hipSetDevice(r.device));
-    atn::DevBuf<int32_t> f, o; atn::DevBuf<uint32_t> c;
-    C_HIP(r, f.resize(n)); C_HIP(r, o.resize(n)); C_HIP(r, c.resize(1));
-    C_HIP(r, hipMemcpyAsync(f.p, flags_host, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
-    hipLaunchKernelGGL(atn::k_compact_stable, dim3(1), dim3(64), 0, r.stream, (const int32_t*)f.p, n, o.p, c.p);
-    C_HIP(r, hipGetLastError());
-    C_HIP(r, hipMemcpyAsync(out_count, c.p, 4, hipMemcpyDeviceToHost, r.stream));
-    C_HIP(r, hipStreamSynchronize(r.stream));
-    if (*out_count) {
-        C_HIP(r, hipMemcpyAsync(out_idx_host, o.p, 4 * (size_t)(*out_count), hipMemcpyDeviceToHost, r.stream));
+    return guarded(ctx, [&]() -> int {
+        C_HIP(r, hipSetDevice(r.device));
+        atn::DevBuf<int32_t> fa, fb; atn::DevBuf<uint32_t> oa, ob, c;
+        C_HIP(r, fa.resize(n)); C_HIP(r, oa.resize(n)); C_HIP(r, c.resize(2));
+        C_HIP(r, hipMemcpyAsync(fa.p, flags_a_host, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        if (flags_b_host) {
+            C_HIP(r, fb.resize(n)); C_HIP(r, ob.resize(n));
+            C_HIP(r, hipMemcpyAsync(fb.p, flags_b_host, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        }
+        C_HIP(r, hipMemsetAsync(c.p, 0, 8, r.stream));
+        uint32_t grid = grid_blocks ? grid_blocks : PathTracing::grid_for((n + (uint32_t)atn::kChunkItems - 1u) / (uint32_t)atn::kChunkItems);
+        hipLaunchKernelGGL(atn::k_compact_append, dim3(grid), dim3(256), 0, r.stream, (const int32_t*)fa.p, (const int32_t*)fb.p, n,
+                           oa.p, c.p, ob.p, c.p + 1);
+        C_HIP(r, hipGetLastError());
+        uint32_t hc[2] = { 0, 0 };
+        C_HIP(r, hipMemcpyAsync(hc, c.p, 8, hipMemcpyDeviceToHost, r.stream));
         C_HIP(r, hipStreamSynchronize(r.stream));
-    }
-    return ATN_OK;
+        if (hc[0] > n || hc[1] > n) return r.fail(ATN_ERR_HIP, "queue append reserved more entries than exist");
+        *out_count_a = hc[0];
+        if (hc[0]) C_HIP(r, hipMemcpyAsync(out_a_host, oa.p, 4 * (size_t)hc[0], hipMemcpyDeviceToHost, r.stream));
+        if (flags_b_host) {
+            *out_count_b = hc[1];
+            if (hc[1]) C_HIP(r, hipMemcpyAsync(out_b_host, ob.p, 4 * (size_t)hc[1], hipMemcpyDeviceToHost, r.stream));
+        }
+        C_HIP(r, hipStreamSynchronize(r.stream));
+        return ATN_OK;
+    });
+}
+
+int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* out_idx_host, uint32_t* out_count)
+{
+    // the product's unordered block append, put into index order on the host: the entries ARE the indices, so the
+    // sorted queue is the stable compaction
+    int rc = atn_compact2(ctx, flags_host, nullptr, n, 0, out_idx_host, out_count, nullptr, nullptr);
+    if (rc == ATN_OK && *out_count) std::sort(out_idx_host, out_idx_host + *out_count);
+    return rc;
 }
 
 uint32_t atn_sizeof_scene_desc(void) { return (uint32_t)sizeof(atn_scene_desc); }

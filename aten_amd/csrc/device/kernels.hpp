@@ -202,10 +202,11 @@ struct ClosestJob {
     PathBuffers pb;
     const uint32_t* __restrict__ q;
     float t_min;
-    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b, float& stop_t) const
     {
         const uint32_t slot = q[j];
         const float4 ro = pb.ray_o[slot], rd = pb.ray_d[slot];
+        stop_t = -kInf;
         a = make_float4(ro.x, ro.y, ro.z, kInf);
         b = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
     }
@@ -361,8 +362,10 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 bool shaded_out = false;
                 // HitTeminatedMaterial -> HitImplicitLight, pathtracing_impl.h:395-509
                 if (m.type == ATN_MTRL_EMISSIVE && (m.attrib & ATN_MTRL_ATTR_EMISSIVE) && !isBackfacing) {
-                    const atn_object_param* obj = &sc.objects[is2.x];
-                    const f3 light_color = area_light_color(sc.lights[obj->light_id], rec.area);
+                    // an emissive surface that is not registered as a light (light_id < 0) has no LightParameter to
+                    // read: the reference indexes lights[-1] there; here it emits nothing
+                    const int32_t lid = sc.objects[is2.x].light_id;
+                    const f3 light_color = (lid >= 0 && lid < sc.n_lights) ? area_light_color(sc.lights[lid], rec.area) : mk3(0.0F);
                     float weight = 1.0f;
                     if (bounce > 0) {
                         const float cosLight = dot(rec.normal, -ray_dir);
@@ -473,18 +476,22 @@ struct ShadowJob {
     PathBuffers pb;
     DevScene sc;
     float t_min;
-    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b, float& stop_t) const
     {
         const uint32_t slot = pb.shadow_q[j];
         const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
         const f3 dir = normalize(mk3(sd));      // aten::ray(org, dir) constructor re-normalises (pathtracing_impl.h:380)
-        // scene::hitLight (scene/scene.h:118-131) needs the closest hit's OBJECT only for area lights.  For
-        // infinite and singular lights its answer is exactly `!isHit` (lightobj is null; t <= t_max < dist),
-        // so those shadow rays are any-hit jobs.
+        // scene::hitLight (scene/scene.h:118-131) needs the closest hit's OBJECT only for area lights.  For an
+        // infinite light without object its answer is exactly `!isHit`: any accepted hit settles it.  For a point /
+        // spot light it is `hit.t > distToLight`: the walk's t_max caps only box tests, so a triangle BEHIND the light
+        // can be accepted first (triangle hits are accepted against isect.t = inf, threaded_bvh_traverser.h:236-262)
+        // while the closest hit is a nearer blocker -- only an accepted hit with t <= distToLight settles it early.
         const atn_light_param* lp = &sc.lights[__float_as_int(sd.w)];
-        const bool needs_closest = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
-        const float t_max = so.w - kEps;                        // distToLight - AT_MATH_EPSILON (:304)
-        a = make_float4(so.x, so.y, so.z, (needs_closest || !(t_max > 0.0F)) ? t_max : -t_max);
+        const bool has_obj = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
+        // (a light with neither object nor attribute is visible iff nothing is hit, like an infinite one)
+        const bool near_only = (lp->attrib & ATN_LIGHT_ATTR_SINGULAR) && !(lp->attrib & ATN_LIGHT_ATTR_INFINITE);
+        stop_t = has_obj ? -kInf : (near_only ? so.w : kInf);
+        a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)
         b = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
     }
     ATN_DEV void finish(uint32_t slot, const Hit& h, bool isHit) const
@@ -496,8 +503,14 @@ struct ShadowJob {
         const uint32_t lattr = lp->attrib;
         const int32_t lightobj = (ltype == ATN_LIGHT_AREA && lobj >= 0) ? lobj : -1;
         const int32_t hitobj = isHit ? h.objid : lightobj;
-        if (sc.any_alpha && isHit && h.objid == lightobj) {
-            // (every other hit already means "not visible", whatever its alpha)
+        bool visible;
+        if (hitobj == lightobj) visible = true;
+        else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
+        else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
+        else visible = false;
+        if (sc.any_alpha && isHit && visible) {
+            // (every other hit already means "not visible", whatever its alpha; and a walk that stopped early --
+            // ShadowJob::fetch -- is never `visible`, so `h` is the exact closest hit here)
             // material::isTranslucentByAlpha hit (material.cpp:193-210): "ignored", and with a lookup budget of one
             // (no alpha blending / stencil) the shadow ray then counts as blocked (pathtracing_impl.h:295-336).
             // Only materials flagged at upload can have alpha < 1.
@@ -510,11 +523,6 @@ struct ShadowJob {
                 if (albedo.w * hm.baseColor.w < 1.0F) return;
             }
         }
-        bool visible;
-        if (hitobj == lightobj) visible = true;
-        else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
-        else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
-        else visible = false;
         if (visible) {
             const float4 c = pb.contrib[slot];
             const float4 lc = pb.sh_c[slot];
@@ -547,14 +555,14 @@ struct FusedJob {
     ClosestJob c;
     uint32_t n_shadow;
     float t_min;
-    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b, float& stop_t) const
     {
         if (j < n_shadow) {
-            s.fetch(j, a, b);
+            s.fetch(j, a, b, stop_t);
             b.w = __uint_as_float(__float_as_uint(b.w) | 0x80000000u);
         }
         else {
-            c.fetch(j - n_shadow, a, b);
+            c.fetch(j - n_shadow, a, b, stop_t);
         }
     }
     ATN_DEV void finish(uint32_t payload, const Hit& h, bool is_hit) const
@@ -655,9 +663,10 @@ struct BatchJob {
     const atn_ray* __restrict__ rays;
     atn_intersection* out;
     float t_min, t_max;
-    ATN_DEV void fetch(uint32_t j, float4& a, float4& b) const
+    ATN_DEV void fetch(uint32_t j, float4& a, float4& b, float& stop_t) const
     {
         const atn_ray r = rays[j];
+        stop_t = -kInf;
         a = make_float4(r.org[0], r.org[1], r.org[2], t_max);
         b = make_float4(r.dir[0], r.dir[1], r.dir[2], __uint_as_float(j));
     }
@@ -727,22 +736,28 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
     e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
 }
 
-// Stable compaction of indices whose flag > 0 (the contract of idaten::StreamCompaction::compact,
-// src/libidaten/kernel/StreamCompaction.cu:175-316) for ONE wave-sized or larger array, done with
-// the same ballot/mbcnt primitive as queue_push but made order-preserving by a serial block loop.
-// Only used by the compaction known-answer test; the renderer's queues need no ordering.
-__global__ void __launch_bounds__(64) k_compact_stable(const int32_t* __restrict__ flags, uint32_t n, int32_t* out_idx, uint32_t* out_count)
+// The renderer's queue append (block_append2) over caller-provided flags: entry i goes to queue A when
+// flags_a[i] > 0 and to queue B when flags_b[i] > 0 (flags_b may be null) -- exactly the call k_shade makes for
+// its next-bounce and shadow queues, same chunking (kChunkItems x 256 entries per block and atomic), grid-stride.
+// The queues come out UNORDERED (slot order is irrelevant to the renderer); atn_compact sorts them on the host
+// to present the stable contract of idaten::StreamCompaction::compact (StreamCompaction.cu:175-316).
+__global__ void __launch_bounds__(256) k_compact_append(const int32_t* __restrict__ flags_a, const int32_t* __restrict__ flags_b, uint32_t n,
+                                                        uint32_t* out_a, uint32_t* cnt_a, uint32_t* out_b, uint32_t* cnt_b)
 {
-    uint32_t total = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + threadIdx.x;
-        const bool pred = i < n && flags[i] > 0;
-        const unsigned long long mask = __ballot(pred);
-        const uint32_t prefix = __popcll(mask & ((1ull << threadIdx.x) - 1ull));
-        if (pred) out_idx[total + prefix] = (int32_t)i;
-        total += (uint32_t)__popcll(mask);
+    __shared__ BlockAppendShared sh;
+    for (uint32_t chunk = blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
+        uint32_t fa = 0, fb = 0;
+#pragma unroll
+        for (int k = 0; k < kChunkItems; k++) {
+            const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
+            if (i < n) {
+                if (flags_a[i] > 0) fa |= 1u << k;
+                if (flags_b && flags_b[i] > 0) fb |= 1u << k;
+            }
+        }
+        block_append2(sh, out_a, cnt_a, fa, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb,
+                      [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
     }
-    if (threadIdx.x == 0) *out_count = total;
 }
 
 } // namespace atn

@@ -86,10 +86,12 @@ ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
 
 // Job interface (all jobs of a launch share t_min):
 //   float t_min
-//   void fetch(uint32_t j, float4& a, float4& b)   a = {org.xyz, +-t_max}, b = {dir.xyz, payload bits}
-//        a.w < 0 marks an "any hit" job: only finish()'s is_hit is used, so the walk may stop at its first
-//        accepted hit.  This is exact, not an approximation: up to its first accepted hit the closest-hit
-//        walk is the same walk, and it reports is_hit = true iff it accepts at least one hit.
+//   void fetch(uint32_t j, float4& a, float4& b, float& stop_t)   a = {org.xyz, t_max}, b = {dir.xyz, payload bits}
+//        stop_t: the walk may stop at the first ACCEPTED hit whose t <= stop_t.  -inf = plain closest-hit walk;
+//        +inf = "any hit" (only finish()'s is_hit is used); a finite value = the caller only needs to know whether
+//        the closest hit is nearer than stop_t (shadow rays toward point / spot lights).  This is exact, not an
+//        approximation: up to that hit the closest-hit walk is the same walk, its final hit can only be nearer,
+//        and when no such hit is accepted the walk runs to its end and reports the exact closest hit.
 //   void finish(uint32_t payload, const Hit& h, bool is_hit)
 // One ray per lane for the lifetime of its walk; grid-stride over the jobs.
 template <bool COUNT, class Job>
@@ -100,9 +102,9 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
         float4 a, b;
-        job.fetch(j, a, b);
-        float t_max = fabsf(a.w);
-        const bool any_hit = a.w < 0.0F;        // see Job::fetch
+        float stop_t;
+        job.fetch(j, a, b, stop_t);
+        float t_max = a.w;
         const uint32_t payload = __float_as_uint(b.w);
         RaySlab wray, ray;
         slab_setup(wray, mk3(a), mk3(b));
@@ -146,7 +148,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     t_max = t;
                 }
                 node = __float_as_int(q1.w);        // leaf: hit link == miss link
-                if (any_hit && accept) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
+                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }    // see Job::fetch
             }
             else {
                 // TLAS leaf with a nested tree
@@ -197,7 +199,7 @@ constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
 #endif
 constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
 constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
-struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; };   // 16 KB
+struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk]; };   // 18 KB
 
 template <bool COUNT, class Job>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
@@ -208,6 +210,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     const uint32_t lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     float4 (*stage)[2] = sh.stage[threadIdx.x >> 6];
+    float* stage_stop = sh.stop[threadIdx.x >> 6];
 
     uint32_t c_count = 0, c_next = 0;   // wave-uniform: staged chunk size / next unassigned entry
     bool drained = false;               // wave-uniform: the global queue is empty
@@ -216,8 +219,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     bool first_chunk = true;            // wave-uniform
 
     uint32_t payload = 0;
-    float t_max = 0.0F;
-    bool any_hit = false;
+    float t_max = 0.0F, stop_t = -kInf;
     RaySlab wray, ray;
     slab_setup(wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
     ray = wray;
@@ -250,9 +252,11 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     for (uint32_t e = 0; e < kFetchChunk; e += 64) {
                         if (e + lane < c_count) {
                             float4 a, b;
-                            job.fetch(base + e + lane, a, b);
+                            float st;
+                            job.fetch(base + e + lane, a, b, st);
                             stage[e + lane][0] = a;
                             stage[e + lane][1] = b;
+                            stage_stop[e + lane] = st;
                         }
                     }
                 }
@@ -264,8 +268,8 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     if (k < avail) {
                         const float4 a = stage[c_next + k][0];
                         const float4 b = stage[c_next + k][1];
-                        t_max = fabsf(a.w);
-                        any_hit = a.w < 0.0F;
+                        t_max = a.w;
+                        stop_t = stage_stop[c_next + k];
                         payload = __float_as_uint(b.w);
                         hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
                         slab_setup(wray, mk3(a), mk3(b));
@@ -316,7 +320,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     t_max = t;
                 }
                 node = __float_as_int(q1.w);
-                if (any_hit && accept) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
+                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
             }
             else {
                 objid = __float_as_int(q0.x);

@@ -50,7 +50,7 @@ inline bool walk_order(const atn_bvh_node* nodes, uint32_t count, std::vector<in
 // What a list's records need from the rest of the scene.
 struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
-    const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0;
+    const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0, n_vertices = 0;
     const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
     bool top = false;
 };
@@ -88,6 +88,10 @@ inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint
         q0 = q1 = q2 = make_float4(0, 0, 0, 0);
         const int32_t h = remap(n.hit), m = remap(n.miss);
         if (h == -2 || m == -2) { err = "BVH link points to an unreachable node"; return false; }
+        // Every link must point FORWARD in walk order: the device walk has no other termination argument (a
+        // corrupted or hand-edited .sbvh with a backward miss link would spin a wave forever).
+        auto forward = [&](float link) { const int32_t l = (int32_t)link; return l < 0 || new_index[l] > (int32_t)j; };
+        if (!forward(n.hit) || !forward(n.miss)) { err = "BVH link points backward in walk order (the walk would not terminate)"; return false; }
         const bool leaf = (n.f0 >= 0 || n.f1 >= 0);         // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
         if (!leaf) {
             if (h == kLinkEnd || ((uint32_t)h & kLinkOffsetMask) != (abs + 1) * kNodeBytes) { err = "inner node whose hit link is not the next node in walk order"; return false; }
@@ -119,6 +123,8 @@ inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint
             if (tri >= c.n_triangles) { err = "leaf triangle id out of range"; return false; }
             if (h != m) { err = "triangle leaf with hit != miss link"; return false; }
             const atn_triangle_param& t = c.tris[tri];
+            for (int v = 0; v < 3; v++)
+                if (t.idx[v] < 0 || (uint32_t)t.idx[v] >= c.n_vertices) { err = "triangle vertex index out of range"; return false; }
             const atn_vec4& a = c.vtx_pos[t.idx[0]];
             const atn_vec4& b = c.vtx_pos[t.idx[1]];
             const atn_vec4& cc = c.vtx_pos[t.idx[2]];
@@ -138,6 +144,33 @@ inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint
     return true;
 }
 
+// Range checks of every id the kernels index with (a bad id is a device out-of-bounds read, not an error code).
+// `s` may be null for a top-layer update (objects / matrices only).
+inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint32_t n_mtx, const atn_scene_desc* s, std::string& err)
+{
+    const uint32_t n_tris = s ? s->n_triangles : 0xffffffffu, n_lights = s ? s->n_lights : 0xffffffffu;
+    for (uint32_t i = 0; i < n_objs; i++) {
+        const atn_object_param& o = objs[i];
+        if (o.type == ATN_OBJ_INSTANCE && (o.object_id < 0 || (uint32_t)o.object_id >= n_objs)) { err = "instance refers to an object id out of range"; return false; }
+        if (o.mtx_id >= 0 && (uint32_t)o.mtx_id + 1 >= n_mtx) { err = "object matrix index out of range"; return false; }
+        if (s && o.light_id >= 0 && (uint32_t)o.light_id >= n_lights) { err = "object light id out of range"; return false; }
+        if (s && o.type == ATN_OBJ_POLYGONS && o.triangle_num > 0
+            && (o.triangle_id < 0 || (uint64_t)o.triangle_id + (uint64_t)o.triangle_num > n_tris)) { err = "object triangle range out of range"; return false; }
+    }
+    if (!s) return true;
+    for (uint32_t i = 0; i < s->n_triangles; i++) {
+        const atn_triangle_param& t = s->triangles[i];
+        if (t.mtrlid >= 0 && (uint32_t)t.mtrlid >= s->n_materials) { err = "triangle material id out of range"; return false; }
+        for (int v = 0; v < 3; v++)
+            if (t.idx[v] < 0 || (uint32_t)t.idx[v] >= s->n_vertices) { err = "triangle vertex index out of range"; return false; }
+    }
+    for (uint32_t i = 0; i < s->n_lights; i++) {
+        const atn_light_param& l = s->lights[i];
+        if (l.arealight_objid >= 0 && (uint32_t)l.arealight_objid >= s->n_objects) { err = "light refers to an object id out of range"; return false; }
+    }
+    return true;
+}
+
 // Node image = [BLAS list 1][BLAS list 2]...[top layer (list 0)]: the top layer comes last so that
 // update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it without moving the others.
 inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err)
@@ -153,8 +186,10 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
 
     ListEmitCtx c;
     c.objects = s->objects; c.n_objects = s->n_objects; c.n_matrices = s->n_matrices;
-    c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles;
+    c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles; c.n_vertices = s->n_vertices;
     c.n_lists = nl;
+    std::string range_err;
+    if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
     uint64_t counts[3] = { 0, 0, 0 };
     uint32_t base = 0;
     for (uint32_t k = 1; k <= nl; k++) {

@@ -123,7 +123,7 @@ def main():
     from aten_amd.interop import tensor_from_ptr
     from aten_amd.renderer import PathTracing
     from aten_amd.scene import scenedefs
-    from oracle import orc     # checker + cpu_baseline leg only; also builds the camera parameter block
+    from aten_amd.scene.camera import create_camera
 
     W, H, spp, depth, rr = args.width, args.height, args.spp, args.depth, 3
     if args.scene == "sponza":
@@ -138,7 +138,7 @@ def main():
         fs, cam = scenedefs.cornell_box()
         workload = "cornell box %dx%d %dspp %d-bounce NEE" % (W, H, spp, depth)
     brk = not args.all_samples
-    camera = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    camera = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
 
     dev = "cuda:%d" % local_rank
     r = PathTracing(local_rank)
@@ -294,6 +294,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import orc     # the cpu_baseline leg is the only place bench.py touches oracle/
         # bounded sample of the same workload: same scene / camera / seeds at 1/3 linear resolution
         cw, ch = max(W // 3, 8), max(H // 3, 8)
         if args.scene == "atrium":

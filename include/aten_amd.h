@@ -179,8 +179,15 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
                        const uint32_t* index, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval);
 /* Stable compaction of indices with flag > 0 (contract of idaten::StreamCompaction::compact,
- * src/libidaten/kernel/StreamCompaction.cu:175-316). */
+ * src/libidaten/kernel/StreamCompaction.cu:175-316): the renderer's own queue append (one ballot + popcount
+ * prefix per wave, one atomic per 1024-entry block chunk -- the call k_shade makes) followed by a host sort,
+ * because the renderer's queues are unordered. */
 int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* out_idx_host, uint32_t* out_count);
+/* The queue append as the renderer uses it: two queues filled in one pass (entry i -> A when flags_a[i] > 0, -> B
+ * when flags_b[i] > 0; flags_b may be NULL), outputs in the (racy) order the device produced.  grid_blocks = 0
+ * picks the renderer's launch geometry; any other value forces that many 256-thread blocks (grid-stride path). */
+int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
+                 int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b);
 
 /* ABI self-description for binding checks. */
 uint32_t atn_sizeof_scene_desc(void);

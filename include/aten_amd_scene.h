@@ -36,6 +36,11 @@ int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t
 
 void atns_free(void* p);
 
+/* The camera block aten::PinholeCamera::CreateCameraParam computes (src/libaten/camera/pinhole.cpp:34-75),
+ * for callers that do not link libaten.  Returns 0, or -1 on a null / non-positive argument. */
+int atns_create_camera(atn_camera_param* out, const float origin[3], const float lookat[3], const float up[3],
+                       float vfov, float z_near, float z_far, int32_t width, int32_t height);
+
 /* Sanity walk of a node list: every link in range or -1, pre-order reachability of all leaves.
  * Returns number of leaves reached by following hit links only, or negative on a bad link. */
 int64_t atns_validate_nodes(const atn_bvh_node* nodes, uint32_t count);

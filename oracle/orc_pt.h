@@ -1089,8 +1089,10 @@ inline bool HitImplicitLight(const Scene& ctxt, int32_t hit_obj_id, bool is_back
     if (!attr_emissive(m)) return false;
     if (is_back_facing) return false;
     const auto& obj = ctxt.GetObject(hit_obj_id);
-    const auto& light = ctxt.GetLight(obj.light_id);
-    const v3 light_color = AreaLight_ComputeLightColor(light, hrec.area);
+    // the reference indexes lights[light_id] unchecked (UB for an emissive surface that is no registered light);
+    // both sides of the parity test define that case as "emits nothing"
+    const bool is_light = obj.light_id >= 0 && obj.light_id < ctxt.GetLightNum();
+    const v3 light_color = is_light ? AreaLight_ComputeLightColor(ctxt.GetLight(obj.light_id), hrec.area) : v3(0.0f);
     float weight = 1.0f;
     if (bounce > 0) {
         float cosLight = dot(hrec.normal, -ray.dir);

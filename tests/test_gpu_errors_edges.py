@@ -89,6 +89,45 @@ def test_corrupted_bvh_is_rejected(orc, cornell):
             lists[0]["f2"][leaf] = np.int32(99).view(np.float32)
         with pytest.raises(AtenAmdError, match="missing BLAS"):
             g.UpdateSceneData(broken(bad_blas))
+
+        def backward_miss(lists):
+            inner = np.nonzero((lists[1]["f0"] < 0) & (lists[1]["f1"] < 0))[0]
+            lists[1]["miss"][inner[inner > 0][0]] = 0.0     # in range, reachable -- and an endless walk for every ray that misses it
+        with pytest.raises(AtenAmdError, match="backward"):
+            g.UpdateSceneData(broken(backward_miss))
+
+        def backward_leaf(lists):
+            leaf = np.nonzero(lists[1]["f1"] >= 0)[0][-1]
+            lists[1]["hit"][leaf] = lists[1]["miss"][leaf] = 0.0
+        with pytest.raises(AtenAmdError, match="backward|cycle"):
+            g.UpdateSceneData(broken(backward_leaf))
+
+        def backward_tlas(lists):
+            leaf = np.nonzero(lists[0]["f2"] >= 0)[0][-1]
+            lists[0]["miss"][leaf] = 0.0
+        with pytest.raises(AtenAmdError, match="backward"):
+            g.UpdateSceneData(broken(backward_tlas))
+
+        def broken_array(name, edit):
+            b = broken(lambda lists: None)
+            arr = fs.arrays[name].copy()
+            edit(arr)
+            b.arrays[name] = arr
+            b.keep.append(arr)
+            setattr(b.desc, name, arr.ctypes.data)
+            return b
+        def bad_vertex(t): t["idx"][3][1] = len(fs.arrays["vtx_pos"]) + 7
+        with pytest.raises(AtenAmdError, match="vertex index out of range"):
+            g.UpdateSceneData(broken_array("triangles", bad_vertex))
+        def bad_mtrl(t): t["mtrlid"][0] = 1000
+        with pytest.raises(AtenAmdError, match="material id out of range"):
+            g.UpdateSceneData(broken_array("triangles", bad_mtrl))
+        def bad_light_obj(l): l["arealight_objid"][0] = 12345
+        with pytest.raises(AtenAmdError, match="light refers to an object"):
+            g.UpdateSceneData(broken_array("lights", bad_light_obj))
+        def bad_obj_light(o): o["light_id"][0] = 77
+        with pytest.raises(AtenAmdError, match="light id out of range"):
+            g.UpdateSceneData(broken_array("objects", bad_obj_light))
         g.UpdateSceneData(fs)               # a good scene still uploads afterwards
     finally:
         g.close()

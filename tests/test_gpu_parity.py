@@ -49,7 +49,8 @@ def test_cmj_bit_exact(gpu, orc, golden):
 
 
 def test_compaction_kat(gpu):
-    """flags from the self-test in src/libidaten/kernel/StreamCompaction.cu:325, then ragged / empty / large."""
+    """flags from the self-test in src/libidaten/kernel/StreamCompaction.cu:325, then ragged / empty / large.
+    atn_compact = the renderer's own block_append2 (kernels.hpp) + a host sort."""
     f = np.array([3, 1, 7, 0, 4, 1, 6, 3], np.int32)
     assert np.array_equal(gpu.compact(f), [0, 1, 2, 4, 5, 6, 7])
     assert len(gpu.compact(np.zeros(0, np.int32))) == 0
@@ -58,6 +59,46 @@ def test_compaction_kat(gpu):
     for n in (1, 63, 64, 65, 1000, 100003):
         f = (rng.random(n) < 0.37).astype(np.int32)
         assert np.array_equal(gpu.compact(f), np.flatnonzero(f > 0))
+
+
+def _check_two_queues(gpu, fa, fb, grid_blocks=0):
+    qa, qb = gpu.compact2(fa, fb, grid_blocks)
+    # every flagged entry exactly once, nothing else, in whatever order the device produced
+    assert np.array_equal(np.sort(qa), np.flatnonzero(np.asarray(fa) > 0))
+    if fb is not None:
+        assert np.array_equal(np.sort(qb), np.flatnonzero(np.asarray(fb) > 0))
+
+
+def test_product_queue_append_adversarial_patterns(gpu):
+    """block_append2 as k_shade calls it (two queues, kChunkItems x 256 entries per block and atomic), through
+    atn_compact2: all-zero waves, a single lane, ragged last chunk, both queues at once, overlapping and disjoint
+    flags, grid-stride with fewer blocks than chunks.  Contract: idaten::StreamCompaction::compact
+    (StreamCompaction.cu:175-316) up to order."""
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4097, 10 * 1024 + 1, 300007):
+        z = np.zeros(n, np.int32)
+        one = np.ones(n, np.int32)
+        _check_two_queues(gpu, z, z)                    # nothing anywhere: no atomic may fire
+        _check_two_queues(gpu, one, z)                  # queue A full, queue B empty
+        _check_two_queues(gpu, z, one)
+        _check_two_queues(gpu, one, one)
+        _check_two_queues(gpu, one, None)               # single-queue form (k_gen_path's call)
+        single = z.copy(); single[n - 1] = 5
+        _check_two_queues(gpu, single, z)               # one lane of the last (ragged) wave
+        single0 = z.copy(); single0[0] = 1
+        _check_two_queues(gpu, single0, single)
+        # whole waves empty, then one lane per wave, then alternating waves
+        lane = (np.arange(n) % 64 == 17).astype(np.int32)
+        waves = ((np.arange(n) // 64) % 2 == 0).astype(np.int32)
+        _check_two_queues(gpu, lane, waves)
+        _check_two_queues(gpu, waves, 1 - waves)        # disjoint queues
+        for p in (0.01, 0.5, 0.97):
+            fa = (rng.random(n) < p).astype(np.int32) * rng.integers(1, 9, n).astype(np.int32)
+            fb = (rng.random(n) < 1 - p).astype(np.int32)
+            fa[rng.integers(0, n)] = -3                  # negative flags are "not set" (flag > 0)
+            _check_two_queues(gpu, fa, fb)
+            _check_two_queues(gpu, fa, fb, grid_blocks=1)       # one block walks every chunk
+            _check_two_queues(gpu, fa, fb, grid_blocks=3)
 
 
 def test_generate_paths_bit_exact(gpu, orc, cornell, golden):

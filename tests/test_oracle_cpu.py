@@ -240,3 +240,23 @@ def test_bvh_builder_contract(cornell):
         assert np.all(nodes["hit"][inner] == np.arange(n)[inner] + 1)       # pre-order
         assert np.all(nodes["hit"][leaf] == nodes["miss"][leaf])
         assert np.all(nodes["f2"][leaf] == -1.0)
+
+
+def test_product_camera_block_equals_oracle(orc):
+    """aten_amd.scene.camera.create_camera (host library, csrc/host/camera.cpp) against the oracle's restatement of
+    PinholeCamera::CreateCameraParam (camera/pinhole.cpp:34-75): byte-equal blocks, so bench / smoke / scene code
+    need nothing from oracle/.  The oracle side is pinned by the reference's camera_test known answer."""
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.camera import create_camera
+    cams = [scenedefs.cornell_box()[1], scenedefs.sponza_lod()[1],
+            dict(pos=(1.5, -2.25, 7.0), at=(-0.3, 0.8, 0.1), vfov=33.3),
+            dict(pos=(0, 10, 0.001), at=(0, 0, 0), vfov=90.0)]
+    for cam in cams:
+        for w, h in ((1280, 720), (1920, 1080), (3840, 2160), (100, 52), (1, 1)):
+            a = create_camera(cam["pos"], cam["at"], cam["vfov"], w, h)
+            b = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], w, h)
+            assert a.tobytes() == b.tobytes(), (cam, w, h)
+    a = create_camera((0, 0, 1), (0, 0, 0), 60.0, 640, 480, up=(0, 0, 1) if False else (0, 1, 0), znear=5.0, zfar=0.5)
+    assert float(a["znear"]) == 0.5 and float(a["zfar"]) == 5.0         # min / max swap of pinhole.cpp:70-71
+    with pytest.raises(ValueError):
+        create_camera((0, 0, 1), (0, 0, 0), 60.0, 0, 480)

@@ -23,6 +23,10 @@ SYMBOLS = [
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples",
     "atn_material_table", "atn_compact", "atn_compact2", "atn_sizeof_scene_desc", "atn_sizeof_destination",
     "atn_abi_version",
+    "atn_mgpu_create", "atn_mgpu_destroy", "atn_mgpu_last_error", "atn_mgpu_shard_count", "atn_mgpu_shard_device",
+    "atn_mgpu_upload_scene", "atn_mgpu_update_tlas", "atn_mgpu_update_camera", "atn_mgpu_init_sampler",
+    "atn_mgpu_set_random", "atn_mgpu_render", "atn_mgpu_reset", "atn_mgpu_synchronize", "atn_mgpu_film_device",
+    "atn_mgpu_download_film",
 ]
 
 
@@ -81,6 +85,21 @@ def lib():
         l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
         l.atn_compact.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         l.atn_compact2.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]
+        l.atn_mgpu_create.argtypes = [C.POINTER(vp), vp, C.c_int32]
+        l.atn_mgpu_destroy.argtypes = [vp]; l.atn_mgpu_destroy.restype = None
+        l.atn_mgpu_last_error.argtypes = [vp]; l.atn_mgpu_last_error.restype = C.c_char_p
+        l.atn_mgpu_shard_count.argtypes = [vp]; l.atn_mgpu_shard_count.restype = C.c_int32
+        l.atn_mgpu_shard_device.argtypes = [vp, C.c_int32]; l.atn_mgpu_shard_device.restype = C.c_int32
+        l.atn_mgpu_upload_scene.argtypes = [vp, vp]
+        l.atn_mgpu_update_tlas.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
+        l.atn_mgpu_update_camera.argtypes = [vp, vp]
+        l.atn_mgpu_init_sampler.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+        l.atn_mgpu_set_random.argtypes = [vp, vp, C.c_uint32]
+        l.atn_mgpu_render.argtypes = [vp, C.POINTER(Destination), vp]
+        l.atn_mgpu_reset.argtypes = [vp]
+        l.atn_mgpu_synchronize.argtypes = [vp]
+        l.atn_mgpu_film_device.argtypes = [vp]; l.atn_mgpu_film_device.restype = vp
+        l.atn_mgpu_download_film.argtypes = [vp, vp]
         for n in ("atn_sizeof_scene_desc", "atn_sizeof_destination", "atn_abi_version"):
             getattr(l, n).restype = C.c_uint32
         _lib = l

@@ -62,6 +62,7 @@ public:
     // batches' kernels fill the machine meanwhile.  Measured (sponza_lod 1080p): 6.83 -> 6.58 ms
     // on the whole frame, 4.35 -> 3.71 ms on half of it (the 2-GPU shard), no gain below ~200 K paths per batch.
     static constexpr int kMaxBatches = 8;
+    static constexpr int kMaxShards = 64;       // screen shards of one node (atn_mgpu_*)
     hipStream_t bstream[kMaxBatches] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {};
     int n_batches = 3;
@@ -748,7 +749,10 @@ public:
 
 } // namespace atn
 
+#include "host/mgpu.hpp"
+
 struct atn_ctx { atn::PathTracing r; };
+struct atn_mgpu { atn::MultiGpu m; };
 
 using atn::PathTracing;
 
@@ -768,6 +772,15 @@ static int guarded(atn_ctx* ctx, F&& f) noexcept
     catch (...) { return ATN_ERR_INVALID_ARG; }
 }
 #define C_HIP(r, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (r).fail(ATN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+#define MG_OR_FAIL(mg) do { if (!(mg)) return ATN_ERR_INVALID_ARG; } while (0)
+template <class F>
+static int mg_guarded(atn_mgpu* mg, F&& f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { try { return mg->m.fail(ATN_ERR_OUT_OF_MEMORY, "out of host memory"); } catch (...) { return ATN_ERR_OUT_OF_MEMORY; } }
+    catch (...) { return ATN_ERR_INVALID_ARG; }
+}
 
 extern "C" {
 
@@ -939,6 +952,84 @@ int atn_reset_kernel_times(atn_ctx* ctx)
     C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
     ctx->r.prof_collect();
     for (int i = 0; i < ATN_K_COUNT; i++) { ctx->r.k_ms[i] = 0; ctx->r.k_launches[i] = 0; }
+    return ATN_OK;
+}
+
+// ---------------------------------------------------------------- one node, every GPU (host/mgpu.hpp)
+int atn_mgpu_create(atn_mgpu** out, const int32_t* devices, int32_t n_devices)
+{
+    if (!out) return ATN_ERR_INVALID_ARG;
+    *out = nullptr;
+    atn_mgpu* mg = new (std::nothrow) atn_mgpu();
+    if (!mg) return ATN_ERR_OUT_OF_MEMORY;
+    int rc = mg_guarded(mg, [&] { return mg->m.init(devices, n_devices); });
+    if (rc != ATN_OK) {
+        std::fprintf(stderr, "atn_mgpu_create: %s\n", mg->m.last_error.c_str());
+        delete mg;
+        return rc;
+    }
+    *out = mg;
+    return ATN_OK;
+}
+void atn_mgpu_destroy(atn_mgpu* mg) { delete mg; }
+const char* atn_mgpu_last_error(atn_mgpu* mg) { return mg ? mg->m.last_error.c_str() : "null context"; }
+int32_t atn_mgpu_shard_count(atn_mgpu* mg) { return mg ? mg->m.n : 0; }
+int32_t atn_mgpu_shard_device(atn_mgpu* mg, int32_t i) { return (mg && i >= 0 && i < mg->m.n) ? mg->m.shard[i]->device : -1; }
+
+int atn_mgpu_upload_scene(atn_mgpu* mg, const atn_scene_desc* scene)
+{
+    MG_OR_FAIL(mg);
+    if (!scene) return mg->m.fail(ATN_ERR_INVALID_ARG, "null scene");
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->UpdateSceneData(scene); }); });
+}
+int atn_mgpu_update_tlas(atn_mgpu* mg, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
+                         const atn_bvh_node* top_nodes, uint32_t n_top_nodes)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); }); });
+}
+int atn_mgpu_update_camera(atn_mgpu* mg, const atn_camera_param* camera)
+{
+    MG_OR_FAIL(mg);
+    for (auto& s : mg->m.shard) { int rc = s->updateCamera(camera); if (rc) return mg->m.fail(rc, s->last_error); }
+    return ATN_OK;
+}
+int atn_mgpu_init_sampler(atn_mgpu* mg, int32_t w, int32_t h, int32_t seed)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&]() -> int {
+        if (w <= 0 || h <= 0) return mg->m.fail(ATN_ERR_INVALID_ARG, "bad sampler size");
+        std::vector<uint32_t> v((size_t)w * h);         // one mt19937 pass, shared by every shard (seeds are global)
+        std::mt19937 src(seed);
+        for (auto& x : v) x = (uint32_t)src();
+        return mg->m.on_all([&](int i) { return mg->m.shard[i]->setRandom(v.data(), (uint32_t)v.size()); });
+    });
+}
+int atn_mgpu_set_random(atn_mgpu* mg, const uint32_t* seeds, uint32_t n)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->setRandom(seeds, n); }); });
+}
+int atn_mgpu_render(atn_mgpu* mg, const atn_destination* dst, atn_vec4* out_host)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.render(dst, out_host); });
+}
+int atn_mgpu_reset(atn_mgpu* mg)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->reset(); }); });
+}
+int atn_mgpu_synchronize(atn_mgpu* mg) { MG_OR_FAIL(mg); return mg_guarded(mg, [&] { return mg->m.synchronize(); }); }
+void* atn_mgpu_film_device(atn_mgpu* mg) { return mg ? (void*)mg->m.full.p : nullptr; }
+int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host)
+{
+    MG_OR_FAIL(mg);
+    atn::MultiGpu& m = mg->m;
+    if (!out_host || !m.full.p || m.width <= 0) return m.fail(ATN_ERR_INVALID_ARG, "atn_mgpu_download_film: nothing rendered yet");
+    if (hipSetDevice(m.shard[0]->device) != hipSuccess
+        || hipMemcpyAsync(out_host, m.full.p, (size_t)m.width * m.height * sizeof(float4), hipMemcpyDeviceToHost, m.comm) != hipSuccess
+        || hipStreamSynchronize(m.comm) != hipSuccess) return m.fail(ATN_ERR_HIP, "film download failed");
     return ATN_OK;
 }
 

@@ -220,3 +220,80 @@ class PathTracing:
                                          oa.ctypes.data, C.byref(ca), ob.ctypes.data if fb is not None else None,
                                          C.byref(cb) if fb is not None else None))
         return oa[:ca.value], (ob[:cb.value] if fb is not None else None)
+
+
+class MultiGpuPathTracing:
+    """The node-wide renderer (atn_mgpu_*, include/aten_amd.h): same calls as PathTracing, every visible GPU
+    (or the given shard list; an ordinal may repeat) behind them."""
+
+    def __init__(self, devices=None):
+        self._l = lib()
+        self._mg = C.c_void_p()
+        if devices is None:
+            rc = self._l.atn_mgpu_create(C.byref(self._mg), None, 0)
+        elif isinstance(devices, int):
+            rc = self._l.atn_mgpu_create(C.byref(self._mg), None, devices)
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self._l.atn_mgpu_create(C.byref(self._mg), arr, len(devices))
+        if rc != 0:
+            raise AtenAmdError("atn_mgpu_create failed (%d)" % rc)
+        self.width = self.height = 0
+
+    def close(self):
+        if self._mg:
+            self._l.atn_mgpu_destroy(self._mg)
+            self._mg = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AtenAmdError("%s (status %d)" % (self._l.atn_mgpu_last_error(self._mg).decode(), rc))
+
+    def shard_count(self):
+        return int(self._l.atn_mgpu_shard_count(self._mg))
+
+    def shard_devices(self):
+        return [int(self._l.atn_mgpu_shard_device(self._mg, i)) for i in range(self.shard_count())]
+
+    def UpdateSceneData(self, scene):
+        self._check(self._l.atn_mgpu_upload_scene(self._mg, C.cast(scene.ref(), C.c_void_p)))
+
+    def updateBVH(self, scene):
+        a = scene.arrays
+        objs = np.ascontiguousarray(a["objects"]); mtx = np.ascontiguousarray(a["matrices"]); top = np.ascontiguousarray(a["bvh_lists"][0])
+        self._check(self._l.atn_mgpu_update_tlas(self._mg, objs.ctypes.data, len(objs), mtx.ctypes.data if len(mtx) else None,
+                                                 len(mtx), top.ctypes.data, len(top)))
+
+    def updateCamera(self, cam):
+        self._check(self._l.atn_mgpu_update_camera(self._mg, cam.ctypes.data))
+
+    def initSampler(self, width, height, seed=0):
+        self._check(self._l.atn_mgpu_init_sampler(self._mg, width, height, seed))
+
+    def render(self, width, height, max_depth=5, rr_depth=3, spp=1, frame=0, progressive=True,
+               break_on_terminate=True, download=True):
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, int(progressive), int(break_on_terminate), 0, 0)
+        out = np.empty((height, width, 4), np.float32) if download else None
+        self._check(self._l.atn_mgpu_render(self._mg, C.byref(d), out.ctypes.data if download else None))
+        self.width, self.height = width, height
+        return out
+
+    def reset(self):
+        self._check(self._l.atn_mgpu_reset(self._mg))
+
+    def synchronize(self):
+        self._check(self._l.atn_mgpu_synchronize(self._mg))
+
+    def film_device_ptr(self):
+        return self._l.atn_mgpu_film_device(self._mg)
+
+    def download_film(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._l.atn_mgpu_download_film(self._mg, out.ctypes.data))
+        return out

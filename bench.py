@@ -73,6 +73,44 @@ def usable_cpus():
     return n
 
 
+def main_mgpu(args):
+    """One process drives every GPU through atn_mgpu_* (no torch.distributed): the path a C++ aten application takes."""
+    import torch
+    from aten_amd.renderer import MultiGpuPathTracing
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.camera import create_camera
+    W, H, spp, depth, rr = args.width, args.height, args.spp, args.depth, 3
+    fs, cam = {"sponza": scenedefs.sponza_lod, "atrium": scenedefs.atrium, "cornell": scenedefs.cornell_box}[args.scene]()
+    n_shards = args.shards or args.gpus
+    devices = [i % args.gpus for i in range(n_shards)]
+    m = MultiGpuPathTracing(devices)
+    m.UpdateSceneData(fs)
+    m.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], W, H))
+    m.initSampler(W, H, 0)
+    brk = not args.all_samples
+    for i in range(args.warmup):
+        m.render(W, H, depth, rr, spp=spp, frame=i, break_on_terminate=brk, download=False)
+    m.reset()
+    m.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        m.render(W, H, depth, rr, spp=spp, frame=i, break_on_terminate=brk, download=False)
+    m.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if args.dump:
+        np.save(args.dump, m.download_film())
+    print(json.dumps({
+        "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition)", "value": round(W * H * spp / 1e6 / (elapsed / args.steps), 3),
+        "unit": "Mrays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d %dspp %d-bounce" % (args.scene, W, H, spp, depth), "shards": n_shards, "devices": m.shard_devices(),
+                   "sharding": "8x8 screen tiles, tile %% %d, one process, atn_mgpu_render: peer-copy gather into GPU 0" % n_shards}}))
+    m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +131,10 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
+    ap.add_argument("--mgpu", action="store_true",
+                    help="one process, every GPU behind the C-ABI (atn_mgpu_*: worker thread per GPU, peer-copy gather into "
+                         "GPU 0) instead of one process per GPU + RCCL all_gather")
+    ap.add_argument("--shards", type=int, default=0, help="with --mgpu: shard count when it differs from --gpus (shards then share GPUs)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -103,13 +145,23 @@ def main():
     elif args.config == "c5":
         args.svgf = True
 
+    if args.gpus > 1 and not args.mgpu and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher the contract describes (one rank per GPU)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.mgpu:
+        return main_mgpu(args)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
     dist = None
     use_dist = world > 1 or args.force_gather

@@ -128,6 +128,41 @@ int atn_reset_kernel_times(atn_ctx* ctx);
  * isolated kernel need). */
 int atn_set_path_batches(atn_ctx* ctx, int32_t n);
 
+/* ---- one node, every GPU ------------------------------------------------------------------------
+ * The reference renderer is single-device (idaten::Renderer, src/libidaten/kernel/renderer.h:17-179; its caller
+ * src/device_renderer/main.cpp:133-149,196-204 makes one UpdateSceneData and one render(dst) per frame).  An
+ * atn_mgpu keeps exactly that call shape and spreads the frame over the node: one context + one host worker thread
+ * per shard, the scene replicated, the screen cut into 8x8-pixel tiles (tile t -> shard t % N, seeds and pixel indices
+ * global, so the image does not depend on N), and per frame ONE exchange: every shard pushes its tile buffer to
+ * shard 0's device with a peer copy over xGMI and shard 0 scatters them into the full frame.  The film of frame f is
+ * assembled while frame f + 1 renders (two gather buffers, events both ways).
+ *
+ * devices: HIP ordinals of the shards, n_devices entries; NULL = ordinals 0 .. n_devices-1, and NULL with
+ * n_devices <= 0 = every visible device.  An ordinal may repeat (shards sharing a GPU): with that the whole N > 1 path
+ * runs on a one-GPU machine.  All calls return 0 or a negative atn_status; none throws. */
+typedef struct atn_mgpu atn_mgpu;
+int atn_mgpu_create(atn_mgpu** out, const int32_t* devices, int32_t n_devices);
+void atn_mgpu_destroy(atn_mgpu* mg);
+const char* atn_mgpu_last_error(atn_mgpu* mg);
+int32_t atn_mgpu_shard_count(atn_mgpu* mg);
+int32_t atn_mgpu_shard_device(atn_mgpu* mg, int32_t shard);
+/* ≙ UpdateSceneData / updateBVH / updateCamera / initSampler on every shard (uploads run in parallel). */
+int atn_mgpu_upload_scene(atn_mgpu* mg, const atn_scene_desc* scene);
+int atn_mgpu_update_tlas(atn_mgpu* mg, const atn_object_param* objects, uint32_t n_objects,
+                         const atn_mat4* matrices, uint32_t n_matrices,
+                         const atn_bvh_node* top_nodes, uint32_t n_top_nodes);
+int atn_mgpu_update_camera(atn_mgpu* mg, const atn_camera_param* camera);
+int atn_mgpu_init_sampler(atn_mgpu* mg, int32_t width, int32_t height, int32_t seed);
+int atn_mgpu_set_random(atn_mgpu* mg, const uint32_t* seeds, uint32_t n);
+/* ≙ idaten::PathTracing::render for the whole node.  out_host NULL: returns when the frame is enqueued; the
+ * assembled film (float4[w*h], row 0 = bottom) is atn_mgpu_film_device on shard 0's device, complete after
+ * atn_mgpu_synchronize.  out_host != NULL: returns with the frame in host memory. */
+int atn_mgpu_render(atn_mgpu* mg, const atn_destination* dst, atn_vec4* out_host);
+int atn_mgpu_reset(atn_mgpu* mg);
+int atn_mgpu_synchronize(atn_mgpu* mg);
+void* atn_mgpu_film_device(atn_mgpu* mg);
+int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host);
+
 /* ---- SVGF (next tier, BASELINE config 5) -------------------------------------------------------
  * ≙ aten::SVGFRenderer (src/libaten/renderer/svgf/svgf.{h,cpp}): the path pass with AOV outputs
  * (SVGFRenderer::Shade / ShadeMiss with AOV spans) followed by the svgf_impl.h passes as HIP kernels --

@@ -90,15 +90,17 @@ def test_corrupted_bvh_is_rejected(orc, cornell):
         with pytest.raises(AtenAmdError, match="missing BLAS"):
             g.UpdateSceneData(broken(bad_blas))
 
+        big = max(range(1, len(fs.arrays["bvh_lists"])), key=lambda k: len(fs.arrays["bvh_lists"][k]))
+
         def backward_miss(lists):
-            inner = np.nonzero((lists[1]["f0"] < 0) & (lists[1]["f1"] < 0))[0]
-            lists[1]["miss"][inner[inner > 0][0]] = 0.0     # in range, reachable -- and an endless walk for every ray that misses it
+            inner = np.nonzero((lists[big]["f0"] < 0) & (lists[big]["f1"] < 0))[0]
+            lists[big]["miss"][inner[inner > 0][0]] = 0.0   # in range, reachable -- and an endless walk for every ray that misses it
         with pytest.raises(AtenAmdError, match="backward"):
             g.UpdateSceneData(broken(backward_miss))
 
         def backward_leaf(lists):
-            leaf = np.nonzero(lists[1]["f1"] >= 0)[0][-1]
-            lists[1]["hit"][leaf] = lists[1]["miss"][leaf] = 0.0
+            leaf = np.nonzero(lists[big]["f1"] >= 0)[0][-1]
+            lists[big]["hit"][leaf] = lists[big]["miss"][leaf] = 0.0
         with pytest.raises(AtenAmdError, match="backward|cycle"):
             g.UpdateSceneData(broken(backward_leaf))
 

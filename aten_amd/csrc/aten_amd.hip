@@ -479,8 +479,15 @@ public:
                     for (int32_t b = 0; b <= d->maxDepth; b++) {
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
                         prof_begin(prof, ATN_K_TRACE_FUSED, st);
-                        if (use_refill) hipLaunchKernelGGL((k_trace_fused<true>), dim3(g_fused), dim3(kTraceBlock), 0, st, pb, scene, bs, bc, b);
-                        else hipLaunchKernelGGL((k_trace_fused<false>), dim3(g_fused * (kTraceBlock / simple_block)), dim3(simple_block), 0, st, pb, scene, bs, bc, b);
+                        const dim3 gr(use_refill ? g_fused : g_fused * (kTraceBlock / simple_block)), tb(use_refill ? (uint32_t)kTraceBlock : simple_block);
+                        if (use_refill) {
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                        }
+                        else {
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                        }
                         prof_end(prof);
                         if (b < d->maxDepth) {
                             prof_begin(prof, ATN_K_SHADE, st);

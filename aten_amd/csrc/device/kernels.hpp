@@ -472,6 +472,9 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 // HitShadowRay -> HitTestToTargetLight -> scene::hitLight
 // (pathtracing_impl.h:266-393, scene/scene.h:64-134): closest hit toward the light, visible iff
 // the hit object IS the light object (or nothing is hit / infinite / singular rules).
+// ALPHA = false compiles the alpha-translucency rule out: chosen by the host when no uploaded material can have
+// alpha < 1 (DevScene::any_alpha == 0), which takes evaluate_hit + a texture fetch -- and their registers -- out of the walk.
+template <bool ALPHA>
 struct ShadowJob {
     PathBuffers pb;
     DevScene sc;
@@ -508,7 +511,7 @@ struct ShadowJob {
         else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
         else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
         else visible = false;
-        if (sc.any_alpha && isHit && visible) {
+        if (ALPHA && sc.any_alpha && isHit && visible) {
             // (every other hit already means "not visible", whatever its alpha; and a walk that stopped early --
             // ShadowJob::fetch -- is never `visible`, so `h` is the exact closest hit here)
             // material::isTranslucentByAlpha hit (material.cpp:193-210): "ignored", and with a lookup budget of one
@@ -535,7 +538,7 @@ template <bool COUNT, bool REFILL>
 __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
 {
     const uint32_t count = pb.sh_count[bounce];
-    const ShadowJob job{ pb, sc, kEps };
+    const ShadowJob<true> job{ pb, sc, kEps };
     TravCounters tc; tc.nodes = 0; tc.tris = 0;
     trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_shadow[bounce], job, &tc);
     if (COUNT) {
@@ -550,8 +553,9 @@ __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(P
 // longest ray), so a frame pays it depth + 1 times instead of 2 * depth times, and each launch has twice the rays to
 // fill the machine with.  The two job kinds touch disjoint state (shadow: contrib; closest: isect).  bs < 0 or
 // bc < 0 = that half is absent (first / last launch of a sample).
+template <bool ALPHA>
 struct FusedJob {
-    ShadowJob s;
+    ShadowJob<ALPHA> s;
     ClosestJob c;
     uint32_t n_shadow;
     float t_min;
@@ -572,12 +576,12 @@ struct FusedJob {
     }
 };
 
-template <bool REFILL>
+template <bool REFILL, bool ALPHA>
 __global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
-    const FusedJob job{ ShadowJob{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
+    const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
     TravCounters tc; tc.nodes = 0; tc.tris = 0;
     trace_dispatch<false, REFILL>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }

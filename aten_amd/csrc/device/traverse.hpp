@@ -199,7 +199,54 @@ constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
 #endif
 constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
 constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
+#ifndef ATN_LEAF_CADENCE
+#define ATN_LEAF_CADENCE 3
+#endif
+constexpr uint32_t kLeafCadence = ATN_LEAF_CADENCE;
 struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk]; };   // 18 KB
+
+// One Moeller-Trumbore test against a triangle-leaf record (q0, q1, q2) -- intersectTriangle (math/intersect.h:45-90) +
+// triangle::hit (geometry/triangle.h:40-67) + the traverser's acceptance (threaded_bvh_traverser.h:236-262).
+// Returns triangle::hit's result; `accept` = the hit became the ray's closest one.
+ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, const float4& q2, float t_min,
+                       Hit& hit, float& t_max, int32_t objid, int32_t meshid, bool& accept, float& t_out)
+{
+    const f3 e1 = mk3(q1), e2 = mk3(q2);
+    const f3 r = ray.org - mk3(q0);
+    const f3 u = cross(ray.dir, e2);
+    const f3 v = cross(r, e1);
+    const float inv = 1.0F / dot(u, e1);
+    const float t = dot(v, e2) * inv;
+    const float beta = dot(u, r) * inv;
+    const float gamma = dot(v, ray.dir) * inv;
+    const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
+        && (beta + gamma <= 1.0F) && t >= 0.0F);
+    const bool is_hit = isect && (t < kInf);
+    accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
+    if (accept) {
+        hit.t = t; hit.a = beta; hit.b = gamma;
+        hit.objid = objid; hit.tri = __float_as_int(q0.w); hit.meshid = meshid;
+        t_max = t;
+    }
+    t_out = t;
+    return is_hit;
+}
+
+// The persistent walk.  One wave iteration = refill, then a BURST of kInnerBurst inner-node steps in a tight loop (two
+// 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a
+// triangle leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.
+// Why: at any moment only ~7 of 64 lanes stand on a leaf (one visit in nine), so a loop that offers every node kind
+// on every iteration issues the ~75-instruction triangle block each time for a handful of lanes, and drags the
+// refill / leave / finish bookkeeping (~60 scalar instructions) through every inner-node step.  Here a lane that
+// reaches a leaf waits, masked off, for the end of the burst (<= kInnerBurst - 1 steps), the triangle block runs once
+// per burst with several times the lanes, and the inner-node step is ~30 VALU + ~10 SALU.
+// The slab test takes ONE of its two forms per wave: the hardware min/max form when every live lane's slab constants
+// are finite (a wave-uniform flag, refreshed only where rays change), the select form -- valid for all inputs --
+// otherwise.  A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
+#ifndef ATN_INNER_BURST
+#define ATN_INNER_BURST 4
+#endif
+constexpr int kInnerBurst = ATN_INNER_BURST;
 
 template <bool COUNT, class Job>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
@@ -217,6 +264,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     bool first_chunk = true;            // wave-uniform
+    bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
 
     uint32_t payload = 0;
     float t_max = 0.0F, stop_t = -kInf;
@@ -225,9 +273,10 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     ray = wray;
     Hit hit; hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
     int32_t node = kLinkEnd, objid = -1, meshid = -1, top_hit = kLinkEnd, top_miss = kLinkEnd;
-    // a lane is idle <=> node == kLinkEnd
+    // a lane is idle <=> node == kLinkEnd at the top of an iteration
 
     for (;;) {
+        // ---- refill
         const unsigned long long m_idle = __ballot(node == kLinkEnd);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle >= kRefillLanes) {
@@ -278,49 +327,49 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     }
                 }
                 c_next += n_idle < avail ? n_idle : avail;
+                all_finite = __all(node == kLinkEnd || ray.finite) != 0;
             }
             else if (n_idle == 64u) {
                 break;          // drained, chunk empty, nothing in flight
             }
         }
 
-        const bool step = node != kLinkEnd;
-        if (step) {
+        // ---- burst of inner-node steps (dead leaves are typed inner, tag kTagDead).  kLinkEnd has both type bits set,
+        // so `(node & 3) == 0` alone selects the live lanes on inner nodes.  An inner node's hit link is the next
+        // record and never kLinkEnd (checked at upload): a list that ends here ended on a MISS link.
+        const bool live = node != kLinkEnd;
+#pragma unroll 1
+        for (int k = 0; k < kInnerBurst; k++) {
+            if (!(node & kLinkTypeMask)) {
+                const uint32_t off = (uint32_t)node;        // type bits are 0: the link is the byte offset
+                const float4 q0 = ld16(nb, off);
+                const float4 q1 = ld16(nb, off + 16u);
+                if (COUNT) cnt->nodes++;
+                bool box;
+                if (all_finite) box = slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max);
+                else box = slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
+                const int32_t tag = __float_as_int(q0.w);
+                node = (box && tag != kTagDead) ? ((int32_t)(off + kNodeBytes) | tag) : __float_as_int(q1.w);  // hit link = next record, typed by the tag
+            }
+        }
+        bool ended = live && node == kLinkEnd;      // this lane's walk left a list in this iteration ...
+        bool is_hit = false;                        // ... and this was the result of its last step
+
+        // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
+        const bool at_tlas = node != kLinkEnd && (node & kLinkTypeMask) == kLinkTlasBit;
+        if (node != kLinkEnd && (node & kLinkTypeMask)) {
             const uint32_t off = (uint32_t)node & kLinkOffsetMask;
             const float4 q0 = ld16(nb, off);
             const float4 q1 = ld16(nb, off + 16u);
             if (COUNT) cnt->nodes++;
-            bool is_hit;
-            if (!(node & kLinkTypeMask)) {
-                is_hit = ray.finite ? slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max)
-                                    : slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
-                const int32_t tag = __float_as_int(q0.w);
-                const int32_t hit_link = (int32_t)(off + kNodeBytes) | tag;
-                node = (is_hit && tag != kTagDead) ? hit_link : __float_as_int(q1.w);
-                is_hit = is_hit && tag != kTagDead;
-            }
-            else if (node & kLinkLeafBit) {
+            if (node & kLinkLeafBit) {
                 const float4 q2 = ld16(nb, off + 32u);
                 if (COUNT) cnt->tris++;
-                const f3 e1 = mk3(q1), e2 = mk3(q2);
-                const f3 r = ray.org - mk3(q0);
-                const f3 u = cross(ray.dir, e2);
-                const f3 v = cross(r, e1);
-                const float inv = 1.0F / dot(u, e1);
-                const float t = dot(v, e2) * inv;
-                const float beta = dot(u, r) * inv;
-                const float gamma = dot(v, ray.dir) * inv;
-                const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
-                    && (beta + gamma <= 1.0F) && t >= 0.0F);
-                is_hit = isect && (t < kInf);
-                const bool accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
-                if (accept) {
-                    hit.t = t; hit.a = beta; hit.b = gamma;
-                    hit.objid = objid; hit.tri = __float_as_int(q0.w); hit.meshid = meshid;
-                    t_max = t;
-                }
-                node = __float_as_int(q1.w);
-                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }
+                bool accept; float t;
+                is_hit = leaf_test(ray, q0, q1, q2, t_min, hit, t_max, objid, meshid, accept, t);
+                node = __float_as_int(q1.w);        // leaf: hit link == miss link
+                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }    // see Job::fetch
+                ended = node == kLinkEnd;
             }
             else {
                 objid = __float_as_int(q0.x);
@@ -329,6 +378,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 top_hit = __float_as_int(q1.y);
                 top_miss = __float_as_int(q1.z);
                 if (w2l >= 0) {
+                    // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
                     m4 m;
                     m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
                     m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
@@ -340,15 +390,20 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                     ray = wray;
                 }
                 is_hit = true;
-                node = __float_as_int(q0.z);
-            }
-            if (node == kLinkEnd) {
-                node = is_hit ? top_hit : top_miss;
-                top_hit = kLinkEnd; top_miss = kLinkEnd;
-                ray = wray;
-                if (node == kLinkEnd) job.finish(payload, hit, hit.objid >= 0);
+                node = __float_as_int(q0.z);        // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
+                ended = false;
             }
         }
+
+        // ---- a list ended: leave the bottom layer (top_* are kLinkEnd inside the top layer), or finish
+        if (ended) {
+            node = is_hit ? top_hit : top_miss;
+            top_hit = kLinkEnd; top_miss = kLinkEnd;
+            ray = wray;
+            if (node == kLinkEnd) job.finish(payload, hit, hit.objid >= 0);
+        }
+        // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
+        if (__any(ended || at_tlas) || !all_finite) all_finite = __all(node == kLinkEnd || ray.finite) != 0;
     }
 }
 

@@ -68,7 +68,7 @@ public:
     int n_batches = 3;
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
-    uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 256u * 8u;
+    uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
     int env_shade_items = 0, env_flavour = -1;
 
     // scene (HBM-resident after UpdateSceneData)
@@ -82,6 +82,7 @@ public:
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
     uint32_t top_base = 0, n_host_matrices = 0;
+    uint64_t n_bottom_nodes = 0;
     atn_camera_param camera{};
 
     // sampler
@@ -176,9 +177,10 @@ public:
         scene.lights = lights.p; scene.texels = texels.p; scene.textures = textures.p;
         has_scene = true;
         list_root_link = img.list_root_link;
-        top_base = img.list_root[0];
+        top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
+        n_bottom_nodes = img.n_nodes - s->bvh_lists[0].count;
         n_host_matrices = s->n_matrices;
-        tree_is_deep = img.nodes.size() / 3 >= kRefillMinNodes;
+        tree_is_deep = img.n_nodes >= kRefillMinNodes;
         use_refill = tree_is_deep;
         flavour_forced = false;
         if (env_flavour >= 0) { use_refill = env_flavour == 1; flavour_forced = true; }
@@ -193,7 +195,7 @@ public:
         if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
         if (!objs || n_objs == 0 || !top || n_top == 0) return fail(ATN_ERR_INVALID_ARG, "empty object or top-layer array");
         ATN_HIP(hipSetDevice(device));
-        if (((uint64_t)top_base + (uint64_t)n_top) * kNodeBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
+        if ((uint64_t)top_base + (uint64_t)n_top * kInnerBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
         if (n_mtxs && !mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
         {
             std::string rerr;
@@ -201,27 +203,34 @@ public:
             for (uint32_t i = 0; i < n_objs; i++)
                 if (objs[i].light_id >= scene.n_lights) return fail(ATN_ERR_UNSUPPORTED, "object light id out of range");
         }
+        // the new top layer: every top-layer record is kInnerBytes long, laid out in walk order at the image's tail
+        ListLayout lay;
+        std::string err;
+        if (!analyse_list(lay, top, n_top, true, err)) return fail(ATN_ERR_UNSUPPORTED, err);
+        for (uint32_t j = 0; j < lay.order.size(); j++) {
+            if (lay.kind[j] == KIND_TRI) return fail(ATN_ERR_UNSUPPORTED, "triangle leaves in this list need a full scene upload");
+            lay.offset[j] = top_base + j * kInnerBytes;
+        }
         ListEmitCtx c;
         c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
         c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
-        c.top = true;
-        std::vector<float4> rec((size_t)n_top * 3);
-        std::string err;
+        const size_t top_bytes = lay.order.size() * (size_t)kInnerBytes;
+        std::vector<float4> rec(top_bytes / 16 + 1, make_float4(0, 0, 0, 0));
         int32_t root = kLinkEnd;
         uint64_t counts[3] = { 0, 0, 0 };
-        if (!emit_list(rec.data(), top, n_top, top_base, c, root, counts, err)) return fail(ATN_ERR_UNSUPPORTED, err);
-        const size_t need = ((size_t)top_base + n_top) * 3;
+        if (!emit_list(reinterpret_cast<char*>(rec.data()), lay, top, c, root, counts, err, top_base)) return fail(ATN_ERR_UNSUPPORTED, err);
+        const size_t need = ((size_t)top_base + top_bytes + 15) / 16;
         if (need > nodes.n) {
             // grow: keep the bottom-level lists (device-to-device), drop the old top layer
             float4* bigger = nullptr;
             ATN_HIP(hipMalloc((void**)&bigger, need * sizeof(float4)));
-            hipError_t e = hipMemcpyAsync(bigger, nodes.p, (size_t)top_base * 3 * sizeof(float4), hipMemcpyDeviceToDevice, stream);
+            hipError_t e = hipMemcpyAsync(bigger, nodes.p, (size_t)top_base, hipMemcpyDeviceToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) { (void)hipFree(bigger); return fail(ATN_ERR_HIP, hipGetErrorString(e)); }
             nodes.release();
             nodes.p = bigger; nodes.n = need;
         }
-        ATN_HIP(hipMemcpyAsync(nodes.p + (size_t)top_base * 3, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
+        if (top_bytes) ATN_HIP(hipMemcpyAsync(reinterpret_cast<char*>(nodes.p) + top_base, rec.data(), top_bytes, hipMemcpyHostToDevice, stream));
         std::vector<atn_object_param> ov(objs, objs + n_objs);
         ATN_HIP(objects.upload(ov, stream));
         std::vector<float4> mv;
@@ -237,7 +246,7 @@ public:
         list_root_link[0] = root;
         scene.root_link = root;
         scene.nodes = nodes.p; scene.objects = objects.p; scene.matrices = matrices.p;
-        tree_is_deep = (size_t)top_base + n_top >= kRefillMinNodes;
+        tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;
         if (!flavour_forced) use_refill = tree_is_deep;
         return ATN_OK;
     }
@@ -358,25 +367,28 @@ public:
     {
         if (use_refill) {
             // persistent waves pulling kFetchChunk-job chunks: about as many waves as fit on the chip
-            uint32_t blocks = ((n_jobs + atn::kFetchChunk - 1u) / atn::kFetchChunk + 3u) / 4u;
+            const uint32_t waves_per_block = (uint32_t)kTraceBlock / 64u;
+            uint32_t blocks = ((n_jobs + atn::kFetchChunk - 1u) / atn::kFetchChunk + waves_per_block - 1u) / waves_per_block;
             if (blocks < 1u) blocks = 1u;
-            const uint32_t cap = env_trace_blocks;
+            const uint32_t cap = env_trace_blocks ? env_trace_blocks : (256u * 8u * 4u) / waves_per_block;   // 8 waves per SIMD's worth
             return blocks < cap ? blocks : cap;
         }
         return grid_for(n_jobs);
     }
 
+    // the persistent kernels run kTraceBlock threads per block and keep the treelet in dynamic LDS
     template <bool SHADOW>
     void launch_trace(const PathBuffers& pb, uint32_t grid, bool count, int32_t b, hipStream_t stream)
     {
-        const dim3 g(grid), t(kTraceBlock);
+        const dim3 g(grid), t(use_refill ? (uint32_t)kTraceBlock : 256u);
+        const uint32_t lds = use_refill ? scene.treelet_bytes : 0u;
         if (SHADOW) {
-            if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, t, 0, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, t, 0, stream, pb, scene, b); }
-            else { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, t, 0, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, t, 0, stream, pb, scene, b); }
+            if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, t, lds, stream, pb, scene, b); }
+            else { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, t, lds, stream, pb, scene, b); }
         }
         else {
-            if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_closest<true, true>), g, t, 0, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_closest<true, false>), g, t, 0, stream, pb, scene, b); }
-            else { if (use_refill) hipLaunchKernelGGL((k_trace_closest<false, true>), g, t, 0, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_closest<false, false>), g, t, 0, stream, pb, scene, b); }
+            if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_closest<true, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_closest<true, false>), g, t, lds, stream, pb, scene, b); }
+            else { if (use_refill) hipLaunchKernelGGL((k_trace_closest<false, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_closest<false, false>), g, t, lds, stream, pb, scene, b); }
         }
     }
 
@@ -479,14 +491,15 @@ public:
                     for (int32_t b = 0; b <= d->maxDepth; b++) {
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
                         prof_begin(prof, ATN_K_TRACE_FUSED, st);
-                        const dim3 gr(use_refill ? g_fused : g_fused * (kTraceBlock / simple_block)), tb(use_refill ? (uint32_t)kTraceBlock : simple_block);
+                        const dim3 gr(use_refill ? g_fused : g_fused * (256u / simple_block)), tb(use_refill ? (uint32_t)kTraceBlock : simple_block);
+                        const uint32_t lds = use_refill ? scene.treelet_bytes : 0u;
                         if (use_refill) {
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, 0, st, pb, scene, bs, bc, b);
-                            else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }
                         else {
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, 0, st, pb, scene, bs, bc, b);
-                            else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, 0, st, pb, scene, bs, bc, b);
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }
                         prof_end(prof);
                         if (b < d->maxDepth) {
@@ -1084,15 +1097,16 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
         // the probe exercises the walk the scene's tree calls for (or the forced one), whatever n is
         const bool probe_refill = r.flavour_forced ? r.use_refill : r.tree_is_deep;
         r.use_refill = probe_refill;        // trace_grid sizes the launch for it
-        const dim3 g(r.trace_grid(n)), t(atn::kTraceBlock);
+        const dim3 g(r.trace_grid(n)), t(probe_refill ? (uint32_t)atn::kTraceBlock : 256u);
+        const uint32_t lds = probe_refill ? r.scene.treelet_bytes : 0u;
         const atn_ray* rp = rays.p;
         if (stats_out) {
-            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
-            else hipLaunchKernelGGL((atn::k_trace_batch<true, false>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            else hipLaunchKernelGGL((atn::k_trace_batch<true, false>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
         }
         else {
-            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<false, true>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
-            else hipLaunchKernelGGL((atn::k_trace_batch<false, false>), g, t, 0, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<false, true>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
+            else hipLaunchKernelGGL((atn::k_trace_batch<false, false>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
         }
     }
     C_HIP(r, hipGetLastError());

@@ -181,17 +181,20 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
     }
 }
 
-#ifndef ATN_TRACE_WAVES
-#define ATN_TRACE_WAVES 1
-#endif
-// REFILL selects the persistent, lane-refilling walk (large trees) or the plain grid-stride walk
-// (small trees, where the refill bookkeeping costs more than the idle lanes it removes).
+// REFILL selects the persistent, lane-refilling walk (large trees) or the plain walk (small trees and small launches,
+// where the refill bookkeeping costs more than the idle lanes it removes).  The persistent kernels keep the treelet
+// -- the first sc.treelet_bytes of the node image -- in dynamic LDS (the launch passes that many bytes).
+extern __shared__ float4 atn_dyn_lds[];
+
 template <bool COUNT, bool REFILL, class Job>
 ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc)
 {
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
-        trace_refill<COUNT>(sc, sh, count, fetch_counter, job, tc);
+        const uint32_t n16 = sc.treelet_bytes / 16u;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
+        __syncthreads();
+        trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {
         trace_simple<COUNT>(sc, count, job, tc);
@@ -218,7 +221,7 @@ struct ClosestJob {
 };
 
 template <bool COUNT, bool REFILL>
-__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_closest(PathBuffers pb, DevScene sc, int32_t bounce)
+__global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_closest(PathBuffers pb, DevScene sc, int32_t bounce)
 {
     const uint32_t count = pb.q_count[bounce];
     const ClosestJob job{ pb, pb.queue[bounce & 1], kEps };
@@ -535,7 +538,7 @@ struct ShadowJob {
 };
 
 template <bool COUNT, bool REFILL>
-__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
+__global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_shadow(PathBuffers pb, DevScene sc, int32_t bounce)
 {
     const uint32_t count = pb.sh_count[bounce];
     const ShadowJob<true> job{ pb, sc, kEps };
@@ -577,7 +580,7 @@ struct FusedJob {
 };
 
 template <bool REFILL, bool ALPHA>
-__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
+__global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
@@ -690,7 +693,7 @@ struct BatchJob {
 
 // The renderer's traversal core over caller-provided rays (parity probe, atn_trace_closest).
 template <bool COUNT, bool REFILL>
-__global__ void __launch_bounds__(kTraceBlock, ATN_TRACE_WAVES) k_trace_batch(DevScene sc, const atn_ray* __restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_batch(DevScene sc, const atn_ray* __restrict__ rays, uint32_t n,
                                                      float t_min, float t_max, atn_intersection* out,
                                                      unsigned long long* stats)
 {

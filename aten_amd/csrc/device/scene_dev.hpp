@@ -6,33 +6,35 @@
 
 namespace atn {
 
-// One 48-byte record per BVH node, all node lists concatenated into a single array with ABSOLUTE
-// indices, each list re-laid-out in walk (pre-)order so that an inner node's hit link is always
-// index + 1.  The walk order -- and therefore every hit/miss decision -- is exactly the
-// reference's (threaded_bvh_traverser.h:98-304); only the storage differs.
+// BVH records.  All node lists live in ONE byte image (DevScene::nodes); a link is the BYTE offset of the target
+// record (a multiple of 16) with the target's type in the low bits: kLinkLeafBit = triangle leaf, kLinkTlasBit = TLAS
+// leaf with a nested tree, 0 = inner node; kLinkEnd (-1, both type bits set) = leave this list.  Links are explicit,
+// so the walk order -- and therefore every hit/miss decision -- is exactly the reference's
+// (threaded_bvh_traverser.h:98-304) whatever the storage order is; records are stored in walk (pre-)order for locality.
 //
-// Links are int32 bit patterns: kLinkEnd (-1) = leave this list; otherwise the BYTE offset of the
-// target record in `nodes` (a multiple of 16) with the target's type in the low bits:
-// kLinkLeafBit = triangle leaf, kLinkTlasBit = TLAS leaf with a nested tree, 0 = inner node.
-//
-//   inner    : q0 = {boxmin.xyz, tag}       q1 = {boxmax.xyz, miss link}
-//              tag (int bits) = type bits of the NEXT record (offset + 48), i.e. of the implicit hit link
-//   tri leaf : q0 = {v0.xyz, triangle id}   q1 = {e1.xyz, next link}   q2 = {e2.xyz, 0}
+//   inner    (32 B): q0 = {boxmin.xyz, hit link}    q1 = {boxmax.xyz, miss link}
+//   tri leaf (48 B): q0 = {v0.xyz, triangle id}     q1 = {e1.xyz, next link}   q2 = {e2.xyz, 0}
 //              (v0, e1 = v1 - v0, e2 = v2 - v0 of the leaf's triangle: the three dependent
 //               gathers node -> TriangleParameter -> 3 vertices become one 48-byte read;
 //               e1/e2 are the same IEEE subtractions intersectTriangle performs, done at upload)
-//   TLAS leaf: q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), BLAS root link, 0}
-//              q1 = {meshid, top hit link, top miss link, 0}
-//   dead leaf: a leaf with neither triangle nor nested tree (sphere instance: never tested on this
-//              path); typed as an inner record whose tag is kTagDead: always "miss".
-//              q0 = {0,0,0, kTagDead}      q1 = {0,0,0, miss link}
+//   TLAS leaf (32 B): q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), BLAS root link, 0}
+//                     q1 = {meshid, top hit link, top miss link, 0}
+//   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
+//              path); an inner record whose hit link IS its miss link.
+//
+// The image starts with the TREELET: the inner records nearest the roots of the bottom-level trees (at most
+// kTreeletMaxBytes), which the persistent trace kernel copies into LDS; [0, treelet_bytes) is that address range.
 constexpr int32_t kLinkEnd = -1;
 constexpr int32_t kLinkLeafBit = 1;
 constexpr int32_t kLinkTlasBit = 2;
 constexpr int32_t kLinkTypeMask = 3;
 constexpr uint32_t kLinkOffsetMask = ~15u;
-constexpr uint32_t kNodeBytes = 48;
-constexpr int32_t kTagDead = 8;
+constexpr uint32_t kInnerBytes = 32;
+constexpr uint32_t kTriLeafBytes = 48;
+#ifndef ATN_TREELET_BYTES
+#define ATN_TREELET_BYTES 0      /* measured on MI355X: the LDS copy loses to the L1; > 0 re-enables it */
+#endif
+constexpr uint32_t kTreeletMaxBytes = ATN_TREELET_BYTES;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
 constexpr uint32_t kAttrIdealRefraction = 0x10000u;   // MaterialParameter::isIdealRefraction, folded into attrib at upload
@@ -60,7 +62,7 @@ struct DevTexture {
 };
 
 struct DevScene {
-    const float4* nodes;                // DevNodes records, 3 float4 per node
+    const float4* nodes;                // byte image of the BVH records (see above)
     const atn_triangle_param* tris;     // 32 B each (ids / needNormal / mtrlid / mesh_id)
     const float4* vtx_pos;              // (pos.xyz, u)
     const float4* vtx_nml;              // (nml.xyz, v)
@@ -83,6 +85,7 @@ struct DevScene {
     int32_t any_alpha;          // some material carries kAttrMaybeAlpha
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
+    uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
 };
 
 } // namespace atn

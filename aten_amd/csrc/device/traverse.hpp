@@ -77,133 +77,15 @@ ATN_DEV bool slab_hit_fast(const RaySlab& s, const f3& bmin, const f3& bmax, flo
     return t0 <= t1;
 }
 
-constexpr int kTraceBlock = 256;
+#ifndef ATN_TRACE_BLOCK
+#define ATN_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = ATN_TRACE_BLOCK;        // threads per block of the persistent (refill) trace kernels
 
 ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
 {
     return *reinterpret_cast<const float4*>(base + byte_off);
 }
-
-// Job interface (all jobs of a launch share t_min):
-//   float t_min
-//   void fetch(uint32_t j, float4& a, float4& b, float& stop_t)   a = {org.xyz, t_max}, b = {dir.xyz, payload bits}
-//        stop_t: the walk may stop at the first ACCEPTED hit whose t <= stop_t.  -inf = plain closest-hit walk;
-//        +inf = "any hit" (only finish()'s is_hit is used); a finite value = the caller only needs to know whether
-//        the closest hit is nearer than stop_t (shadow rays toward point / spot lights).  This is exact, not an
-//        approximation: up to that hit the closest-hit walk is the same walk, its final hit can only be nearer,
-//        and when no such hit is accepted the walk runs to its end and reports the exact closest hit.
-//   void finish(uint32_t payload, const Hit& h, bool is_hit)
-// One ray per lane for the lifetime of its walk; grid-stride over the jobs.
-template <bool COUNT, class Job>
-ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
-{
-    const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
-    const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
-        float4 a, b;
-        float stop_t;
-        job.fetch(j, a, b, stop_t);
-        float t_max = a.w;
-        const uint32_t payload = __float_as_uint(b.w);
-        RaySlab wray, ray;
-        slab_setup(wray, mk3(a), mk3(b));
-        ray = wray;
-        Hit hit; hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
-        int32_t node = sc.root_link, objid = -1, meshid = -1, top_hit = kLinkEnd, top_miss = kLinkEnd;
-
-        while (node != kLinkEnd) {
-            const uint32_t off = (uint32_t)node & kLinkOffsetMask;
-            const float4 q0 = ld16(nb, off);
-            const float4 q1 = ld16(nb, off + 16u);
-            if (COUNT) cnt->nodes++;
-            bool is_hit;
-            if (!(node & kLinkTypeMask)) {
-                // inner node (or a leaf with nothing to test: its tag makes the slab result irrelevant)
-                is_hit = ray.finite ? slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max)
-                                    : slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
-                const int32_t tag = __float_as_int(q0.w);
-                const int32_t hit_link = (int32_t)(off + kNodeBytes) | tag;       // tag = type bits of the next node
-                node = (is_hit && tag != kTagDead) ? hit_link : __float_as_int(q1.w);
-                is_hit = is_hit && tag != kTagDead;
-            }
-            else if (node & kLinkLeafBit) {
-                const float4 q2 = ld16(nb, off + 32u);
-                if (COUNT) cnt->tris++;
-                const f3 e1 = mk3(q1), e2 = mk3(q2);
-                const f3 r = ray.org - mk3(q0);
-                const f3 u = cross(ray.dir, e2);
-                const f3 v = cross(r, e1);
-                const float inv = 1.0F / dot(u, e1);
-                const float t = dot(v, e2) * inv;
-                const float beta = dot(u, r) * inv;
-                const float gamma = dot(v, ray.dir) * inv;
-                const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
-                    && (beta + gamma <= 1.0F) && t >= 0.0F);
-                is_hit = isect && (t < kInf);                       // triangle::hit against isect_tmp.t = INF
-                const bool accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
-                if (accept) {
-                    hit.t = t; hit.a = beta; hit.b = gamma;
-                    hit.objid = objid; hit.tri = __float_as_int(q0.w); hit.meshid = meshid;
-                    t_max = t;
-                }
-                node = __float_as_int(q1.w);        // leaf: hit link == miss link
-                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }    // see Job::fetch
-            }
-            else {
-                // TLAS leaf with a nested tree
-                objid = __float_as_int(q0.x);
-                const int32_t w2l = __float_as_int(q0.y);
-                meshid = __float_as_int(q1.x);
-                top_hit = __float_as_int(q1.y);
-                top_miss = __float_as_int(q1.z);
-                if (w2l >= 0) {
-                    // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
-                    m4 m;
-                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
-                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
-                    const f3 o = m4_apply(m, wray.org);
-                    const f3 d = normalize(m4_applyXYZ(m, wray.dir));
-                    slab_setup(ray, o, d);
-                }
-                else {
-                    ray = wray;
-                }
-                is_hit = true;
-                node = __float_as_int(q0.z);        // BLAS root link
-            }
-            if (node == kLinkEnd) {
-                // leave the bottom layer (top_* are kLinkEnd inside the top layer)
-                node = is_hit ? top_hit : top_miss;
-                top_hit = kLinkEnd; top_miss = kLinkEnd;
-                ray = wray;
-            }
-        }
-        job.finish(payload, hit, hit.objid >= 0);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Same per-ray walk, but the wave is persistent: it reserves chunks of kFetchChunk jobs with one
-// atomicAdd, stages the chunk's rays in LDS with one coalesced burst, and whenever kRefillLanes
-// lanes have finished their rays it hands them new ones (ballot + popcount prefix).  Rays visit
-// very different numbers of nodes (sponza_lod: mean 56, long tail); without refill a wave idles
-// ~60 % of its lane-iterations waiting for its longest ray.
-#ifndef ATN_REFILL_LANES
-#define ATN_REFILL_LANES 16
-#endif
-constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
-#ifndef ATN_FETCH_CHUNK
-#define ATN_FETCH_CHUNK 128
-#endif
-constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
-constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
-#ifndef ATN_LEAF_CADENCE
-#define ATN_LEAF_CADENCE 3
-#endif
-constexpr uint32_t kLeafCadence = ATN_LEAF_CADENCE;
-struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk]; };   // 18 KB
 
 // One Moeller-Trumbore test against a triangle-leaf record (q0, q1, q2) -- intersectTriangle (math/intersect.h:45-90) +
 // triangle::hit (geometry/triangle.h:40-67) + the traverser's acceptance (threaded_bvh_traverser.h:236-262).
@@ -221,7 +103,7 @@ ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, c
     const float gamma = dot(v, ray.dir) * inv;
     const bool isect = ((beta >= 0.0F && beta <= 1.0F) && (gamma >= 0.0F && gamma <= 1.0F)
         && (beta + gamma <= 1.0F) && t >= 0.0F);
-    const bool is_hit = isect && (t < kInf);
+    const bool is_hit = isect && (t < kInf);                        // triangle::hit against isect_tmp.t = INF
     accept = (t_min < (is_hit ? t : kInf)) && is_hit && (t < hit.t);
     if (accept) {
         hit.t = t; hit.a = beta; hit.b = gamma;
@@ -232,28 +114,201 @@ ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, c
     return is_hit;
 }
 
-// The persistent walk.  One wave iteration = refill, then a BURST of kInnerBurst inner-node steps in a tight loop (two
-// 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a
-// triangle leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.
-// Why: at any moment only ~7 of 64 lanes stand on a leaf (one visit in nine), so a loop that offers every node kind
-// on every iteration issues the ~75-instruction triangle block each time for a handful of lanes, and drags the
-// refill / leave / finish bookkeeping (~60 scalar instructions) through every inner-node step.  Here a lane that
-// reaches a leaf waits, masked off, for the end of the burst (<= kInnerBurst - 1 steps), the triangle block runs once
-// per burst with several times the lanes, and the inner-node step is ~30 VALU + ~10 SALU.
-// The slab test takes ONE of its two forms per wave: the hardware min/max form when every live lane's slab constants
-// are finite (a wave-uniform flag, refreshed only where rays change), the select form -- valid for all inputs --
-// otherwise.  A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
+// Job interface (all jobs of a launch share t_min):
+//   float t_min
+//   void fetch(uint32_t j, float4& a, float4& b, float& stop_t)   a = {org.xyz, t_max}, b = {dir.xyz, payload bits}
+//        stop_t: the walk may stop at the first ACCEPTED hit whose t <= stop_t.  -inf = plain closest-hit walk;
+//        +inf = "any hit" (only finish()'s is_hit is used); a finite value = the caller only needs to know whether
+//        the closest hit is nearer than stop_t (shadow rays toward point / spot lights).  This is exact, not an
+//        approximation: up to that hit the closest-hit walk is the same walk, its final hit can only be nearer,
+//        and when no such hit is accepted the walk runs to its end and reports the exact closest hit.
+//   void finish(uint32_t payload, const Hit& h, bool is_hit)
+
+// Per-lane state of one walk.  A lane is idle <=> node == kLinkEnd at the top of an iteration.
+struct Walk {
+    RaySlab wray, ray;      // world-space ray and the ray of the list being walked (transformed inside a nested tree)
+    Hit hit;
+    float t_max, stop_t;
+    uint32_t payload;
+    int32_t node, objid, meshid, top_hit, top_miss;
+};
+
+ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t)
+{
+    w.t_max = a.w;
+    w.stop_t = stop_t;
+    w.payload = __float_as_uint(b.w);
+    w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
+    slab_setup(w.wray, mk3(a), mk3(b));
+    w.ray = w.wray;
+    w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+}
+
 #ifndef ATN_INNER_BURST
 #define ATN_INNER_BURST 4
 #endif
 constexpr int kInnerBurst = ATN_INNER_BURST;
 
+// One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
+// 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
+// leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.
+// Why: at any moment only ~7 of 64 lanes stand on a leaf (one visit in nine), so a loop that offers every node kind on
+// every iteration issues the ~75-instruction triangle block each time for a handful of lanes, and drags the leave /
+// finish (and refill) bookkeeping -- ~60 scalar instructions -- through every inner-node step.  Here a lane that
+// reaches a leaf waits, masked off, for the end of the burst, the triangle block runs once per burst with several
+// times the lanes, and the inner-node step is ~30 VALU + ~15 SALU.
+// The slab test takes ONE of its two forms per wave: the hardware min/max form when every live lane's slab constants
+// are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form -- valid for all inputs
+// -- otherwise.  TREELET: records below sc.treelet_bytes are read from the block's LDS copy (`treelet`).
+// A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
+template <bool COUNT, bool TREELET, class Job>
+ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* treelet,
+                            uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
+{
+    // ---- burst of inner-node steps.  kLinkEnd has both type bits set, so `(node & 3) == 0` alone selects the live
+    // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
+    // link is its miss link): a list that ends here ended on a MISS.
+    const bool live = w.node != kLinkEnd;
+#pragma unroll 1
+    for (int k = 0; k < kInnerBurst; k++) {
+        if (!(w.node & kLinkTypeMask)) {
+            const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
+            float4 q0, q1;
+            if (TREELET) {
+                // Straight-line: every lane reads BOTH sources (the LDS copy at its offset or at 0, the global image at
+                // its offset or at 0 -- the unused side of a lane is a broadcast read of record 0) and the results are
+                // merged with one v_bfi per dword.  With a branch per source and shared destination registers the
+                // compiler has to complete one side before it issues the other (it cannot see that the lanes are
+                // disjoint), which adds the two latencies; here all four loads are in flight together.
+                const bool in_lds = off < treelet_bytes;
+                const uint32_t m = in_lds ? 0xffffffffu : 0u;
+                const uint32_t loff = off & m, goff = off & ~m;
+                const uint4 l0 = *reinterpret_cast<const uint4*>(treelet + loff);
+                const uint4 l1 = *reinterpret_cast<const uint4*>(treelet + loff + 16u);
+                const uint4 g0 = *reinterpret_cast<const uint4*>(nb + goff);
+                const uint4 g1 = *reinterpret_cast<const uint4*>(nb + goff + 16u);
+                q0 = make_float4(__uint_as_float((l0.x & m) | (g0.x & ~m)), __uint_as_float((l0.y & m) | (g0.y & ~m)),
+                                 __uint_as_float((l0.z & m) | (g0.z & ~m)), __uint_as_float((l0.w & m) | (g0.w & ~m)));
+                q1 = make_float4(__uint_as_float((l1.x & m) | (g1.x & ~m)), __uint_as_float((l1.y & m) | (g1.y & ~m)),
+                                 __uint_as_float((l1.z & m) | (g1.z & ~m)), __uint_as_float((l1.w & m) | (g1.w & ~m)));
+            }
+            else {
+                q0 = ld16(nb, off);
+                q1 = ld16(nb, off + 16u);
+            }
+            if (COUNT) cnt->nodes++;
+            bool box;
+            if (all_finite) box = slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+            else box = slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+            w.node = __float_as_int(box ? q0.w : q1.w);
+        }
+    }
+    bool ended = live && w.node == kLinkEnd;    // this lane's walk left a list in this iteration ...
+    bool is_hit = false;                        // ... and this was the result of its last step
+
+    // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
+    const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
+    if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
+        const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
+        const float4 q0 = ld16(nb, off);
+        const float4 q1 = ld16(nb, off + 16u);
+        if (COUNT) cnt->nodes++;
+        if (w.node & kLinkLeafBit) {
+            const float4 q2 = ld16(nb, off + 32u);
+            if (COUNT) cnt->tris++;
+            bool accept; float t;
+            is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
+            w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
+            if (accept && t <= w.stop_t) { w.node = kLinkEnd; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd; }    // see Job::fetch
+            ended = w.node == kLinkEnd;
+        }
+        else {
+            w.objid = __float_as_int(q0.x);
+            const int32_t w2l = __float_as_int(q0.y);
+            w.meshid = __float_as_int(q1.x);
+            w.top_hit = __float_as_int(q1.y);
+            w.top_miss = __float_as_int(q1.z);
+            if (w2l >= 0) {
+                // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
+                m4 m;
+                m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
+                m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                const f3 o = m4_apply(m, w.wray.org);
+                const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
+                slab_setup(w.ray, o, d);
+            }
+            else {
+                w.ray = w.wray;
+            }
+            is_hit = true;
+            w.node = __float_as_int(q0.z);      // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
+            ended = false;
+        }
+    }
+
+    // ---- a list ended: leave the bottom layer (top_* are kLinkEnd inside the top layer), or finish
+    if (ended) {
+        w.node = is_hit ? w.top_hit : w.top_miss;
+        w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+        w.ray = w.wray;
+        if (w.node == kLinkEnd) job.finish(w.payload, w.hit, w.hit.objid >= 0);
+    }
+    // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
+    if (__any(ended || at_tlas) || !all_finite) all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
+}
+
+// Plain flavour: one ray per lane for the lifetime of its walk, the wave moves on to its next 64 jobs when all of its
+// lanes have finished (small trees and small launches, where the refill bookkeeping costs more than the idle lanes).
 template <bool COUNT, class Job>
-ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
+ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
+{
+    const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
+    const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;      // the wave's first job: wave-uniform loop bound
+    const uint32_t lane = threadIdx.x & 63u;
+    Walk w;
+    slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
+    w.ray = w.wray;
+    w.node = kLinkEnd;
+    for (uint32_t base = first; base < count; base += stride) {
+        const uint32_t j = base + lane;
+        if (j < count) {
+            float4 a, b;
+            float stop_t;
+            job.fetch(j, a, b, stop_t);
+            walk_start(w, sc, a, b, stop_t);
+        }
+        bool all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
+        while (__any(w.node != kLinkEnd))
+            walk_iteration<COUNT, false>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same per-ray walk, but the wave is persistent: it reserves chunks of kFetchChunk jobs with one
+// atomicAdd, stages the chunk's rays in LDS with one coalesced burst, and whenever kRefillLanes
+// lanes have finished their rays it hands them new ones (ballot + popcount prefix).  Rays visit
+// very different numbers of nodes (sponza_lod: mean 56, long tail); without refill a wave idles
+// ~60 % of its lane-iterations waiting for its longest ray.
+#ifndef ATN_REFILL_LANES
+#define ATN_REFILL_LANES 16
+#endif
+constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
+#ifndef ATN_FETCH_CHUNK
+#define ATN_FETCH_CHUNK 128
+#endif
+constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
+constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
+struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk]; };   // 18 KB
+
+template <bool COUNT, class Job>
+ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treelet, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
+    const uint32_t treelet_bytes = sc.treelet_bytes;
     const uint32_t lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     float4 (*stage)[2] = sh.stage[threadIdx.x >> 6];
@@ -266,18 +321,17 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     bool first_chunk = true;            // wave-uniform
     bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
 
-    uint32_t payload = 0;
-    float t_max = 0.0F, stop_t = -kInf;
-    RaySlab wray, ray;
-    slab_setup(wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
-    ray = wray;
-    Hit hit; hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
-    int32_t node = kLinkEnd, objid = -1, meshid = -1, top_hit = kLinkEnd, top_miss = kLinkEnd;
-    // a lane is idle <=> node == kLinkEnd at the top of an iteration
+    Walk w;
+    slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
+    w.ray = w.wray;
+    w.node = kLinkEnd;
+    w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
+    w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
+    w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
 
     for (;;) {
         // ---- refill
-        const unsigned long long m_idle = __ballot(node == kLinkEnd);
+        const unsigned long long m_idle = __ballot(w.node == kLinkEnd);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle >= kRefillLanes) {
             if (c_next >= c_count && !drained) {
@@ -312,98 +366,18 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
             }
             if (c_next < c_count) {
                 const uint32_t avail = c_count - c_next;
-                if (node == kLinkEnd) {
+                if (w.node == kLinkEnd) {
                     const uint32_t k = (uint32_t)__popcll(m_idle & lt);
-                    if (k < avail) {
-                        const float4 a = stage[c_next + k][0];
-                        const float4 b = stage[c_next + k][1];
-                        t_max = a.w;
-                        stop_t = stage_stop[c_next + k];
-                        payload = __float_as_uint(b.w);
-                        hit.t = kInf; hit.objid = -1; hit.tri = -1; hit.a = 0.0F; hit.b = 0.0F; hit.meshid = -1;
-                        slab_setup(wray, mk3(a), mk3(b));
-                        ray = wray;
-                        node = sc.root_link; objid = -1; meshid = -1; top_hit = kLinkEnd; top_miss = kLinkEnd;
-                    }
+                    if (k < avail) walk_start(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
                 }
                 c_next += n_idle < avail ? n_idle : avail;
-                all_finite = __all(node == kLinkEnd || ray.finite) != 0;
+                all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
             }
             else if (n_idle == 64u) {
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-
-        // ---- burst of inner-node steps (dead leaves are typed inner, tag kTagDead).  kLinkEnd has both type bits set,
-        // so `(node & 3) == 0` alone selects the live lanes on inner nodes.  An inner node's hit link is the next
-        // record and never kLinkEnd (checked at upload): a list that ends here ended on a MISS link.
-        const bool live = node != kLinkEnd;
-#pragma unroll 1
-        for (int k = 0; k < kInnerBurst; k++) {
-            if (!(node & kLinkTypeMask)) {
-                const uint32_t off = (uint32_t)node;        // type bits are 0: the link is the byte offset
-                const float4 q0 = ld16(nb, off);
-                const float4 q1 = ld16(nb, off + 16u);
-                if (COUNT) cnt->nodes++;
-                bool box;
-                if (all_finite) box = slab_hit_fast(ray, mk3(q0), mk3(q1), t_min, t_max);
-                else box = slab_hit_exact(ray, mk3(q0), mk3(q1), t_min, t_max);
-                const int32_t tag = __float_as_int(q0.w);
-                node = (box && tag != kTagDead) ? ((int32_t)(off + kNodeBytes) | tag) : __float_as_int(q1.w);  // hit link = next record, typed by the tag
-            }
-        }
-        bool ended = live && node == kLinkEnd;      // this lane's walk left a list in this iteration ...
-        bool is_hit = false;                        // ... and this was the result of its last step
-
-        // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
-        const bool at_tlas = node != kLinkEnd && (node & kLinkTypeMask) == kLinkTlasBit;
-        if (node != kLinkEnd && (node & kLinkTypeMask)) {
-            const uint32_t off = (uint32_t)node & kLinkOffsetMask;
-            const float4 q0 = ld16(nb, off);
-            const float4 q1 = ld16(nb, off + 16u);
-            if (COUNT) cnt->nodes++;
-            if (node & kLinkLeafBit) {
-                const float4 q2 = ld16(nb, off + 32u);
-                if (COUNT) cnt->tris++;
-                bool accept; float t;
-                is_hit = leaf_test(ray, q0, q1, q2, t_min, hit, t_max, objid, meshid, accept, t);
-                node = __float_as_int(q1.w);        // leaf: hit link == miss link
-                if (accept && t <= stop_t) { node = kLinkEnd; top_hit = kLinkEnd; top_miss = kLinkEnd; }    // see Job::fetch
-                ended = node == kLinkEnd;
-            }
-            else {
-                objid = __float_as_int(q0.x);
-                const int32_t w2l = __float_as_int(q0.y);
-                meshid = __float_as_int(q1.x);
-                top_hit = __float_as_int(q1.y);
-                top_miss = __float_as_int(q1.z);
-                if (w2l >= 0) {
-                    // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
-                    m4 m;
-                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
-                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
-                    const f3 o = m4_apply(m, wray.org);
-                    const f3 d = normalize(m4_applyXYZ(m, wray.dir));
-                    slab_setup(ray, o, d);
-                }
-                else {
-                    ray = wray;
-                }
-                is_hit = true;
-                node = __float_as_int(q0.z);        // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
-                ended = false;
-            }
-        }
-
-        // ---- a list ended: leave the bottom layer (top_* are kLinkEnd inside the top layer), or finish
-        if (ended) {
-            node = is_hit ? top_hit : top_miss;
-            top_hit = kLinkEnd; top_miss = kLinkEnd;
-            ray = wray;
-            if (node == kLinkEnd) job.finish(payload, hit, hit.objid >= 0);
-        }
-        // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
-        if (__any(ended || at_tlas) || !all_finite) all_finite = __all(node == kLinkEnd || ray.finite) != 0;
+        walk_iteration<COUNT, (kTreeletMaxBytes > 0)>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
     }
 }
 

@@ -11,8 +11,9 @@
 namespace atn {
 
 struct HostSceneImage {
-    std::vector<float4> nodes;          // 3 per node
-    std::vector<uint32_t> list_root;    // absolute index of each list's first node
+    std::vector<float4> nodes;          // the byte image of all records (16-byte units)
+    uint64_t n_nodes = 0;
+    std::vector<uint32_t> list_root;    // byte offset of each list's first non-treelet record
     std::vector<int32_t> list_root_link; // typed link of each list's root
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
@@ -47,64 +48,104 @@ inline bool walk_order(const atn_bvh_node* nodes, uint32_t count, std::vector<in
     return true;
 }
 
+enum NodeKind : uint8_t { KIND_INNER = 0, KIND_TRI = 1, KIND_TLAS = 2, KIND_DEAD = 3 };
+inline uint32_t record_bytes(uint8_t kind) { return kind == KIND_TRI ? kTriLeafBytes : kInnerBytes; }
+inline int32_t kind_type_bits(uint8_t kind) { return kind == KIND_TRI ? kLinkLeafBit : (kind == KIND_TLAS ? kLinkTlasBit : 0); }
+
+// One threaded list analysed: walk order, node kinds, depth of every node, and (filled by the layout pass) the byte
+// offset of every node's device record.
+struct ListLayout {
+    std::vector<uint32_t> order;        // walk position -> caller's node index
+    std::vector<int32_t> new_index;     // caller's node index -> walk position (-1 = unreachable)
+    std::vector<uint8_t> kind;          // by walk position
+    std::vector<int32_t> depth;         // by walk position
+    std::vector<uint32_t> offset;       // by walk position: byte offset of the record in the device image
+    std::vector<uint8_t> in_treelet;    // by walk position
+};
+
+// Validates a list (reachability, forward links, the structural rules the walk relies on) and fills order/kind/depth.
+inline bool analyse_list(ListLayout& L, const atn_bvh_node* src, uint32_t count, bool top, std::string& err)
+{
+    if (!walk_order(src, count, L.new_index, L.order, err)) return false;
+    const uint32_t n = (uint32_t)L.order.size();
+    L.kind.assign(n, KIND_INNER); L.depth.assign(n, 0); L.offset.assign(n, 0); L.in_treelet.assign(n, 0);
+    std::vector<uint32_t> open_end;     // walk positions at which the open subtrees end (a stack)
+    for (uint32_t j = 0; j < n; j++) {
+        const atn_bvh_node& nd = src[L.order[j]];
+        // every link in range, reachable, and pointing FORWARD in walk order: the device walk has no other termination
+        // argument (a corrupted or hand-edited .sbvh with a backward miss link would spin a wave forever)
+        for (const float link : { nd.hit, nd.miss }) {
+            const int32_t l = (int32_t)link;
+            if (l < 0) continue;
+            if ((uint32_t)l >= count || L.new_index[l] < 0) { err = "BVH link points to an unreachable node"; return false; }
+            if (L.new_index[l] <= (int32_t)j) { err = "BVH link points backward in walk order (the walk would not terminate)"; return false; }
+        }
+        const bool leaf = (nd.f0 >= 0 || nd.f1 >= 0);       // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
+        uint8_t kind;
+        if (!leaf) {
+            kind = KIND_INNER;
+            // the walk treats "a list ended on an inner node" as "ended on its miss link" (traverse.hpp)
+            if ((int32_t)nd.hit < 0) { err = "inner node without a hit link"; return false; }
+        }
+        else if (nd.f2 >= 0) {
+            if (!top) { err = "nested BVH reference inside a bottom-level list"; return false; }
+            kind = KIND_TLAS;
+        }
+        else if (nd.f1 >= 0) {
+            if ((int32_t)nd.hit != (int32_t)nd.miss) { err = "triangle leaf with hit != miss link"; return false; }
+            kind = KIND_TRI;
+        }
+        else kind = KIND_DEAD;      // leaf without triangle or nested tree (sphere instance): never tested on this path
+        L.kind[j] = kind;
+        while (!open_end.empty() && open_end.back() <= j) open_end.pop_back();
+        L.depth[j] = (int32_t)open_end.size();
+        if (kind == KIND_INNER) {
+            const int32_t m = (int32_t)nd.miss;
+            open_end.push_back(m < 0 ? 0xffffffffu : (uint32_t)L.new_index[m]);       // the subtree is skipped by the miss link
+        }
+    }
+    return true;
+}
+
 // What a list's records need from the rest of the scene.
 struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
     const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0, n_vertices = 0;
     const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
-    bool top = false;
 };
 
-// Emits the device records of one threaded list in walk order at absolute node index `base`.
-// Returns the typed link of the list's root through `root_link`.
-inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint32_t base, const ListEmitCtx& c,
-                      int32_t& root_link, uint64_t counts[3], std::string& err)
+// Writes the device records of one analysed list (offsets already assigned) into the byte image `img`.
+// (`img` + offset - write_bias is where a record goes: write_bias > 0 when `img` holds only the image's tail.)
+inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, const ListEmitCtx& c,
+                      int32_t& root_link, uint64_t counts[3], std::string& err, uint32_t write_bias = 0)
 {
-    std::vector<int32_t> new_index;
-    std::vector<uint32_t> order;
-    if (!walk_order(src, count, new_index, order, err)) return false;
-    auto type_bits = [&](uint32_t old_idx) -> int32_t {
-        const atn_bvh_node& n = src[old_idx];
-        if (!(n.f0 >= 0 || n.f1 >= 0)) return 0;        // inner
-        if (n.f2 >= 0) return kLinkTlasBit;             // nested tree
-        if (n.f1 >= 0) return kLinkLeafBit;             // triangle
-        return 0;                                       // dead leaf: handled on the inner path by its tag
-    };
-    // typed link of a float link: kLinkEnd, or absolute byte offset | type bits; -2 = invalid
-    auto remap = [&](float link) -> int32_t {
+    const uint32_t n = (uint32_t)L.order.size();
+    auto typed = [&](float link) -> int32_t {
         const int32_t l = (int32_t)link;
         if (l < 0) return kLinkEnd;
-        if ((uint32_t)l >= count || new_index[l] < 0) return -2;
-        const int32_t abs = (int32_t)base + new_index[l];
-        return (int32_t)((uint32_t)abs * kNodeBytes) | type_bits((uint32_t)l);
+        const uint32_t j = (uint32_t)L.new_index[l];
+        return (int32_t)L.offset[j] | kind_type_bits(L.kind[j]);
     };
-    root_link = count ? remap(0.0F) : kLinkEnd;
-    for (uint32_t j = 0; j < order.size(); j++) {
-        const atn_bvh_node& n = src[order[j]];
-        const uint32_t abs = base + j;
-        float4& q0 = out[3 * (size_t)j + 0];
-        float4& q1 = out[3 * (size_t)j + 1];
-        float4& q2 = out[3 * (size_t)j + 2];
-        q0 = q1 = q2 = make_float4(0, 0, 0, 0);
-        const int32_t h = remap(n.hit), m = remap(n.miss);
-        if (h == -2 || m == -2) { err = "BVH link points to an unreachable node"; return false; }
-        // Every link must point FORWARD in walk order: the device walk has no other termination argument (a
-        // corrupted or hand-edited .sbvh with a backward miss link would spin a wave forever).
-        auto forward = [&](float link) { const int32_t l = (int32_t)link; return l < 0 || new_index[l] > (int32_t)j; };
-        if (!forward(n.hit) || !forward(n.miss)) { err = "BVH link points backward in walk order (the walk would not terminate)"; return false; }
-        const bool leaf = (n.f0 >= 0 || n.f1 >= 0);         // ThreadedBvhNode::isLeaf, threaded_bvh.h:41-44
-        if (!leaf) {
-            if (h == kLinkEnd || ((uint32_t)h & kLinkOffsetMask) != (abs + 1) * kNodeBytes) { err = "inner node whose hit link is not the next node in walk order"; return false; }
-            q0 = make_float4(n.boxmin[0], n.boxmin[1], n.boxmin[2], i2f(h & kLinkTypeMask));
-            q1 = make_float4(n.boxmax[0], n.boxmax[1], n.boxmax[2], i2f(m));
+    root_link = n ? ((int32_t)L.offset[0] | kind_type_bits(L.kind[0])) : kLinkEnd;
+    for (uint32_t j = 0; j < n; j++) {
+        const atn_bvh_node& nd = src[L.order[j]];
+        float4* q = reinterpret_cast<float4*>(img + (L.offset[j] - write_bias));
+        const int32_t h = typed(nd.hit), m = typed(nd.miss);
+        switch (L.kind[j]) {
+        case KIND_INNER:
+            q[0] = make_float4(nd.boxmin[0], nd.boxmin[1], nd.boxmin[2], i2f(h));
+            q[1] = make_float4(nd.boxmax[0], nd.boxmax[1], nd.boxmax[2], i2f(m));
             counts[0]++;
-        }
-        else if (n.f2 >= 0) {
+            break;
+        case KIND_DEAD:     // an inner record whose both links are the miss link: whatever the slab test says, the walk goes on
+            q[0] = make_float4(0, 0, 0, i2f(m));
+            q[1] = make_float4(0, 0, 0, i2f(m));
+            break;
+        case KIND_TLAS: {
             // nested tree (exid bit-field, threaded_bvh.h:29-37)
-            if (!c.top) { err = "nested BVH reference inside a bottom-level list"; return false; }
-            const int32_t objid = (int32_t)n.f0;
+            const int32_t objid = (int32_t)nd.f0;
             if (objid < 0 || (uint32_t)objid >= c.n_objects) { err = "TLAS leaf object id out of range"; return false; }
-            const uint32_t bits = f2u(n.f2);
+            const uint32_t bits = f2u(nd.f2);
             const int32_t exid = ATN_EXID_MAIN(bits);
             if (exid <= 0 || (uint32_t)exid >= c.n_lists || c.list_root_link[exid] == kLinkEnd) { err = "TLAS leaf references a missing BLAS list"; return false; }
             const atn_object_param& obj = c.objects[objid];
@@ -113,15 +154,15 @@ inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint
                 if ((uint32_t)obj.mtx_id + 1 >= c.n_matrices) { err = "object matrix index out of range"; return false; }
                 w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
             }
-            q0 = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), 0.0F);
-            q1 = make_float4(i2f((int32_t)n.f3), i2f(h), i2f(m), 0.0F);
+            q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), 0.0F);
+            q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), 0.0F);
             counts[2]++;
+            break;
         }
-        else if (n.f1 >= 0) {
+        default: {  // KIND_TRI
             if (!c.tris) { err = "triangle leaves in this list need a full scene upload"; return false; }
-            const uint32_t tri = (uint32_t)n.f1;
+            const uint32_t tri = (uint32_t)nd.f1;
             if (tri >= c.n_triangles) { err = "leaf triangle id out of range"; return false; }
-            if (h != m) { err = "triangle leaf with hit != miss link"; return false; }
             const atn_triangle_param& t = c.tris[tri];
             for (int v = 0; v < 3; v++)
                 if (t.idx[v] < 0 || (uint32_t)t.idx[v] >= c.n_vertices) { err = "triangle vertex index out of range"; return false; }
@@ -130,15 +171,12 @@ inline bool emit_list(float4* out, const atn_bvh_node* src, uint32_t count, uint
             const atn_vec4& cc = c.vtx_pos[t.idx[2]];
             // e1 = v1 - v0, e2 = v2 - v0: the same fp32 subtractions intersectTriangle performs
             // per test (math/intersect.h:61-62), hoisted to upload time.
-            q0 = make_float4(a.x, a.y, a.z, i2f((int32_t)tri));
-            q1 = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, i2f(h));
-            q2 = make_float4(cc.x - a.x, cc.y - a.y, cc.z - a.z, 0.0F);
+            q[0] = make_float4(a.x, a.y, a.z, i2f((int32_t)tri));
+            q[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, i2f(h));
+            q[2] = make_float4(cc.x - a.x, cc.y - a.y, cc.z - a.z, 0.0F);
             counts[1]++;
+            break;
         }
-        else {
-            // leaf without triangle or nested tree (sphere instance): never tested on this path
-            q0 = make_float4(0, 0, 0, i2f(kTagDead));
-            q1 = make_float4(0, 0, 0, i2f(m));
         }
     }
     return true;
@@ -171,38 +209,78 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
     return true;
 }
 
-// Node image = [BLAS list 1][BLAS list 2]...[top layer (list 0)]: the top layer comes last so that
-// update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it without moving the others.
+// Node image (bytes): [treelet | BLAS list 1 | BLAS list 2 | ... | top layer (list 0)].
+//  * treelet = the inner nodes nearest the roots of the bottom-level trees, level by level over all of them, at most
+//    kTreeletMaxBytes: the region the persistent trace kernel keeps in LDS (on sponza_lod the top 10 levels, 1023
+//    nodes = 32 KB, receive 65-78 % of all node visits).  Because it is an address range, any kernel can equally
+//    read it from global memory: there is one set of links.
+//  * every list in walk order (locality; the links are explicit, so correctness does not depend on it)
+//  * the top layer comes last so that update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it
+//    without moving the others; top-layer records are all kInnerBytes long.
 inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err)
 {
     if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
     const uint32_t nl = s->n_bvh_lists;
-    uint64_t total = 0;
-    for (uint32_t k = 0; k < nl; k++) total += s->bvh_lists[k].count;
-    if (total * kNodeBytes >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
-    img.nodes.assign((size_t)total * 3, make_float4(0, 0, 0, 0));
+    std::string range_err;
+    if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
+
+    std::vector<ListLayout> lay(nl);
+    uint64_t total_nodes = 0;
+    for (uint32_t k = 0; k < nl; k++) {
+        if (!analyse_list(lay[k], s->bvh_lists[k].nodes, s->bvh_lists[k].count, k == 0, err)) return false;
+        total_nodes += lay[k].order.size();
+    }
+    // treelet: bottom-level inner nodes by depth, whole levels first, then the walk-order head of the next level
+    uint32_t treelet_nodes = 0;
+    {
+        const uint32_t budget = kTreeletMaxBytes / kInnerBytes;
+        for (int32_t d = 0; treelet_nodes < budget; d++) {
+            bool any_deeper = false;
+            for (uint32_t k = 1; k < nl && treelet_nodes < budget; k++) {
+                ListLayout& L = lay[k];
+                for (uint32_t j = 0; j < L.order.size() && treelet_nodes < budget; j++) {
+                    if (L.depth[j] >= d && L.kind[j] == KIND_INNER) any_deeper = true;
+                    if (L.depth[j] == d && L.kind[j] == KIND_INNER) { L.in_treelet[j] = 1; treelet_nodes++; }
+                }
+            }
+            if (!any_deeper) break;
+        }
+    }
+    uint64_t off = 0;
+    for (uint32_t k = 1; k < nl; k++)
+        for (uint32_t j = 0; j < lay[k].order.size(); j++)
+            if (lay[k].in_treelet[j]) { lay[k].offset[j] = (uint32_t)off; off += kInnerBytes; }
+    const uint64_t treelet_bytes = off;
     img.list_root.assign(nl, 0);
+    for (uint32_t kk = 1; kk <= nl; kk++) {
+        const uint32_t k = kk % nl;         // 1, 2, ..., nl-1, 0
+        img.list_root[k] = (uint32_t)off;
+        for (uint32_t j = 0; j < lay[k].order.size(); j++) {
+            if (lay[k].in_treelet[j]) continue;
+            if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
+            lay[k].offset[j] = (uint32_t)off;
+            off += record_bytes(lay[k].kind[j]);
+        }
+    }
+    if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
+    img.nodes.assign((size_t)(off / 16), make_float4(0, 0, 0, 0));
     img.list_root_link.assign(nl, kLinkEnd);
+    img.n_nodes = total_nodes;
 
     ListEmitCtx c;
     c.objects = s->objects; c.n_objects = s->n_objects; c.n_matrices = s->n_matrices;
     c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles; c.n_vertices = s->n_vertices;
     c.n_lists = nl;
-    std::string range_err;
-    if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
     uint64_t counts[3] = { 0, 0, 0 };
-    uint32_t base = 0;
-    for (uint32_t k = 1; k <= nl; k++) {
-        const uint32_t list = k % nl;       // 1, 2, ..., nl-1, 0
-        c.top = (list == 0);
+    for (uint32_t kk = 1; kk <= nl; kk++) {
+        const uint32_t k = kk % nl;
         c.list_root_link = img.list_root_link.data();
-        img.list_root[list] = base;
         int32_t root = kLinkEnd;
-        if (!emit_list(img.nodes.data() + 3 * (size_t)base, s->bvh_lists[list].nodes, s->bvh_lists[list].count, base, c, root, counts, err)) return false;
-        img.list_root_link[list] = root;
-        base += s->bvh_lists[list].count;
+        if (!emit_list(reinterpret_cast<char*>(img.nodes.data()), lay[k], s->bvh_lists[k].nodes, c, root, counts, err)) return false;
+        img.list_root_link[k] = root;
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
+    img.params.treelet_bytes = (uint32_t)treelet_bytes;
 
     // ---- plain copies
     img.tris.assign(s->triangles, s->triangles + s->n_triangles);
@@ -248,13 +326,13 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     size_t ntex = 0;
     for (uint32_t i = 0; i < s->n_textures; i++) ntex += (size_t)s->textures[i].width * s->textures[i].height;
     img.texels.resize(ntex);
-    size_t off = 0;
+    size_t toff = 0;
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const atn_texture_desc& t = s->textures[i];
-        img.textures[i].offset = (uint32_t)off; img.textures[i].width = t.width; img.textures[i].height = t.height; img.textures[i]._pad = 0;
+        img.textures[i].offset = (uint32_t)toff; img.textures[i].width = t.width; img.textures[i].height = t.height; img.textures[i]._pad = 0;
         const size_t n = (size_t)t.width * t.height;
-        for (size_t j = 0; j < n; j++) img.texels[off + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
-        off += n;
+        for (size_t j = 0; j < n; j++) img.texels[toff + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
+        toff += n;
     }
 
     DevScene& p = img.params;

@@ -1161,6 +1161,12 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
 int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
                  int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
 {
+    return atn_compact3(ctx, flags_a_host, flags_b_host, n, grid_blocks, 0, out_a_host, out_count_a, out_b_host, out_count_b);
+}
+
+int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks, int32_t binned,
+                 int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
+{
     CTX_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!flags_a_host || !out_a_host || !out_count_a) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
@@ -1180,7 +1186,7 @@ int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags
         C_HIP(r, hipMemsetAsync(c.p, 0, 8, r.stream));
         uint32_t grid = grid_blocks ? grid_blocks : PathTracing::grid_for((n + (uint32_t)atn::kChunkItems - 1u) / (uint32_t)atn::kChunkItems);
         hipLaunchKernelGGL(atn::k_compact_append, dim3(grid), dim3(256), 0, r.stream, (const int32_t*)fa.p, (const int32_t*)fb.p, n,
-                           oa.p, c.p, ob.p, c.p + 1);
+                           oa.p, c.p, ob.p, c.p + 1, binned);
         C_HIP(r, hipGetLastError());
         uint32_t hc[2] = { 0, 0 };
         C_HIP(r, hipMemcpyAsync(hc, c.p, 8, hipMemcpyDeviceToHost, r.stream));

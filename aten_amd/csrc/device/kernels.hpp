@@ -122,6 +122,57 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
     __syncthreads();    // sh is reused by the next chunk
 }
 
+// The same append with the chunk's entries written in BIN-major order inside the range the chunk reserves (still one
+// atomicAdd per queue and chunk).  k_shade bins next-bounce and shadow rays by direction octant: a trace wave reads 64
+// consecutive queue entries, i.e. a slice of one chunk's output, so its rays then come from one 16-tile screen region
+// AND point into the same octant -- they walk the tree through neighbouring records instead of 64 unrelated paths.
+// Queue order is free (all per-path state is indexed by slot, section 8 a26), so results are unchanged.
+// binsA/binsB: 3 bits per item (item k's bin at bits 3k..3k+2).  Positions inside a bin come from LDS atomics on 8
+// cursors -- a few hundred cycles per chunk against the ~30 K cycles the chunk's shading takes.
+#ifndef ATN_RAY_BINS
+#define ATN_RAY_BINS 1      /* measured: octant binning costs more in scattered path-state gathers than the walk gains */
+#endif
+constexpr uint32_t kRayBins = ATN_RAY_BINS;        // 1 = no binning (the plain append)
+struct BlockBinShared { uint32_t hist[2][8]; uint32_t start[2][8]; uint32_t base[2]; };
+
+template <class EntryFn>
+ATN_DEV void block_append2_binned(BlockBinShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA, uint32_t binsA,
+                                  uint32_t* qB, uint32_t* cntB, uint32_t flagsB, uint32_t binsB, EntryFn entry)
+{
+    if (threadIdx.x < 16u) sh.hist[threadIdx.x >> 3][threadIdx.x & 7u] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kChunkItems; k++) {
+        if ((flagsA >> k) & 1u) atomicAdd(&sh.hist[0][(binsA >> (3 * k)) & 7u], 1u);
+        if ((flagsB >> k) & 1u) atomicAdd(&sh.hist[1][(binsB >> (3 * k)) & 7u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        // exclusive prefix over the 8 bins of queue threadIdx.x, one global atomic for the whole chunk; the histogram
+        // cells become the bins' write cursors
+        const uint32_t q = threadIdx.x;
+        uint32_t run = 0;
+        for (int b = 0; b < 8; b++) { const uint32_t c = sh.hist[q][b]; sh.start[q][b] = run; run += c; sh.hist[q][b] = 0u; }
+        uint32_t* cnt = q ? cntB : cntA;
+        sh.base[q] = (run && cnt) ? atomicAdd(cnt, run) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kChunkItems; k++) {
+        if ((flagsA >> k) & 1u) {
+            const uint32_t b = (binsA >> (3 * k)) & 7u;
+            qA[sh.base[0] + sh.start[0][b] + atomicAdd(&sh.hist[0][b], 1u)] = entry(k);
+        }
+        if ((flagsB >> k) & 1u) {
+            const uint32_t b = (binsB >> (3 * k)) & 7u;
+            qB[sh.base[1] + sh.start[1][b] + atomicAdd(&sh.hist[1][b], 1u)] = entry(k);
+        }
+    }
+    __syncthreads();    // sh is reused by the next chunk
+}
+
+ATN_DEV uint32_t dir_octant(const f3& d) { return (d.x < 0.0F ? 1u : 0u) | (d.y < 0.0F ? 2u : 0u) | (d.z < 0.0F ? 4u : 0u); }
+
 ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
 {
     // wave reduction, one atomic per wave
@@ -185,6 +236,11 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
 // where the refill bookkeeping costs more than the idle lanes it removes).  The persistent kernels keep the treelet
 // -- the first sc.treelet_bytes of the node image -- in dynamic LDS (the launch passes that many bytes).
 extern __shared__ float4 atn_dyn_lds[];
+#ifdef ATN_TRACE_WPE
+#define ATN_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(ATN_TRACE_WPE, ATN_TRACE_WPE)))
+#else
+#define ATN_TRACE_ATTR
+#endif
 
 template <bool COUNT, bool REFILL, class Job>
 ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc)
@@ -251,6 +307,7 @@ template <bool SVGF>
 __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     __shared__ BlockAppendShared sh;
+    __shared__ BlockBinShared shb;
     const uint32_t count = pb.q_count[bounce];
     const uint32_t* __restrict__ q = pb.queue[bounce & 1];
     uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
@@ -259,12 +316,13 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
     const int items = fp.chunk_items;
     const uint32_t chunk_size = 256u * (uint32_t)items;
     for (uint32_t chunk = blockIdx.x * chunk_size; chunk < count; chunk += gridDim.x * chunk_size) {
-      uint32_t flags_next = 0, flags_shadow = 0;
+      uint32_t flags_next = 0, flags_shadow = 0, bins_next = 0, bins_shadow = 0;
 #pragma unroll 1
       for (int k = 0; k < items; k++) {
         const uint32_t j = chunk + (uint32_t)k * 256u + threadIdx.x;
         const bool valid = j < count;
         bool push_next = false, push_shadow = false;
+        uint32_t bin_next = 0, bin_shadow = 0;
         uint32_t slot = 0;
 
         if (valid) {
@@ -410,6 +468,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
                         pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, __int_as_float(li));
                         pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, 0.0F);
+                        bin_shadow = dir_octant(dirToLight);
                     }
 
                     // ---- ComputeRussianProbability, pathtracing_impl.h:680-698
@@ -447,6 +506,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
                         pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
                         push_next = (bounce + 1 < fp.max_depth);
+                        bin_next = dir_octant(nd);
                     }
                     // HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     push_shadow = shadow_active && !(flags & F_TERMINATED);
@@ -463,11 +523,15 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             }
         }
-        if (push_next) flags_next |= 1u << k;
-        if (push_shadow) flags_shadow |= 1u << k;
+        if (push_next) { flags_next |= 1u << k; bins_next |= bin_next << (3 * k); }
+        if (push_shadow) { flags_shadow |= 1u << k; bins_shadow |= bin_shadow << (3 * k); }
       }
-      block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow,
-                    [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; });
+      if (kRayBins > 1)
+          block_append2_binned(shb, qn, &pb.q_count[bounce + 1], flags_next, bins_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, bins_shadow,
+                               [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; });
+      else
+          block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow,
+                        [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; });
     }
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
 }
@@ -580,7 +644,7 @@ struct FusedJob {
 };
 
 template <bool REFILL, bool ALPHA>
-__global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
+__global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
@@ -748,22 +812,28 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
 // its next-bounce and shadow queues, same chunking (kChunkItems x 256 entries per block and atomic), grid-stride.
 // The queues come out UNORDERED (slot order is irrelevant to the renderer); atn_compact sorts them on the host
 // to present the stable contract of idaten::StreamCompaction::compact (StreamCompaction.cu:175-316).
+// binned != 0: the bin-major variant k_shade uses, entry i's bin = (flag - 1) & 7.
 __global__ void __launch_bounds__(256) k_compact_append(const int32_t* __restrict__ flags_a, const int32_t* __restrict__ flags_b, uint32_t n,
-                                                        uint32_t* out_a, uint32_t* cnt_a, uint32_t* out_b, uint32_t* cnt_b)
+                                                        uint32_t* out_a, uint32_t* cnt_a, uint32_t* out_b, uint32_t* cnt_b, int32_t binned)
 {
     __shared__ BlockAppendShared sh;
+    __shared__ BlockBinShared shb;
     for (uint32_t chunk = blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
-        uint32_t fa = 0, fb = 0;
+        uint32_t fa = 0, fb = 0, ba = 0, bb = 0;
 #pragma unroll
         for (int k = 0; k < kChunkItems; k++) {
             const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
             if (i < n) {
-                if (flags_a[i] > 0) fa |= 1u << k;
-                if (flags_b && flags_b[i] > 0) fb |= 1u << k;
+                if (flags_a[i] > 0) { fa |= 1u << k; ba |= ((uint32_t)(flags_a[i] - 1) & 7u) << (3 * k); }
+                if (flags_b && flags_b[i] > 0) { fb |= 1u << k; bb |= ((uint32_t)(flags_b[i] - 1) & 7u) << (3 * k); }
             }
         }
-        block_append2(sh, out_a, cnt_a, fa, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb,
-                      [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
+        if (binned)
+            block_append2_binned(shb, out_a, cnt_a, fa, ba, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb, bb,
+                                 [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
+        else
+            block_append2(sh, out_a, cnt_a, fa, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb,
+                          [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
     }
 }
 

@@ -147,7 +147,7 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
 #ifndef ATN_INNER_BURST
 #define ATN_INNER_BURST 4
 #endif
-constexpr int kInnerBurst = ATN_INNER_BURST;
+constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
 
 // One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
 // 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
@@ -161,7 +161,7 @@ constexpr int kInnerBurst = ATN_INNER_BURST;
 // are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form -- valid for all inputs
 // -- otherwise.  TREELET: records below sc.treelet_bytes are read from the block's LDS copy (`treelet`).
 // A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
-template <bool COUNT, bool TREELET, class Job>
+template <bool COUNT, bool TREELET, int BURST, class Job>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* treelet,
                             uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
 {
@@ -170,27 +170,26 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     // link is its miss link): a list that ends here ended on a MISS.
     const bool live = w.node != kLinkEnd;
 #pragma unroll 1
-    for (int k = 0; k < kInnerBurst; k++) {
+    for (int k = 0; k < BURST; k++) {
         if (!(w.node & kLinkTypeMask)) {
             const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
             float4 q0, q1;
             if (TREELET) {
-                // Straight-line: every lane reads BOTH sources (the LDS copy at its offset or at 0, the global image at
-                // its offset or at 0 -- the unused side of a lane is a broadcast read of record 0) and the results are
-                // merged with one v_bfi per dword.  With a branch per source and shared destination registers the
-                // compiler has to complete one side before it issues the other (it cannot see that the lanes are
-                // disjoint), which adds the two latencies; here all four loads are in flight together.
+                // The L1 (TCP) counts one access per ACTIVE lane and load, so the global loads are issued for the
+                // lanes outside the treelet only (exec-masked); the lanes inside read the block's LDS copy.  The two
+                // sides must land in DIFFERENT registers: with a shared destination the compiler completes one side
+                // before it issues the other (it cannot see that the lanes are disjoint) and the latencies add up.
+                // The empty asm keeps the LDS values live in their own registers while the global loads are in flight.
                 const bool in_lds = off < treelet_bytes;
-                const uint32_t m = in_lds ? 0xffffffffu : 0u;
-                const uint32_t loff = off & m, goff = off & ~m;
-                const uint4 l0 = *reinterpret_cast<const uint4*>(treelet + loff);
-                const uint4 l1 = *reinterpret_cast<const uint4*>(treelet + loff + 16u);
-                const uint4 g0 = *reinterpret_cast<const uint4*>(nb + goff);
-                const uint4 g1 = *reinterpret_cast<const uint4*>(nb + goff + 16u);
-                q0 = make_float4(__uint_as_float((l0.x & m) | (g0.x & ~m)), __uint_as_float((l0.y & m) | (g0.y & ~m)),
-                                 __uint_as_float((l0.z & m) | (g0.z & ~m)), __uint_as_float((l0.w & m) | (g0.w & ~m)));
-                q1 = make_float4(__uint_as_float((l1.x & m) | (g1.x & ~m)), __uint_as_float((l1.y & m) | (g1.y & ~m)),
-                                 __uint_as_float((l1.z & m) | (g1.z & ~m)), __uint_as_float((l1.w & m) | (g1.w & ~m)));
+                float4 g0, g1;      // deliberately not initialised: only the lanes that load them select them
+                if (!in_lds) { g0 = ld16(nb, off); g1 = ld16(nb, off + 16u); }
+                const uint32_t loff = in_lds ? off : 0u;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f l0 = *reinterpret_cast<const v4f*>(treelet + loff);
+                v4f l1 = *reinterpret_cast<const v4f*>(treelet + loff + 16u);
+                asm volatile("" : "+v"(l0), "+v"(l1));
+                q0 = make_float4(in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w);
+                q1 = make_float4(in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w);
             }
             else {
                 q0 = ld16(nb, off);
@@ -257,31 +256,77 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     if (__any(ended || at_tlas) || !all_finite) all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
 }
 
-// Plain flavour: one ray per lane for the lifetime of its walk, the wave moves on to its next 64 jobs when all of its
-// lanes have finished (small trees and small launches, where the refill bookkeeping costs more than the idle lanes).
+// Plain flavour: one ray per lane for the lifetime of its walk, grid-stride over the jobs; every iteration offers every
+// node kind.  Without refill a wave lasts as long as its longest ray, so what counts here is the latency of a single
+// walk, and making lanes wait at leaves for the end of a burst (walk_iteration) only lengthens it: measured on MI355X
+// with the burst form, Cornell 1080p 1.85 -> 2.08 ms per frame and sponza_lod forced onto this flavour 6.24 -> 7.17 ms.
+// Used for small trees and small launches, where the refill bookkeeping costs more than the idle lanes it removes.
 template <bool COUNT, class Job>
 ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u;      // the wave's first job: wave-uniform loop bound
-    const uint32_t lane = threadIdx.x & 63u;
-    Walk w;
-    slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
-    w.ray = w.wray;
-    w.node = kLinkEnd;
-    for (uint32_t base = first; base < count; base += stride) {
-        const uint32_t j = base + lane;
-        if (j < count) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        Walk w;
+        {
             float4 a, b;
             float stop_t;
             job.fetch(j, a, b, stop_t);
             walk_start(w, sc, a, b, stop_t);
         }
-        bool all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
-        while (__any(w.node != kLinkEnd))
-            walk_iteration<COUNT, false>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
+        while (w.node != kLinkEnd) {
+            const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
+            const float4 q0 = ld16(nb, off);
+            const float4 q1 = ld16(nb, off + 16u);
+            if (COUNT) cnt->nodes++;
+            bool is_hit;
+            if (!(w.node & kLinkTypeMask)) {
+                // inner node, or a dead leaf (both links = its miss link).  An inner record's hit link is never kLinkEnd
+                // (checked at upload), so a list can only end here on a miss.
+                const bool box = w.ray.finite ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                              : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+                w.node = __float_as_int(box ? q0.w : q1.w);
+                is_hit = false;
+            }
+            else if (w.node & kLinkLeafBit) {
+                const float4 q2 = ld16(nb, off + 32u);
+                if (COUNT) cnt->tris++;
+                bool accept; float t;
+                is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
+                w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
+                if (accept && t <= w.stop_t) { w.node = kLinkEnd; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd; }    // see Job::fetch
+            }
+            else {
+                // TLAS leaf with a nested tree
+                w.objid = __float_as_int(q0.x);
+                const int32_t w2l = __float_as_int(q0.y);
+                w.meshid = __float_as_int(q1.x);
+                w.top_hit = __float_as_int(q1.y);
+                w.top_miss = __float_as_int(q1.z);
+                if (w2l >= 0) {
+                    // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
+                    m4 m;
+                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
+                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                    const f3 o = m4_apply(m, w.wray.org);
+                    const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
+                    slab_setup(w.ray, o, d);
+                }
+                else {
+                    w.ray = w.wray;
+                }
+                is_hit = true;
+                w.node = __float_as_int(q0.z);      // BLAS root link
+            }
+            if (w.node == kLinkEnd) {
+                // leave the bottom layer (top_* are kLinkEnd inside the top layer)
+                w.node = is_hit ? w.top_hit : w.top_miss;
+                w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+                w.ray = w.wray;
+            }
+        }
+        job.finish(w.payload, w.hit, w.hit.objid >= 0);
     }
 }
 
@@ -377,7 +422,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        walk_iteration<COUNT, (kTreeletMaxBytes > 0)>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
+        walk_iteration<COUNT, (kTreeletMaxBytes > 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
     }
 }
 

@@ -78,6 +78,7 @@ public:
     DevBuf<DevMaterial> materials;
     DevBuf<atn_light_param> lights;
     DevBuf<DevTexture> textures;
+    DevBuf<uint32_t> texels8;
     DevScene scene{};
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
@@ -169,12 +170,13 @@ public:
         ATN_HIP(materials.upload(img.materials, stream));
         ATN_HIP(lights.upload(img.lights, stream));
         ATN_HIP(texels.upload(img.texels, stream));
+        ATN_HIP(texels8.upload(img.texels8, stream));
         ATN_HIP(textures.upload(img.textures, stream));
         ATN_HIP(hipStreamSynchronize(stream));      // `img` is pageable host memory
         scene = img.params;
         scene.nodes = nodes.p; scene.tris = tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p;
-        scene.lights = lights.p; scene.texels = texels.p; scene.textures = textures.p;
+        scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         has_scene = true;
         list_root_link = img.list_root_link;
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)

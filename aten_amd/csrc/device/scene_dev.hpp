@@ -55,10 +55,14 @@ struct DevMaterial {
 };
 static_assert(sizeof(DevMaterial) == 80, "DevMaterial");
 
+// A texture whose every channel value is EXACTLY k / 255.0f -- or exactly k * (1.0f / 255), aten::Image::Load's form
+// (image/image.cpp:76-80) -- for an integer k in 0..255, i.e. an 8-bit image the caller converted with one IEEE operation,
+// is stored as packed RGBA8 and converted back with the same operation on fetch -- bit-identical values at a quarter of the bytes (sponza_lod: 50 MB of float4 texels -> 12.5 MB, 32 texels
+// per 128-byte line instead of 8).  Anything else (HDR environment maps, filtered images) stays float4.
 struct DevTexture {
-    uint32_t offset;    // first texel in `texels`
+    uint32_t offset;    // first texel in `texels` (format 0) or `texels8` (format 1)
     int32_t width, height;
-    int32_t _pad;
+    int32_t format;     // 0 = float4, 1 = RGBA8 decoded as k / 255.0f, 2 = RGBA8 decoded as k * (1.0f / 255)
 };
 
 struct DevScene {
@@ -71,6 +75,7 @@ struct DevScene {
     const DevMaterial* materials;
     const atn_light_param* lights;
     const float4* texels;
+    const uint32_t* texels8;            // packed r | g << 8 | b << 16 | a << 24
     const DevTexture* textures;
     int32_t n_lights;
     int32_t n_textures;

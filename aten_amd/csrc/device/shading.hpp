@@ -79,7 +79,16 @@ ATN_DEV float4 sample_texture(const DevScene& sc, int32_t texid, float u, float 
     const int32_t iv = (int32_t)(v * (float)(t.height - 1));
     const int32_t x = wrap_repeat(iu, t.width - 1);
     const int32_t y = wrap_repeat(iv, t.height - 1);
-    return sc.texels[t.offset + (uint32_t)(y * t.width + x)];
+    const uint32_t idx = t.offset + (uint32_t)(y * t.width + x);
+    if (t.format) {
+        // the same IEEE operation the caller's 8-bit -> float conversion made (which one: checked per texel at upload)
+        const uint32_t p = sc.texels8[idx];
+        const float r = (float)(p & 255u), g = (float)((p >> 8) & 255u), b = (float)((p >> 16) & 255u), a = (float)(p >> 24);
+        if (t.format == 1) return make_float4(r / 255.0F, g / 255.0F, b / 255.0F, a / 255.0F);
+        const float norm = 1.0F / 255;
+        return make_float4(r * norm, g * norm, b * norm, a * norm);
+    }
+    return sc.texels[idx];
 }
 
 // applyNormalMap, material/sample_texture.h:62-87

@@ -22,6 +22,7 @@ struct HostSceneImage {
     std::vector<DevMaterial> materials;
     std::vector<atn_light_param> lights;
     std::vector<float4> texels;
+    std::vector<uint32_t> texels8;
     std::vector<DevTexture> textures;
     DevScene params{};                  // scalar fields filled; pointers left null
     uint64_t n_inner = 0, n_tri_leaf = 0, n_tlas_leaf = 0;
@@ -322,17 +323,44 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         img.materials.push_back(d);
     }
     img.lights.assign(s->lights, s->lights + s->n_lights);
+    // textures: RGBA8 where every channel of every texel is exactly k / 255.0f (DevTexture), float4 otherwise
     img.textures.resize(s->n_textures);
-    size_t ntex = 0;
-    for (uint32_t i = 0; i < s->n_textures; i++) ntex += (size_t)s->textures[i].width * s->textures[i].height;
-    img.texels.resize(ntex);
-    size_t toff = 0;
+    img.texels.clear(); img.texels8.clear();
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const atn_texture_desc& t = s->textures[i];
-        img.textures[i].offset = (uint32_t)toff; img.textures[i].width = t.width; img.textures[i].height = t.height; img.textures[i]._pad = 0;
         const size_t n = (size_t)t.width * t.height;
-        for (size_t j = 0; j < n; j++) img.texels[toff + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
-        toff += n;
+        // which 8-bit -> float conversion reproduces EVERY channel of EVERY texel?  1: k / 255.0f,  2: k * (1.0f / 255)
+        // (aten::Image::Load multiplies by `norm = 1.0F / 255`, image/image.cpp:76-80)
+        int32_t fmt = 0;
+        const size_t at8 = img.texels8.size();
+        for (int32_t cand = 1; cand <= 2 && !fmt && n > 0; cand++) {
+            auto decode = [cand](uint32_t k) { return cand == 1 ? (float)k / 255.0F : (float)k * (1.0F / 255); };
+            auto code = [&](float v, uint32_t& k) {
+                if (!(v >= 0.0F && v <= 1.0F)) return false;
+                k = (uint32_t)(v * 255.0F + 0.5F);
+                return k <= 255u && decode(k) == v;
+            };
+            img.texels8.resize(at8 + n);
+            bool ok = true;
+            for (size_t j = 0; j < n && ok; j++) {
+                uint32_t r = 0, g = 0, b = 0, a = 0;
+                ok = code(t.texels[j].x, r) && code(t.texels[j].y, g) && code(t.texels[j].z, b) && code(t.texels[j].w, a);
+                img.texels8[at8 + j] = r | (g << 8) | (b << 16) | (a << 24);
+            }
+            if (ok) fmt = cand;
+        }
+        const bool unorm8 = fmt != 0;
+        img.textures[i].width = t.width; img.textures[i].height = t.height;
+        if (unorm8) {
+            img.textures[i].offset = (uint32_t)at8; img.textures[i].format = fmt;
+        }
+        else {
+            img.texels8.resize(at8);
+            const size_t at = img.texels.size();
+            img.textures[i].offset = (uint32_t)at; img.textures[i].format = 0;
+            img.texels.resize(at + n);
+            for (size_t j = 0; j < n; j++) img.texels[at + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
+        }
     }
 
     DevScene& p = img.params;

@@ -37,20 +37,34 @@ def algorithmic_bytes(nodes, tris, rays):
     return 48 * nodes + 80 * tris + 56 * rays
 
 
-def measured_traffic(scene, w, h, kernel="k_trace_closest"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*traffic.json,
-    written from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); None when
-    no profile matches the workload."""
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, MI355X_MICROARCH.md (L2 section)
+
+
+def profile_counters(scene, w, h, spp, depth, svgf):
+    """Per-launch PMC averages of this workload's kernels from the committed passes (profiles/*counters*.json, written by
+    tools/pmc_to_json.py from `rocprofv3 --pmc` runs of this same command): bench.py cannot collect PMC counters itself
+    (they need the profiler around the process), so the fractions below combine those counters with the launch
+    durations measured live here.  None when no committed profile matches the workload."""
     import glob
+    tag = "%s %dx%d %dspp %d-bounce%s" % (scene, w, h, spp, depth, " svgf" if svgf else "")
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*counters*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if scene in d.get("workload", "") and ("%dx%d" % (w, h)) in d.get("workload", "") and d.get("kernel", "").startswith(kernel):
-            best = d
+        if d.get("workload", "") == tag:
+            best = (os.path.relpath(f, ROOT), d)
     return best
+
+
+def kernel_entry(counters, prefix):
+    if not counters:
+        return None
+    for k, e in counters[1]["kernels"].items():
+        if k.startswith(prefix):
+            return e
+    return None
 
 
 def usable_cpus():
@@ -245,21 +259,32 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     r.reset()
-    r.reset_kernel_times()
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, True)
+        step(i, False)      # the timed region carries no instrumentation: no event records, no counters
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ktimes = r.kernel_times()
     final_img = None
     if args.dump and rank == 0:
         final_img = full.cpu().numpy() if use_dist else r.download_film()
+
+    # the same K frames once more with every launch bracketed by HIP events on the stream it runs on: per-kernel
+    # durations of the timed workload, measured live (the events cost ~2 % of a frame, which is why `value` is not
+    # taken from this region)
+    r.reset()
+    r.reset_kernel_times()
+    sync_all()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    sync_all()
+    elapsed_events = time.perf_counter() - t1
+    ktimes = r.kernel_times()
 
     ms_per_step = 1e3 * elapsed / args.steps
     mrays = W * H * spp / 1e6 / (elapsed / args.steps)
@@ -292,40 +317,85 @@ def main():
     r.set_path_batches(3)
 
     frames_prof = args.steps
+    kernel_count_batches = max(1, round(ktimes["gen_path"][1] / max(frames_prof * spp, 1)))
     if ktimes["trace_fused"][1]:
         # the frame's trace work runs as depth + 1 launches of k_trace_fused (shadow rays of bounce b + closest-hit
         # rays of bounce b + 1): that kernel is the dominant one
         dominant, tkey = "k_trace_fused", "trace_fused"
-        bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"] + per_frame["shadow_nodes"],
-                                            per_frame["closest_tris"] + per_frame["shadow_tris"],
-                                            per_frame["closest_rays"] + per_frame["shadow_rays"])
+        nodes = per_frame["closest_nodes"] + per_frame["shadow_nodes"]
+        tris = per_frame["closest_tris"] + per_frame["shadow_tris"]
+        rays = per_frame["closest_rays"] + per_frame["shadow_rays"]
     else:
         dominant, tkey = "k_trace_closest", "trace_closest"
-        bytes_per_frame = algorithmic_bytes(per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"])
+        nodes, tris, rays = per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"]
+    bytes_per_frame = algorithmic_bytes(nodes, tris, rays)
+    own_bytes_per_frame = 32 * (nodes - tris) + 48 * tris + 56 * rays       # this layout: 32-B inner records, 48-B leaf records
     tc_ms, tc_n = ktimes[tkey]
-    launches_per_frame = tc_n / max(frames_prof, 1)
+    launches_per_frame = max(tc_n / max(frames_prof, 1), 1)
     avg_launch_ms = tc_ms / max(tc_n, 1)
-    achieved = (bytes_per_frame / max(launches_per_frame, 1)) / (avg_launch_ms * 1e-3) / 1e9 if tc_n else 0.0
-    tr = measured_traffic({"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene], W, H, dominant) if world == 1 else None
+    avg_launch_s = max(avg_launch_ms * 1e-3, 1e-12)
+    scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene]
+    prof = profile_counters(scene_tag, W, H, spp, depth, args.svgf) if world == 1 else None
+    pk = kernel_entry(prof, dominant)
+    # Three candidate roofs for the dominant kernel, each a fraction <= 1 of a hardware limit; `bound` names the
+    # largest, `frac` is that fraction.  HBM and L2 bytes and the VALU counters come from the committed PMC passes of
+    # this workload (per launch), the duration from the HIP events above.
+    fractions = {}
+    if pk:
+        if "hbm_bytes" in pk:
+            fractions["hbm"] = pk["hbm_bytes"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        if "l2_bytes_max" in pk:
+            fractions["l2"] = pk["l2_bytes_max"] / avg_launch_s / 1e9 / L2_PEAK_GBS
+        if "valu_busy" in pk:
+            # issue slots are per cycle: rescale the profiled run's busy fraction by the duration ratio
+            prof_ms = pk["cycles"] / 2.4e6
+            fractions["valu"] = pk["valu_busy"] * (prof_ms / avg_launch_ms) if avg_launch_ms > 0 else pk["valu_busy"]
+    bound = max(fractions, key=fractions.get) if fractions else "hbm"
+    units = {"hbm": ("GB/s", HBM_PEAK_GBS), "l2": ("GB/s", L2_PEAK_GBS), "valu": ("VALU issue slots busy", 1.0)}
+    frac = fractions.get(bound)
     roofline = {
-        "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": tr["traffic_bytes_per_launch"] if tr else None,
-        "traffic_source": tr["source"] if tr else None,
-        "pmc": tr.get("pmc") if tr else None,
+        "kernel": dominant, "bound": bound,
+        "achieved": round(frac * units[bound][1], 3) if frac is not None else None, "peak": units[bound][1], "unit": units[bound][0],
+        "frac": round(frac, 4) if frac is not None else None,
+        "traffic": pk.get("hbm_bytes") if pk else None,
+        "fractions": {k: round(v, 4) for k, v in fractions.items()},
         "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
-        "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
-        "note": "scene (%.1f MB nodes) is L2/MALL-resident: the HBM roofline is not the binding limit; see DESIGN.md" % (sum(len(n) for n in fs.arrays["bvh_lists"]) * 48 / 1e6),
+        "algorithmic": {"bytes_per_launch": round(bytes_per_frame / launches_per_frame),
+                        "GBps": round(bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
+                        "bytes_per_launch_this_layout": round(own_bytes_per_frame / launches_per_frame),
+                        "GBps_this_layout": round(own_bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
+                        "note": "SURVEY 8(d): 48 B per node visit + 80 B per triangle test + 56 B per ray (reference layout); "
+                                "this layout reads 32 B per inner visit and 48 B per leaf visit.  A rate, not a fraction of a roof: "
+                                "the records are served by L1/L2"},
+        "pmc": ({"file": prof[0], "lane_utilisation": pk.get("lane_utilisation"), "l1_hit_rate": pk.get("l1_hit_rate"),
+                 "l2_hit_rate": pk.get("l2_hit_rate"), "l1_stall": pk.get("l1_stall"), "valu_busy_profiled": pk.get("valu_busy"),
+                 "valu_useful": round(pk["valu_busy"] * pk["lane_utilisation"], 4) if pk.get("lane_utilisation") and pk.get("valu_busy") else None,
+                 "avg_launch_ms_profiled": round(pk["cycles"] / 2.4e6, 5) if pk.get("cycles") else None} if pk else None),
+        "note": "fractions: hbm = (FETCH_SIZE*2 + WRITE_SIZE) / t / 8 TB/s; l2 = TCC_REQ*128 B / t / 34.5 TB/s (upper bound); "
+                "valu = SQ_ACTIVE_INST_VALU / 256 CUs / cycles (rocprofiler's VALUBusy); formulas in DESIGN.md section 6",
     }
-    te_ms, te_n = ktimes_excl[tkey]
-    excl_launch_ms = te_ms / max(te_n, 1)
-    excl_bytes = bytes_per_frame / max(te_n / max(n_excl, 1), 1)
-    roofline["isolated"] = {"avg_launch_ms": round(excl_launch_ms, 5), "launches": te_n,
-                            "algorithmic_bytes_per_launch": round(excl_bytes),
-                            "achieved": round(excl_bytes / (excl_launch_ms * 1e-3) / 1e9, 2) if te_n else None,
-                            "frac": round(excl_bytes / (excl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if te_n else None,
-                            "note": "same frames, atn_set_path_batches(1): one kernel in flight at a time"}
-    roofline["note"] += "; in the timed region up to 3 batches of the frame run on separate streams, so avg_launch_ms is the duration of a launch that shares the GPU with other kernels"
+    # k_shade: the one kernel with material HBM traffic.  Compulsory bytes = the path state it must read and write once
+    # per queue entry (80 B in: queue entry, ray, hit, throughput, seed; 16 B throughput out; per hit the next ray 32 B,
+    # the shadow ray 48 B and two queue entries 8 B; per miss the contribution read-modify-write 32 B).
+    sh_ms, sh_n = ktimes["shade"]
+    sk = kernel_entry(prof, "k_shade")
+    shade = None
+    if sh_n:
+        sh_launch_s = sh_ms * 1e-3 / sh_n
+        entries, hits = per_frame["closest_rays"], per_frame["hits"]
+        comp = (96 * entries + 88 * hits + 32 * (entries - hits)) / max(sh_n / max(frames_prof, 1), 1)
+        shade = {"kernel": "k_shade", "bound": "hbm", "avg_launch_ms": round(sh_launch_s * 1e3, 5), "launches": sh_n,
+                 "compulsory_bytes_per_launch": round(comp),
+                 "compulsory_GBps": round(comp / sh_launch_s / 1e9, 1),
+                 "traffic": sk.get("hbm_bytes") if sk else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "achieved": round(sk["hbm_bytes"] / sh_launch_s / 1e9, 1) if sk and "hbm_bytes" in sk else None,
+                 "frac": round(sk["hbm_bytes"] / sh_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sk and "hbm_bytes" in sk else None,
+                 "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None}
+    roofline["shade"] = shade
+    if ktimes_excl[tkey][1] and kernel_count_batches > 1:
+        te_ms, te_n = ktimes_excl[tkey]
+        roofline["isolated_avg_launch_ms"] = round(te_ms / te_n, 5)
+        roofline["note"] += "; the frame runs as %d batches on separate streams, avg_launch_ms is the duration of a launch that shares the GPU (isolated_avg_launch_ms: one kernel in flight at a time)" % kernel_count_batches
     kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
     kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
     svgf_info = None
@@ -347,9 +417,11 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc     # the cpu_baseline leg is the only place bench.py touches oracle/
-        # bounded sample of the same workload: same scene / camera / seeds at 1/3 linear resolution
-        cw, ch = max(W // 3, 8), max(H // 3, 8)
-        if args.scene == "atrium":
+        # bounded sample of the same workload: the benchmarked frame itself (same scene / camera / seeds / size) when a
+        # CPU frame takes seconds (1080p 1 spp: ~1.2 s with 16 threads); 1/6 linear resolution for the 4K 8-spp config,
+        # whose full frame would take minutes
+        cw, ch = W, H
+        if W * H * spp > 4 * 1920 * 1080:
             cw, ch = max(W // 6, 8), max(H // 6, 8)
         ccam = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], cw, ch)
         cseeds = orc.init_sampler(cw, ch, 0)
@@ -376,10 +448,10 @@ def main():
             return float(np.median(ts)), len(ts)
 
         n_cpu = usable_cpus()
-        med, nfr = cpu_median(n_cpu, 5, 20.0)
-        med8, nfr8 = cpu_median(8, 2, 10.0)     # the reference app's own setting (host_renderer/main.cpp:18-23,271)
+        med, nfr = cpu_median(n_cpu, 5, 16.0)
+        med8, nfr8 = cpu_median(8, 2, 8.0)      # the reference app's own setting (host_renderer/main.cpp:18-23,271)
         cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": n_cpu, "logical_cpus": orc.lib().orc_num_procs(),
-                        "kind": "port", "sample": "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
+                        "kind": "port", "sample": ("the benchmarked frame itself: " if (cw, ch) == (W, H) else "reduced frame: ") + "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
                         "ms_per_frame_sample": round(1e3 * med, 2),
                         "value_8_threads": round(cw * ch * spp / 1e6 / med8, 4), "frames_8_threads": nfr8}
 
@@ -391,7 +463,8 @@ def main():
             "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5) and not args.svgf)
             else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",

@@ -289,6 +289,7 @@ public:
         const uint32_t n_tiles = (uint32_t)tx * ty;
         const uint32_t tiles_per_rank = (n_tiles + world - 1) / world;
         const uint32_t slots = tiles_per_rank * 64;
+        if (slots > kShadowSlotMask) return fail(ATN_ERR_UNSUPPORTED, "more than 2^26 path slots per GPU (shard the screen)");
         if (slots != n_slots) {
             ATN_HIP(ray_o.resize(slots)); ATN_HIP(ray_d.resize(slots)); ATN_HIP(thr.resize(slots));
             ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots)); ATN_HIP(isect2.resize(slots));

@@ -16,6 +16,8 @@
 namespace atn {
 
 constexpr uint32_t F_TERMINATED = 1u, F_SINGULAR = 2u, F_HIT = 4u;
+constexpr uint32_t kShadowSlotMask = (1u << 26) - 1u;      // shadow-job payload: slot bits (ShadowJob)
+constexpr uint32_t kShadowStencilFlag = 0x40000000u;      // in sh_d.w next to the light index: the shaded surface's material is StencilType::ALWAYS
 constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.last_hit_mtrl_idx names a Specular material
 
 struct PathBuffers {
@@ -269,10 +271,11 @@ struct ClosestJob {
         a = make_float4(ro.x, ro.y, ro.z, kInf);
         b = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
     }
-    ATN_DEV void finish(uint32_t slot, const Hit& h, bool) const
+    ATN_DEV bool finish(uint32_t slot, const Hit& h, bool, float4&, float4&, float&) const
     {
         pb.isect[slot] = make_float4(h.t, h.a, h.b, __int_as_float(h.tri));
         pb.isect2[slot] = make_int2(h.objid, h.meshid);
+        return false;
     }
 };
 
@@ -466,7 +469,9 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                             shadow_active = true;
                         }
                         pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
-                        pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, __int_as_float(li));
+                        // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
+                        pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z,
+                                                    __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)));
                         pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, 0.0F);
                         bin_shadow = dir_octant(dirToLight);
                     }
@@ -539,8 +544,16 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 // HitShadowRay -> HitTestToTargetLight -> scene::hitLight
 // (pathtracing_impl.h:266-393, scene/scene.h:64-134): closest hit toward the light, visible iff
 // the hit object IS the light object (or nothing is hit / infinite / singular rules).
-// ALPHA = false compiles the alpha-translucency rule out: chosen by the host when no uploaded material can have
-// alpha < 1 (DevScene::any_alpha == 0), which takes evaluate_hit + a texture fetch -- and their registers -- out of the walk.
+// ALPHA = false compiles the "ignored hit" rules (alpha translucency, stencil) out: chosen by the host when no uploaded
+// material can be ignored (DevScene::any_alpha == 0), which takes evaluate_hit + a texture fetch -- and their registers
+// -- out of the walk.
+//
+// Lookups (HitTestToTargetLight's loop, pathtracing_impl.h:295-336): a hit on an alpha-translucent surface -- or, when
+// the SHADED surface's material has StencilType::ALWAYS, on a STENCIL surface -- is ignored and the ray restarts behind
+// it, up to 10 times when scene_rendering_config.enable_alpha_blending is set or the stencil check applies, ONCE
+// otherwise (the ray then simply counts as blocked).  A restart re-uses the lane: finish() returns true with the new
+// ray.  Payload bits: 0-25 slot, 26 "an ignored hit was the light object", 27-30 lookups done, 31 (FusedJob) shadow.
+
 template <bool ALPHA>
 struct ShadowJob {
     PathBuffers pb;
@@ -556,41 +569,71 @@ struct ShadowJob {
         // spot light it is `hit.t > distToLight`: the walk's t_max caps only box tests, so a triangle BEHIND the light
         // can be accepted first (triangle hits are accepted against isect.t = inf, threaded_bvh_traverser.h:236-262)
         // while the closest hit is a nearer blocker -- only an accepted hit with t <= distToLight settles it early.
-        const atn_light_param* lp = &sc.lights[__float_as_int(sd.w)];
+        const uint32_t lbits = __float_as_uint(sd.w);
+        const atn_light_param* lp = &sc.lights[lbits & 0xffffffu];
         const bool has_obj = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
         // (a light with neither object nor attribute is visible iff nothing is hit, like an infinite one)
         const bool near_only = (lp->attrib & ATN_LIGHT_ATTR_SINGULAR) && !(lp->attrib & ATN_LIGHT_ATTR_INFINITE);
         stop_t = has_obj ? -kInf : (near_only ? so.w : kInf);
+        // with more than one lookup an ignored hit restarts the ray BEHIND it, so it has to be the closest one
+        if (ALPHA && sc.any_alpha && (sc.enable_alpha_blending || (lbits & kShadowStencilFlag))) stop_t = -kInf;
         a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)
         b = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
     }
-    ATN_DEV void finish(uint32_t slot, const Hit& h, bool isHit) const
+    ATN_DEV bool finish(uint32_t payload, const Hit& h, bool isHit, float4& ra, float4& rb, float& rstop) const
     {
-        const float distToLight = pb.sh_o[slot].w;
-        const int32_t li = __float_as_int(pb.sh_d[slot].w);
-        const atn_light_param* lp = &sc.lights[li];
+        const uint32_t slot = payload & kShadowSlotMask;
+        const uint32_t lookups = (payload >> 27) & 15u;
+        const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
+        const float distToLight = so.w;
+        const uint32_t lbits = __float_as_uint(sd.w);
+        const atn_light_param* lp = &sc.lights[lbits & 0xffffffu];
         const int32_t ltype = lp->type, lobj = lp->arealight_objid;
         const uint32_t lattr = lp->attrib;
         const int32_t lightobj = (ltype == ATN_LIGHT_AREA && lobj >= 0) ? lobj : -1;
-        const int32_t hitobj = isHit ? h.objid : lightobj;
+        // `hitobj` survives ignored hits (the reference keeps the pointer across lookups, :291,309): after a miss it is
+        // the last ignored object, or the light object if nothing was ever hit
+        const bool same_obj = isHit ? h.objid == lightobj : (lookups == 0u || (payload & (1u << 26)) != 0u);
         bool visible;
-        if (hitobj == lightobj) visible = true;
+        if (same_obj) visible = true;
         else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
         else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
         else visible = false;
-        if (ALPHA && sc.any_alpha && isHit && visible) {
-            // (every other hit already means "not visible", whatever its alpha; and a walk that stopped early --
-            // ShadowJob::fetch -- is never `visible`, so `h` is the exact closest hit here)
-            // material::isTranslucentByAlpha hit (material.cpp:193-210): "ignored", and with a lookup budget of one
-            // (no alpha blending / stencil) the shadow ray then counts as blocked (pathtracing_impl.h:295-336).
-            // Only materials flagged at upload can have alpha < 1.
-            const int32_t mid = sc.tris[h.tri].mtrlid;
-            if (mid >= 0 && (sc.materials[mid].attrib & kAttrMaybeAlpha)) {
-                HitRec rec;
-                evaluate_hit(rec, sc, h.objid, h.tri, h.a, h.b);
-                const DevMaterial& hm = sc.materials[mid];
-                const float4 albedo = sample_texture(sc, hm.albedoMap, rec.u, rec.v, make_float4(1.0F, 1.0F, 1.0F, 1.0F));
-                if (albedo.w * hm.baseColor.w < 1.0F) return;
+        if (ALPHA && sc.any_alpha && isHit) {
+            const bool need_stencil = (lbits & kShadowStencilFlag) != 0u;
+            const uint32_t max_lookups = (sc.enable_alpha_blending || need_stencil) ? 10u : 1u;
+            // With a budget of one an ignored hit just means "blocked", which every hit that is not `visible` means
+            // anyway: only then is the material worth a look.  (A walk that stopped early -- fetch -- is never
+            // `visible` and has a budget of one, so `h` is the exact closest hit whenever it matters.)
+            if (visible || max_lookups > 1u) {
+                const int32_t mid = sc.tris[h.tri].mtrlid;
+                const uint32_t mattr = mid >= 0 ? sc.materials[mid].attrib : 0u;
+                bool ignore = need_stencil && (mattr & kAttrStencilStencil);
+                f3 hit_p = mk3(0.0F), hit_n = mk3(0.0F, 1.0F, 0.0F);
+                if (ignore || (mattr & kAttrMaybeAlpha)) {
+                    HitRec rec;
+                    evaluate_hit(rec, sc, h.objid, h.tri, h.a, h.b);
+                    hit_p = rec.p; hit_n = rec.normal;
+                    if (mattr & kAttrMaybeAlpha) {
+                        // material::isTranslucentByAlpha (material.cpp:193-210); only flagged materials can have alpha < 1
+                        const DevMaterial& hm = sc.materials[mid];
+                        const float4 albedo = sample_texture(sc, hm.albedoMap, rec.u, rec.v, make_float4(1.0F, 1.0F, 1.0F, 1.0F));
+                        if (albedo.w * hm.baseColor.w < 1.0F) ignore = true;
+                    }
+                }
+                if (ignore) {
+                    if (lookups + 1u >= max_lookups) return false;      // budget spent: is_hit_to_light stays false
+                    // r = ray(rec.p, original_ray.dir, normal facing along the ray), :319-330
+                    const f3 odir = normalize(mk3(sd));
+                    const bool is_same_facing = dot(hit_n, odir) > 0.0F;
+                    const f3 on = is_same_facing ? hit_n : -hit_n;
+                    const f3 o = ray_offset(hit_p, on);
+                    const f3 d = normalize(odir);
+                    ra = make_float4(o.x, o.y, o.z, distToLight - kEps);
+                    rb = make_float4(d.x, d.y, d.z, __uint_as_float(slot | ((lookups + 1u) << 27) | (h.objid == lightobj ? (1u << 26) : 0u)));
+                    rstop = -kInf;
+                    return true;
+                }
             }
         }
         if (visible) {
@@ -598,6 +641,7 @@ struct ShadowJob {
             const float4 lc = pb.sh_c[slot];
             pb.contrib[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
         }
+        return false;
     }
 };
 
@@ -636,10 +680,14 @@ struct FusedJob {
             c.fetch(j - n_shadow, a, b, stop_t);
         }
     }
-    ATN_DEV void finish(uint32_t payload, const Hit& h, bool is_hit) const
+    ATN_DEV bool finish(uint32_t payload, const Hit& h, bool is_hit, float4& ra, float4& rb, float& rstop) const
     {
-        if (payload & 0x80000000u) s.finish(payload & 0x7fffffffu, h, is_hit);
-        else c.finish(payload, h, is_hit);
+        if (payload & 0x80000000u) {
+            const bool again = s.finish(payload & 0x7fffffffu, h, is_hit, ra, rb, rstop);
+            if (again) rb.w = __uint_as_float(__float_as_uint(rb.w) | 0x80000000u);
+            return again;
+        }
+        return c.finish(payload, h, is_hit, ra, rb, rstop);
     }
 };
 
@@ -741,7 +789,7 @@ struct BatchJob {
         a = make_float4(r.org[0], r.org[1], r.org[2], t_max);
         b = make_float4(r.dir[0], r.dir[1], r.dir[2], __uint_as_float(j));
     }
-    ATN_DEV void finish(uint32_t j, const Hit& h, bool) const
+    ATN_DEV bool finish(uint32_t j, const Hit& h, bool, float4&, float4&, float&) const
     {
         atn_intersection o;
         o.t = h.t; o.objid = h.objid; o.tri_id = h.tri; o.a = h.a; o.b = h.b; o.isVoxel = 0;
@@ -752,6 +800,7 @@ struct BatchJob {
             o.meshid = tp.mesh_id < 0 ? h.meshid : tp.mesh_id;     // threaded_bvh_traverser.h:206-209
         }
         out[j] = o;
+        return false;
     }
 };
 

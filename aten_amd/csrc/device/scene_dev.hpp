@@ -38,6 +38,8 @@ constexpr uint32_t kTreeletMaxBytes = ATN_TREELET_BYTES;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
 constexpr uint32_t kAttrIdealRefraction = 0x10000u;   // MaterialParameter::isIdealRefraction, folded into attrib at upload
+constexpr uint32_t kAttrStencilAlways = 0x40000u;     // MaterialParameter::stencil_type == StencilType::ALWAYS (material.h:224-228)
+constexpr uint32_t kAttrStencilStencil = 0x80000u;    // ... == StencilType::STENCIL
 constexpr uint32_t kAttrMaybeAlpha = 0x20000u;        // baseColor.a < 1 or an albedo texel with a < 1 exists: material::isTranslucentByAlpha
                                                       // can be true, so shadow-ray hits on it must evaluate it (set at upload)
 
@@ -87,7 +89,8 @@ struct DevScene {
     float avgIllum;
     float multiplyer;
     int32_t enable_env_map;
-    int32_t any_alpha;          // some material carries kAttrMaybeAlpha
+    int32_t any_alpha;          // some material carries kAttrMaybeAlpha or kAttrStencilStencil: a shadow-ray hit may be "ignored"
+    int32_t enable_alpha_blending;      // scene_rendering_config.enable_alpha_blending
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS

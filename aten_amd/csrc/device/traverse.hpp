@@ -122,7 +122,9 @@ ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, c
 //        the closest hit is nearer than stop_t (shadow rays toward point / spot lights).  This is exact, not an
 //        approximation: up to that hit the closest-hit walk is the same walk, its final hit can only be nearer,
 //        and when no such hit is accepted the walk runs to its end and reports the exact closest hit.
-//   void finish(uint32_t payload, const Hit& h, bool is_hit)
+//   bool finish(uint32_t payload, const Hit& h, bool is_hit, float4& a, float4& b, float& stop_t)
+//        true = the job is not over: the lane walks the ray (a, b, stop_t) next (a shadow ray restarting behind an
+//        ignored surface)
 
 // Per-lane state of one walk.  A lane is idle <=> node == kLinkEnd at the top of an iteration.
 struct Walk {
@@ -250,7 +252,11 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
         w.node = is_hit ? w.top_hit : w.top_miss;
         w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         w.ray = w.wray;
-        if (w.node == kLinkEnd) job.finish(w.payload, w.hit, w.hit.objid >= 0);
+        if (w.node == kLinkEnd) {
+            float4 ra, rb;
+            float rstop;
+            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start(w, sc, ra, rb, rstop);
+        }
     }
     // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
     if (__any(ended || at_tlas) || !all_finite) all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
@@ -269,12 +275,11 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
         Walk w;
-        {
-            float4 a, b;
-            float stop_t;
-            job.fetch(j, a, b, stop_t);
-            walk_start(w, sc, a, b, stop_t);
-        }
+        float4 a, b;
+        float stop_t;
+        job.fetch(j, a, b, stop_t);
+      restart:
+        walk_start(w, sc, a, b, stop_t);
         while (w.node != kLinkEnd) {
             const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
             const float4 q0 = ld16(nb, off);
@@ -326,7 +331,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                 w.ray = w.wray;
             }
         }
-        job.finish(w.payload, w.hit, w.hit.objid >= 0);
+        if (job.finish(w.payload, w.hit, w.hit.objid >= 0, a, b, stop_t)) goto restart;
     }
 }
 

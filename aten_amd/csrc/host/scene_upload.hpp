@@ -308,6 +308,8 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         d.baseColor = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, m.baseColor.w);
         d.type = m.type; d.attrib = (m.attrib & 0xFu) | (m.isIdealRefraction ? kAttrIdealRefraction : 0u); d.id = m.id;
         if (m.baseColor.w < 1.0F || (m.albedoMap >= 0 && (uint32_t)m.albedoMap < s->n_textures && tex_has_alpha[m.albedoMap])) d.attrib |= kAttrMaybeAlpha;
+        if (m.stencil_type == 1) d.attrib |= kAttrStencilAlways;
+        if (m.stencil_type == 2) d.attrib |= kAttrStencilStencil;
         d.albedoMap = m.albedoMap; d.normalMap = m.normalMap; d.roughnessMap = m.roughnessMap;
         const atn_standard_mtrl& st = m.u.standard;
         d.ior = st.ior; d.roughness = st.roughness; d.subsurface = st.subsurface; d.metallic = st.metallic;
@@ -373,7 +375,8 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     p.multiplyer = s->config.bg.multiplyer;
     p.enable_env_map = s->config.bg.enable_env_map;
     p.any_alpha = 0;
-    for (const DevMaterial& dm : img.materials) if (dm.attrib & kAttrMaybeAlpha) p.any_alpha = 1;
+    for (const DevMaterial& dm : img.materials) if (dm.attrib & (kAttrMaybeAlpha | kAttrStencilStencil)) p.any_alpha = 1;
+    p.enable_alpha_blending = s->config.enable_alpha_blending ? 1 : 0;
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /
     // ComputeDistanceToCoverBoundingSphere, math/aabb.h:176-180,231-234,346-362), evaluated once on the host.
     {

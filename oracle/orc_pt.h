@@ -1040,43 +1040,63 @@ inline void FillShadowRay(ShadowRay& shadow_ray, const Scene& ctxt, PathState& p
 }
 
 // HitShadowRay + HitTestToTargetLight + scene::hitLight,
-// pathtracing_impl.h:266-393, scene/scene.h:64-134 (alpha blending / stencil disabled: 1 lookup)
-inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& shadow_ray, PathCounters* cnt)
+// pathtracing_impl.h:266-393, scene/scene.h:64-134.
+// surface_stencil_type: stencil_type of the material at the SHADED point (pathtracing.cpp:59-66 passes
+// ctxt.GetMaterial(isect.mtrlid)); ALWAYS raises the lookup budget to 10 and makes STENCIL surfaces transparent to
+// the shadow ray; scene_rendering_config.enable_alpha_blending raises it to 10 as well.
+inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& shadow_ray, int32_t surface_stencil_type,
+    PathCounters* cnt)
 {
     if (path.is_terminated) return false;
     if (!shadow_ray.isActive) return false;
     const auto& light = ctxt.GetLight(shadow_ray.targetLightId);
     const float distToLight = shadow_ray.distToLight;
-    Ray r(shadow_ray.rayorg, shadow_ray.raydir);
+    const Ray original_ray(shadow_ray.rayorg, shadow_ray.raydir);
 
     const bool valid_obj = (light.type == ATN_LIGHT_AREA) && light.arealight_objid >= 0;
     const int32_t lightobj = valid_obj ? light.arealight_objid : -1;
-    int32_t hitobj = lightobj;
+    int32_t hitobj = lightobj;      // kept across lookups, like the reference's pointer (:291)
 
-    Isect isect;
+    Ray r = original_ray;
+    size_t max_lookups = ctxt.d->config.enable_alpha_blending ? 10 : 1;
+    const bool need_stencil_check = surface_stencil_type == 1;      // StencilType::ALWAYS
+    max_lookups = need_stencil_check ? 10 : max_lookups;
+
+    bool is_hit_to_light = false;
     if (cnt) cnt->shadow_rays++;
-    bool isHit = TraverseClosest(isect, ctxt, r, EPS, distToLight - EPS, cnt ? &cnt->trav : nullptr);
-    if (isHit) {
-        hitobj = isect.objid;
-        // material::isTranslucentByAlpha (material.cpp:193-210): such a hit is "ignored" and the lookup loop, whose
-        // budget is one iteration without alpha blending / stencil, ends with is_hit_to_light still false
-        // (pathtracing_impl.h:295-336)
-        const auto& hobj = ctxt.GetObject(static_cast<uint32_t>(isect.objid));
-        HitRec rec;
-        evaluate_hit_result(rec, hobj, ctxt, r, isect);
-        if (isect.mtrlid >= 0) {        // (the reference indexes unconditionally)
-            const auto& hm = ctxt.GetMaterial(isect.mtrlid);
-            v4 albedo = sampleTexture(ctxt, hm.albedoMap, rec.u, rec.v, v4(1.0F));
-            const float alpha = albedo.w * hm.baseColor.w;
-            if (alpha < 1.0F) return false;
+    for (size_t i = 0; i < max_lookups; i++) {
+        Isect isect;
+        bool isHit = TraverseClosest(isect, ctxt, r, EPS, distToLight - EPS, cnt ? &cnt->trav : nullptr);
+        if (isHit) {
+            hitobj = isect.objid;
+            const auto& hobj = ctxt.GetObject(static_cast<uint32_t>(isect.objid));
+            HitRec rec;
+            evaluate_hit_result(rec, hobj, ctxt, r, isect);
+            bool is_ignore_hit = false;
+            if (isect.mtrlid >= 0) {        // (the reference indexes unconditionally)
+                const auto& hm = ctxt.GetMaterial(isect.mtrlid);
+                if (need_stencil_check && hm.stencil_type == 2) is_ignore_hit = true;       // StencilType::STENCIL
+                // material::isTranslucentByAlpha (material.cpp:193-210)
+                v4 albedo = sampleTexture(ctxt, hm.albedoMap, rec.u, rec.v, v4(1.0F));
+                const float alpha = albedo.w * hm.baseColor.w;
+                if (alpha < 1.0F) is_ignore_hit = true;
+            }
+            if (is_ignore_hit) {
+                // go through the object: offset along the normal that faces the ray's direction (:319-330); with a
+                // budget of one lookup the loop ends here and the ray counts as blocked
+                v3 orienting_normal = rec.normal;
+                const bool is_same_facing = dot(rec.normal, original_ray.dir) > 0.0F;
+                if (!is_same_facing) orienting_normal = -orienting_normal;
+                r = Ray(rec.p, original_ray.dir, orienting_normal);
+                continue;
+            }
         }
+        if (hitobj == lightobj) is_hit_to_light = true;
+        else if (light.attrib & ATN_LIGHT_ATTR_INFINITE) is_hit_to_light = !isHit;
+        else if (light.attrib & ATN_LIGHT_ATTR_SINGULAR) is_hit_to_light = isect.t > distToLight;
+        else is_hit_to_light = false;
+        break;
     }
-
-    bool is_hit_to_light;
-    if (hitobj == lightobj) is_hit_to_light = true;
-    else if (light.attrib & ATN_LIGHT_ATTR_INFINITE) is_hit_to_light = !isHit;
-    else if (light.attrib & ATN_LIGHT_ATTR_SINGULAR) is_hit_to_light = isect.t > distToLight;
-    else is_hit_to_light = false;
 
     if (is_hit_to_light) path.contrib += shadow_ray.lightcontrib;
     return is_hit_to_light;
@@ -1237,7 +1257,7 @@ inline void radiance(PathState& path, Ray& ray, ShadowRay& shadow_ray, int32_t i
         if (is_hit) {
             path.isHit = true;
             shade(path, ctxt, ray, shadow_ray, isect, rrDepth, depth, cnt);
-            HitShadowRay(ctxt, path, shadow_ray, cnt);
+            HitShadowRay(ctxt, path, shadow_ray, isect.mtrlid >= 0 ? ctxt.GetMaterial(isect.mtrlid).stencil_type : 0, cnt);
             willContinue = !path.is_terminated;
         }
         else {

@@ -226,7 +226,7 @@ inline void ExecRendering(PathState& path, Ray& ray, ShadowRay& shadow_ray, int3
         if (is_hit) {
             path.isHit = true;
             Shade(path, ctxt, ray, shadow_ray, isect, rrDepth, depth, W2C, aov_nd, aov_am, primary_pos, cnt);
-            HitShadowRay(ctxt, path, shadow_ray, cnt);
+            HitShadowRay(ctxt, path, shadow_ray, isect.mtrlid >= 0 ? ctxt.GetMaterial(isect.mtrlid).stencil_type : 0, cnt);
             willContinue = !path.is_terminated;
         }
         else {

@@ -42,6 +42,7 @@ struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
     hipError_t upload(const std::vector<T>& v, hipStream_t s)
     {
         hipError_t e = resize(v.size() ? v.size() : 1);
@@ -100,6 +101,67 @@ public:
     uint32_t n_slots = 0;
     int32_t counters_depth = 0;
 
+    // Frames in flight (atn_set_frames_in_flight): everything a frame's kernels write except the film lives in a BANK --
+    // path state, queues, counters, tile buffer, and the streams / events the frame runs on.  The members above ARE the
+    // current bank; render() rotates them with the spare banks, so frame f + 1 is enqueued on another stream while frame
+    // f's launch tails (a few long rays keep a handful of waves alive at the end of every trace launch) still run.
+    // Only the film orders consecutive frames: a frame's k_gather waits for the previous frame's.
+    static constexpr int kMaxInFlight = 4;
+    struct Bank {
+        DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
+        DevBuf<int2> isect2;
+        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
+        uint32_t n_slots = 0;
+        int32_t counters_depth = 0;
+        hipStream_t stream = nullptr, bstream[kMaxBatches] = {};
+        hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {}, ev_gather = nullptr;
+    };
+    Bank spare[kMaxInFlight - 1];
+    int frames_in_flight = 1, n_spare_ready = 0;
+    uint64_t frame_seq = 0;
+    hipEvent_t ev_gather = nullptr;         // the current bank's "film updated" event
+    hipEvent_t last_gather = nullptr;       // the previous frame's, when it ran on another bank
+
+    void swap_bank(Bank& b)
+    {
+        ray_o.swap(b.ray_o); ray_d.swap(b.ray_d); thr.swap(b.thr); contrib.swap(b.contrib); isect.swap(b.isect);
+        sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
+        isect2.swap(b.isect2); done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
+        counters.swap(b.counters);
+        std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth);
+        std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
+        for (int k = 0; k < kMaxBatches; k++) { std::swap(bstream[k], b.bstream[k]); std::swap(ev_join[k], b.ev_join[k]); }
+    }
+
+    int set_frames_in_flight(int n)
+    {
+        if (n < 1 || n > kMaxInFlight) return fail(ATN_ERR_INVALID_ARG, "frames in flight out of range");
+        ATN_HIP(hipSetDevice(device));
+        int rc = quiesce();
+        if (rc) return rc;
+        for (; n_spare_ready < n - 1; n_spare_ready++) {
+            Bank& b = spare[n_spare_ready];
+            ATN_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+            ATN_HIP(hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
+            ATN_HIP(hipEventCreateWithFlags(&b.ev_gather, hipEventDisableTiming));
+            for (int k = 0; k < kMaxBatches; k++) {
+                ATN_HIP(hipStreamCreateWithFlags(&b.bstream[k], hipStreamNonBlocking));
+                ATN_HIP(hipEventCreateWithFlags(&b.ev_join[k], hipEventDisableTiming));
+            }
+        }
+        frames_in_flight = n;
+        return ATN_OK;
+    }
+
+    // every frame in flight finished (all banks' streams idle): required before anything but the next render()
+    int quiesce()
+    {
+        ATN_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < n_spare_ready; i++) ATN_HIP(hipStreamSynchronize(spare[i].stream));
+        last_gather = nullptr;
+        return ATN_OK;
+    }
+
     // profiling
     float k_ms[ATN_K_COUNT] = {};
     uint32_t k_launches[ATN_K_COUNT] = {};
@@ -127,6 +189,7 @@ public:
             ATN_HIP(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
         }
         ATN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        ATN_HIP(hipEventCreateWithFlags(&ev_gather, hipEventDisableTiming));
         // experiment knobs (tools/variants.sh): read once here, never inside a frame
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
         if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
@@ -151,6 +214,17 @@ public:
             if (bstream[k]) (void)hipStreamDestroy(bstream[k]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_gather) (void)hipEventDestroy(ev_gather);
+        for (int i = 0; i < n_spare_ready; i++) {
+            Bank& b = spare[i];
+            for (int k = 0; k < kMaxBatches; k++) {
+                if (b.ev_join[k]) (void)hipEventDestroy(b.ev_join[k]);
+                if (b.bstream[k]) (void)hipStreamDestroy(b.bstream[k]);
+            }
+            if (b.ev_fork) (void)hipEventDestroy(b.ev_fork);
+            if (b.ev_gather) (void)hipEventDestroy(b.ev_gather);
+            if (b.stream) (void)hipStreamDestroy(b.stream);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -158,6 +232,7 @@ public:
     int UpdateSceneData(const atn_scene_desc* s)
     {
         ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
         HostSceneImage img;
         std::string err;
         if (!build_host_image(img, s, err)) return fail(ATN_ERR_UNSUPPORTED, err);
@@ -197,6 +272,7 @@ public:
         if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
         if (!objs || n_objs == 0 || !top || n_top == 0) return fail(ATN_ERR_INVALID_ARG, "empty object or top-layer array");
         ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
         if ((uint64_t)top_base + (uint64_t)n_top * kInnerBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
         if (n_mtxs && !mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
         {
@@ -266,6 +342,7 @@ public:
     {
         if (!v || n == 0) return fail(ATN_ERR_INVALID_ARG, "empty seed array");
         ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
         ATN_HIP(seeds.resize(n));
         ATN_HIP(hipMemcpyAsync(seeds.p, v, (size_t)n * 4, hipMemcpyHostToDevice, stream));
         ATN_HIP(hipStreamSynchronize(stream));
@@ -300,6 +377,7 @@ public:
             n_slots = slots;
         }
         if (w != film_w || h != film_h) {
+            if (frames_in_flight > 1) { int qrc = quiesce(); if (qrc) return qrc; }
             ATN_HIP(film.resize((size_t)w * h));
             ATN_HIP(hipMemsetAsync(film.p, 0, (size_t)w * h * sizeof(float4), stream));
             film_w = w; film_h = h;
@@ -537,9 +615,19 @@ public:
         if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
         if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
         ATN_HIP(hipSetDevice(device));
-        int rc = ensure_frame(d->width, d->height, d->maxDepth);
-        if (rc) return rc;
         const bool count = d->count_stats != 0, prof = d->profile != 0;
+        int rc;
+        if (frames_in_flight > 1) {
+            if (count) { rc = quiesce(); if (rc) return rc; }       // the counters are one set, read back synchronously
+            else {
+                // rotate: the bank that has been idle longest becomes the current one
+                last_gather = ev_gather;
+                swap_bank(spare[frame_seq % (uint64_t)(frames_in_flight - 1)]);
+            }
+        }
+        frame_seq++;
+        rc = ensure_frame(d->width, d->height, d->maxDepth);
+        if (rc) return rc;
         PathBuffers pb = buffers(count);
         FrameParams fp = frame_params(*d);
         if (count) ATN_HIP(hipMemsetAsync(stats.p, 0, 64, stream));
@@ -548,11 +636,13 @@ public:
         rc = run_paths<false>(d, fp, count, prof, SvgfShade{}, SvgfFrame{});
         if (rc) return rc;
         fp.slot_begin = 0; fp.slot_end = (int32_t)n_slots;
+        if (last_gather) ATN_HIP(hipStreamWaitEvent(stream, last_gather, 0));     // the film is a running mean: frame order
         prof_begin(prof, ATN_K_GATHER);
         if (d->sample == 1) hipLaunchKernelGGL((k_gather<true>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         else hipLaunchKernelGGL((k_gather<false>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
+        if (frames_in_flight > 1) ATN_HIP(hipEventRecord(ev_gather, stream));
 
         if (count) {
             ATN_HIP(hipMemcpyAsync(host_stats, stats.p, 64, hipMemcpyDeviceToHost, stream));
@@ -764,6 +854,7 @@ public:
     {
         if (film.p) {
             ATN_HIP(hipSetDevice(device));
+            { int q = quiesce(); if (q) return q; }
             ATN_HIP(hipMemsetAsync(film.p, 0, film.n * sizeof(float4), stream));
         }
         return ATN_OK;
@@ -780,6 +871,9 @@ struct atn_mgpu { atn::MultiGpu m; };
 using atn::PathTracing;
 
 #define CTX_OR_FAIL(ctx) do { if (!(ctx)) return ATN_ERR_INVALID_ARG; } while (0)
+// every entry point except atn_render first lets the frames in flight finish (atn_set_frames_in_flight)
+#define CTX_QUIET_OR_FAIL(ctx) do { if (!(ctx)) return ATN_ERR_INVALID_ARG; \
+    if ((ctx)->r.frames_in_flight > 1) { int q_ = (ctx)->r.quiesce(); if (q_) return q_; } } while (0)
 
 // No exception may cross the C boundary (std::vector growth in the upload paths can throw std::bad_alloc).
 template <class F>
@@ -829,7 +923,7 @@ const char* atn_last_error(atn_ctx* ctx) { return ctx ? ctx->r.last_error.c_str(
 
 int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     if (!scene) return ctx->r.fail(ATN_ERR_INVALID_ARG, "null scene");
     return guarded(ctx, [&] { return ctx->r.UpdateSceneData(scene); });
 }
@@ -839,11 +933,11 @@ int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAI
 int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
                     const atn_bvh_node* top_nodes, uint32_t n_top_nodes)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); });
 }
-int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.initSampler(w, h, seed); }); }
-int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.setRandom(seeds, n); }); }
+int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.initSampler(w, h, seed); }); }
+int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.setRandom(seeds, n); }); }
 
 int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
 {
@@ -854,7 +948,7 @@ int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
 }
 
 int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.render(dst, out_host); }); }
-int atn_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.reset(); }
+int atn_reset(atn_ctx* ctx) { CTX_QUIET_OR_FAIL(ctx); return ctx->r.reset(); }
 int atn_set_path_batches(atn_ctx* ctx, int32_t n)
 {
     CTX_OR_FAIL(ctx);
@@ -864,13 +958,19 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n)
     return ATN_OK;
 }
 
-int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
+int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n)
 {
     CTX_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.set_frames_in_flight(n); });
+}
+
+int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host); });
 }
-int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.svgf_set_motion_depth(motion_depth, n); }); }
-int atn_svgf_reset(atn_ctx* ctx) { CTX_OR_FAIL(ctx); return ctx->r.svgf_reset(); }
+int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.svgf_set_motion_depth(motion_depth, n); }); }
+int atn_svgf_reset(atn_ctx* ctx) { CTX_QUIET_OR_FAIL(ctx); return ctx->r.svgf_reset(); }
 int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n)
 {
     CTX_OR_FAIL(ctx);
@@ -880,7 +980,7 @@ int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n)
 }
 int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     float4* p = r.sv_w > 0 ? r.svgf_buffer(which) : nullptr;
     if (!p || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "no such SVGF buffer (or atn_svgf_render has not run)");
@@ -891,12 +991,12 @@ int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host)
 }
 int atn_svgf_denoise(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host, false); });
 }
 int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, const atn_vec4* host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!host || width <= 0 || height <= 0) return r.fail(ATN_ERR_INVALID_ARG, "bad SVGF upload");
     C_HIP(r, hipSetDevice(r.device));
@@ -918,7 +1018,7 @@ void* atn_stream(atn_ctx* ctx) { return ctx ? (void*)ctx->r.stream : nullptr; }
 
 int atn_synchronize(atn_ctx* ctx)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
     return ATN_OK;
 }
@@ -945,7 +1045,7 @@ int atn_assemble_tiles_on(atn_ctx* ctx, const void* gathered_dev, int32_t world,
 
 int atn_download_film(atn_ctx* ctx, atn_vec4* out_host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!out_host || !r.film.p) return r.fail(ATN_ERR_INVALID_ARG, "atn_download_film: nothing rendered yet");
     C_HIP(r, hipMemcpyAsync(out_host, r.film.p, (size_t)r.film_w * r.film_h * sizeof(float4), hipMemcpyDeviceToHost, r.stream));
@@ -955,14 +1055,14 @@ int atn_download_film(atn_ctx* ctx, atn_vec4* out_host)
 
 int atn_get_stats(atn_ctx* ctx, uint64_t out[8])
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     for (int i = 0; i < 8; i++) out[i] = ctx->r.host_stats[i];
     return ATN_OK;
 }
 
 int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[ATN_K_COUNT])
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
     ctx->r.prof_collect();
     for (int i = 0; i < ATN_K_COUNT; i++) { ms[i] = ctx->r.k_ms[i]; launches[i] = ctx->r.k_launches[i]; }
@@ -971,7 +1071,7 @@ int atn_get_kernel_times(atn_ctx* ctx, float ms[ATN_K_COUNT], uint32_t launches[
 
 int atn_reset_kernel_times(atn_ctx* ctx)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     C_HIP(ctx->r, hipStreamSynchronize(ctx->r.stream));
     ctx->r.prof_collect();
     for (int i = 0; i < ATN_K_COUNT; i++) { ctx->r.k_ms[i] = 0; ctx->r.k_launches[i] = 0; }
@@ -1044,6 +1144,11 @@ int atn_mgpu_reset(atn_mgpu* mg)
     return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->reset(); }); });
 }
 int atn_mgpu_synchronize(atn_mgpu* mg) { MG_OR_FAIL(mg); return mg_guarded(mg, [&] { return mg->m.synchronize(); }); }
+int atn_mgpu_set_frames_in_flight(atn_mgpu* mg, int32_t n)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->set_frames_in_flight(n); }); });
+}
 void* atn_mgpu_film_device(atn_mgpu* mg) { return mg ? (void*)mg->m.full.p : nullptr; }
 int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host)
 {
@@ -1059,7 +1164,7 @@ int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host)
 // ---------------------------------------------------------------- stage entry points
 int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t sample, uint32_t frame, atn_ray* out_host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!r.has_camera || r.n_seeds == 0 || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "atn_generate_paths: camera / sampler / output missing");
     C_HIP(r, hipSetDevice(r.device));
@@ -1086,7 +1191,7 @@ int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t samp
 int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float t_min, float t_max,
                       atn_intersection* out_host, uint64_t* stats_out)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
     if (!rays_host || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "null rays / output");
@@ -1123,7 +1228,7 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
 
 int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t scramble, int32_t n, float* out_host)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (n <= 0 || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "bad sample count");
     C_HIP(r, hipSetDevice(r.device));
@@ -1139,7 +1244,7 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
                        const uint32_t* index, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
     if (mtrl_id < 0 || mtrl_id >= r.scene.n_materials || n == 0) return r.fail(ATN_ERR_INVALID_ARG, "bad material id / count");
@@ -1170,7 +1275,7 @@ int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags
 int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks, int32_t binned,
                  int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
 {
-    CTX_OR_FAIL(ctx);
+    CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!flags_a_host || !out_a_host || !out_count_a) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
     if (flags_b_host && (!out_b_host || !out_count_b)) return r.fail(ATN_ERR_INVALID_ARG, "null output for the second queue");

@@ -223,8 +223,8 @@ public:
     {
         int rc = on_all([&](int i) -> int {
             PathTracing& r = *shard[i];
-            if (hipSetDevice(r.device) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipStreamSynchronize");
-            return ATN_OK;
+            if (hipSetDevice(r.device) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipSetDevice");
+            return r.quiesce();
         });
         if (rc != ATN_OK) return rc;
         ATN_HIP(hipSetDevice(shard[0]->device));

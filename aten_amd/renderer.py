@@ -83,6 +83,9 @@ class PathTracing:
     def set_path_batches(self, n):
         self._check(self._l.atn_set_path_batches(self._ctx, n))
 
+    def set_frames_in_flight(self, n):
+        self._check(self._l.atn_set_frames_in_flight(self._ctx, n))
+
     def reset(self):
         self._check(self._l.atn_reset(self._ctx))
 
@@ -289,6 +292,9 @@ class MultiGpuPathTracing:
 
     def synchronize(self):
         self._check(self._l.atn_mgpu_synchronize(self._mg))
+
+    def set_frames_in_flight(self, n):
+        self._check(self._l.atn_mgpu_set_frames_in_flight(self._mg, n))
 
     def film_device_ptr(self):
         return self._l.atn_mgpu_film_device(self._mg)

@@ -101,6 +101,7 @@ def main_mgpu(args):
     m.UpdateSceneData(fs)
     m.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], W, H))
     m.initSampler(W, H, 0)
+    m.set_frames_in_flight(min(args.frames_in_flight, 2))      # the node renderer double-buffers its gather
     brk = not args.all_samples
     for i in range(args.warmup):
         m.render(W, H, depth, rr, spp=spp, frame=i, break_on_terminate=brk, download=False)
@@ -145,6 +146,9 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="consecutive frames enqueued on rotating banks of path state and streams (atn_set_frames_in_flight): "
+                         "one frame's launch tails overlap the next frame's bulk; 1 = strictly one frame at a time")
     ap.add_argument("--mgpu", action="store_true",
                     help="one process, every GPU behind the C-ABI (atn_mgpu_*: worker thread per GPU, peer-copy gather into "
                          "GPU 0) instead of one process per GPU + RCCL all_gather")
@@ -212,11 +216,13 @@ def main():
     r.updateCamera(camera)
     r.initSampler(W, H, 0)
     r.setScreenShard(rank, world)
+    if not args.svgf:
+        r.set_frames_in_flight(args.frames_in_flight)
 
     # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
     # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
     # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
-    ext_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=dev) if use_dist else None
+    ext_streams = {}        # the renderer's stream of the frame just enqueued (one per bank of frames in flight)
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
     full = None
@@ -239,6 +245,10 @@ def main():
                 ev_free[k].record(comm_stream)
             if full is None:
                 full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            sp = r.stream_ptr()
+            if sp not in ext_streams:
+                ext_streams[sp] = torch.cuda.ExternalStream(sp, device=dev)
+            ext_stream = ext_streams[sp]
             with torch.cuda.stream(ext_stream):
                 ext_stream.wait_event(ev_free[k])           # the exchange of frame f - 2 has read stage[k]
                 stage[k].copy_(tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev))
@@ -304,6 +314,7 @@ def main():
     # the same frames once more with one kernel in flight at a time: per-kernel durations of isolated kernels
     # (in the timed region up to three batches of the frame overlap on separate streams, so a launch shares the GPU)
     r.set_path_batches(1)
+    r.set_frames_in_flight(1)
     r.reset()
     r.reset_kernel_times()
     n_excl = min(args.steps, 10)
@@ -315,6 +326,8 @@ def main():
     r.synchronize()
     ktimes_excl = r.kernel_times()
     r.set_path_batches(3)
+    if not args.svgf:
+        r.set_frames_in_flight(args.frames_in_flight)
 
     frames_prof = args.steps
     kernel_count_batches = max(1, round(ktimes["gen_path"][1] / max(frames_prof * spp, 1)))
@@ -333,7 +346,15 @@ def main():
     tc_ms, tc_n = ktimes[tkey]
     launches_per_frame = max(tc_n / max(frames_prof, 1), 1)
     avg_launch_ms = tc_ms / max(tc_n, 1)
-    avg_launch_s = max(avg_launch_ms * 1e-3, 1e-12)
+    # With frames in flight (or several batches per frame) a launch shares the GPU with other launches, so its wall
+    # duration says nothing about how hard IT drives the machine; the roofline fractions use the duration of the same
+    # launch with one kernel in flight at a time (the isolated pass above -- also the mode the PMC passes run in, the
+    # profiler serialises dispatches), the overlapped duration is reported next to it.
+    in_flight = 1 if args.svgf else args.frames_in_flight
+    overlapped = kernel_count_batches > 1 or in_flight > 1
+    iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
+    roof_ms = iso_ms if overlapped else avg_launch_ms
+    avg_launch_s = max(roof_ms * 1e-3, 1e-12)
     scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene]
     prof = profile_counters(scene_tag, W, H, spp, depth, args.svgf) if world == 1 else None
     pk = kernel_entry(prof, dominant)
@@ -349,7 +370,7 @@ def main():
         if "valu_busy" in pk:
             # issue slots are per cycle: rescale the profiled run's busy fraction by the duration ratio
             prof_ms = pk["cycles"] / 2.4e6
-            fractions["valu"] = pk["valu_busy"] * (prof_ms / avg_launch_ms) if avg_launch_ms > 0 else pk["valu_busy"]
+            fractions["valu"] = pk["valu_busy"] * (prof_ms / roof_ms) if roof_ms > 0 else pk["valu_busy"]
     bound = max(fractions, key=fractions.get) if fractions else "hbm"
     units = {"hbm": ("GB/s", HBM_PEAK_GBS), "l2": ("GB/s", L2_PEAK_GBS), "valu": ("VALU issue slots busy", 1.0)}
     frac = fractions.get(bound)
@@ -360,6 +381,7 @@ def main():
         "traffic": pk.get("hbm_bytes") if pk else None,
         "fractions": {k: round(v, 4) for k, v in fractions.items()},
         "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
+        "roofline_launch_ms": round(roof_ms, 5),
         "algorithmic": {"bytes_per_launch": round(bytes_per_frame / launches_per_frame),
                         "GBps": round(bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
                         "bytes_per_launch_this_layout": round(own_bytes_per_frame / launches_per_frame),
@@ -381,6 +403,8 @@ def main():
     sk = kernel_entry(prof, "k_shade")
     shade = None
     if sh_n:
+        if overlapped and ktimes_excl["shade"][1]:
+            sh_ms, sh_n = ktimes_excl["shade"][0] * (frames_prof / max(n_excl, 1)), ktimes_excl["shade"][1] * (frames_prof / max(n_excl, 1))
         sh_launch_s = sh_ms * 1e-3 / sh_n
         entries, hits = per_frame["closest_rays"], per_frame["hits"]
         comp = (96 * entries + 88 * hits + 32 * (entries - hits)) / max(sh_n / max(frames_prof, 1), 1)
@@ -392,10 +416,10 @@ def main():
                  "frac": round(sk["hbm_bytes"] / sh_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sk and "hbm_bytes" in sk else None,
                  "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None}
     roofline["shade"] = shade
-    if ktimes_excl[tkey][1] and kernel_count_batches > 1:
-        te_ms, te_n = ktimes_excl[tkey]
-        roofline["isolated_avg_launch_ms"] = round(te_ms / te_n, 5)
-        roofline["note"] += "; the frame runs as %d batches on separate streams, avg_launch_ms is the duration of a launch that shares the GPU (isolated_avg_launch_ms: one kernel in flight at a time)" % kernel_count_batches
+    if overlapped:
+        roofline["note"] += ("; %d frames in flight x %d batches per frame run on separate streams: avg_launch_ms (what rocprofv3 --kernel-trace "
+                             "of this command shows) is the wall duration of a launch that shares the GPU, roofline_launch_ms the same launch "
+                             "with one kernel in flight at a time, which the fractions use" % (in_flight, kernel_count_batches))
     kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
     kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
     svgf_info = None
@@ -468,6 +492,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
+                       "frames_in_flight": 1 if args.svgf else args.frames_in_flight,
                        "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"]))},
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / args.steps), 2),
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},

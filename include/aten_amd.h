@@ -128,6 +128,14 @@ int atn_reset_kernel_times(atn_ctx* ctx);
  * isolated kernel need). */
 int atn_set_path_batches(atn_ctx* ctx, int32_t n);
 
+/* Execution knob, no effect on results: how many consecutive atn_render frames may be in flight on the GPU at once
+ * (1 .. 4, default 1).  With n > 1 the context keeps n banks of path state and streams and atn_render(f + 1) is enqueued
+ * on another stream than frame f: the launch tails of one frame overlap the bulk of the next (what limits a small frame
+ * -- one GPU's share of a sharded 1080p image -- is the ~0.13 ms tail of each of its depth + 1 trace launches, DESIGN.md
+ * section 8).  Only the film orders the frames.  atn_stream / atn_tile_device then refer to the LAST rendered frame;
+ * every other entry point first waits for all frames in flight. */
+int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n);
+
 /* ---- one node, every GPU ------------------------------------------------------------------------
  * The reference renderer is single-device (idaten::Renderer, src/libidaten/kernel/renderer.h:17-179; its caller
  * src/device_renderer/main.cpp:133-149,196-204 makes one UpdateSceneData and one render(dst) per frame).  An
@@ -162,6 +170,8 @@ int atn_mgpu_reset(atn_mgpu* mg);
 int atn_mgpu_synchronize(atn_mgpu* mg);
 void* atn_mgpu_film_device(atn_mgpu* mg);
 int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host);
+/* atn_set_frames_in_flight on every shard. */
+int atn_mgpu_set_frames_in_flight(atn_mgpu* mg, int32_t n);
 
 /* ---- SVGF (next tier, BASELINE config 5) -------------------------------------------------------
  * ≙ aten::SVGFRenderer (src/libaten/renderer/svgf/svgf.{h,cpp}): the path pass with AOV outputs

@@ -107,3 +107,59 @@ def test_errors(cornell):
     finally:
         m.close()
     assert lib().atn_mgpu_render(None, None, None) == -1
+
+
+@pytest.mark.parametrize("in_flight", [2, 3, 4])
+def test_frames_in_flight_equal_serial_frames(sponza, in_flight):
+    """atn_set_frames_in_flight: consecutive frames on rotating banks of path state and streams, ordered only by the
+    film.  The progressive film after 7 frames, every downloaded intermediate frame, a counted frame in the middle and
+    a shard change must all equal the one-frame-at-a-time result, byte for byte."""
+    from aten_amd.renderer import PathTracing
+    fs, cam = sponza
+    w, h = 320, 180
+    want = _single(fs, cam, w, h, 7)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs)
+        r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+        r.initSampler(w, h, 0)
+        r.set_frames_in_flight(in_flight)
+        for f in range(7):
+            r.render(w, h, 5, 3, frame=f, download=False)
+        r.synchronize()
+        assert r.download_film().tobytes() == want[6].tobytes()
+        r.reset()
+        for f in range(7):
+            img = r.render(w, h, 5, 3, frame=f, download=(f in (2, 5)), count_stats=(f == 3))
+            if img is not None:
+                assert img.tobytes() == want[f].tobytes(), f
+            if f == 3:
+                assert r.stats()["closest_rays"] >= w * h
+        assert r.download_film().tobytes() == want[6].tobytes()
+        # back to one frame at a time on the same context
+        r.set_frames_in_flight(1)
+        r.reset()
+        for f in range(3):
+            img = r.render(w, h, 5, 3, frame=f)
+        assert img.tobytes() == want[2].tobytes()
+    finally:
+        r.close()
+
+
+def test_frames_in_flight_on_shards(cornell):
+    from aten_amd.renderer import MultiGpuPathTracing
+    fs, cam = cornell
+    w, h = 160, 96
+    want = _single(fs, cam, w, h, 6)
+    m = MultiGpuPathTracing([0, 0, 0])
+    try:
+        m.UpdateSceneData(fs)
+        m.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+        m.initSampler(w, h, 0)
+        m.set_frames_in_flight(2)
+        for f in range(6):
+            m.render(w, h, 5, 3, frame=f, download=False)
+        m.synchronize()
+        assert m.download_film().tobytes() == want[5].tobytes()
+    finally:
+        m.close()

@@ -93,7 +93,6 @@ public:
 
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
-    DevBuf<int2> isect2;
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
     DevBuf<unsigned long long> stats;
     int32_t film_w = 0, film_h = 0;
@@ -109,7 +108,6 @@ public:
     static constexpr int kMaxInFlight = 4;
     struct Bank {
         DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
-        DevBuf<int2> isect2;
         DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
@@ -126,7 +124,7 @@ public:
     {
         ray_o.swap(b.ray_o); ray_d.swap(b.ray_d); thr.swap(b.thr); contrib.swap(b.contrib); isect.swap(b.isect);
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
-        isect2.swap(b.isect2); done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
+        done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
         counters.swap(b.counters);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
@@ -369,7 +367,7 @@ public:
         if (slots > kShadowSlotMask) return fail(ATN_ERR_UNSUPPORTED, "more than 2^26 path slots per GPU (shard the screen)");
         if (slots != n_slots) {
             ATN_HIP(ray_o.resize(slots)); ATN_HIP(ray_d.resize(slots)); ATN_HIP(thr.resize(slots));
-            ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots)); ATN_HIP(isect2.resize(slots));
+            ATN_HIP(contrib.resize(slots)); ATN_HIP(isect.resize(slots));
             ATN_HIP(sh_o.resize(slots)); ATN_HIP(sh_d.resize(slots)); ATN_HIP(sh_c.resize(slots));
             ATN_HIP(accum.resize(slots)); ATN_HIP(done.resize(slots));
             ATN_HIP(queue0.resize(slots)); ATN_HIP(queue1.resize(slots)); ATN_HIP(shadow_q.resize(slots));
@@ -399,7 +397,7 @@ public:
     {
         PathBuffers pb{};
         pb.ray_o = ray_o.p; pb.ray_d = ray_d.p; pb.thr = thr.p; pb.contrib = contrib.p; pb.seeds = seeds.p;
-        pb.isect = isect.p; pb.isect2 = isect2.p; pb.sh_o = sh_o.p; pb.sh_d = sh_d.p; pb.sh_c = sh_c.p;
+        pb.isect = isect.p; pb.sh_o = sh_o.p; pb.sh_d = sh_d.p; pb.sh_c = sh_c.p;
         pb.accum = accum.p; pb.done = done.p; pb.queue[0] = queue0.p + slot_begin; pb.queue[1] = queue1.p + slot_begin;
         pb.shadow_q = shadow_q.p + slot_begin;
         uint32_t* cb = counters.p + (size_t)batch * 4 * counters_depth;

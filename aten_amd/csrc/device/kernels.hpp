@@ -27,8 +27,7 @@ struct PathBuffers {
     float4* contrib;    // contrib.xyz, -
     const uint32_t* seeds;  // aten::getRandom(): the CMJ scramble is recomputed from seed + frame + sample instead of being
                             // carried through HBM (32 B of traffic per path and bounce); only the dimension counter is state
-    float4* isect;      // t, a, b, triangle id (bit pattern)
-    int2* isect2;       // instance object id, TLAS mesh id
+    float4* isect;      // instance object id (bit pattern; < 0 = miss), a, b, triangle id (bit pattern): what shade reads of the hit
     float4* sh_o;       // shadow org.xyz, distToLight
     float4* sh_d;       // shadow dir.xyz, target light id (bit pattern)
     float4* sh_c;       // lightcontrib.xyz, -
@@ -273,8 +272,7 @@ struct ClosestJob {
     }
     ATN_DEV bool finish(uint32_t slot, const Hit& h, bool, float4&, float4&, float&) const
     {
-        pb.isect[slot] = make_float4(h.t, h.a, h.b, __int_as_float(h.tri));
-        pb.isect2[slot] = make_int2(h.objid, h.meshid);
+        pb.isect[slot] = make_float4(__int_as_float(h.objid), h.a, h.b, __int_as_float(h.tri));
         return false;
     }
 };
@@ -335,9 +333,10 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
             float pdfb = ro4.w;
             uint32_t flags = __float_as_uint(rd4.w);
             const float4 is4 = pb.isect[slot];
-            const int2 is2 = pb.isect2[slot];
+            const int32_t hit_objid = __float_as_int(is4.x);
             const float4 thr4 = pb.thr[slot];
             f3 throughput = mk3(thr4);
+            bool wrote_ray = false;
             f3 contrib_add = mk3(0.0F);         // contrib is read-modify-written only by the paths that add to it
             bool contrib_changed = false;
             // sampler state: GeneratePath's scramble (pathtracing_impl.h:75-81) from the pixel's seed
@@ -355,7 +354,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
             Cmj smp; smp.idx = s4.x; smp.dim = s4.y; smp.scramble = s4.z;
 
             flags &= ~F_HIT;
-            const bool is_hit = is2.x >= 0;
+            const bool is_hit = hit_objid >= 0;
 
             if (!is_hit) {
                 // ---------------- ShadeMiss
@@ -394,7 +393,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 // ---------------- shade
                 const int32_t tri_id = __float_as_int(is4.w);
                 HitRec rec;
-                evaluate_hit(rec, sc, is2.x, tri_id, is4.y, is4.z);
+                evaluate_hit(rec, sc, hit_objid, tri_id, is4.y, is4.z);
                 const int32_t mtrlid = sc.tris[tri_id].mtrlid;
 
                 const bool isBackfacing = dot(rec.normal, -ray_dir) < 0.0F;
@@ -428,7 +427,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                 if (m.type == ATN_MTRL_EMISSIVE && (m.attrib & ATN_MTRL_ATTR_EMISSIVE) && !isBackfacing) {
                     // an emissive surface that is not registered as a light (light_id < 0) has no LightParameter to
                     // read: the reference indexes lights[-1] there; here it emits nothing
-                    const int32_t lid = sc.objects[is2.x].light_id;
+                    const int32_t lid = sc.objects[hit_objid].light_id;
                     const f3 light_color = (lid >= 0 && lid < sc.n_lights) ? area_light_color(sc.lights[lid], rec.area) : mk3(0.0F);
                     float weight = 1.0f;
                     if (bounce > 0) {
@@ -453,6 +452,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                     // ---- FillShadowRay / SampleLight, pathtracing_impl.h:178-264
                     const bool invalid_mtrl = (m.attrib & (ATN_MTRL_ATTR_SINGULAR | ATN_MTRL_ATTR_TRANSLUCENT)) != 0;
                     bool shadow_active = false;
+                    float4 sh_o4 = make_float4(0, 0, 0, 0), sh_d4 = sh_o4, sh_c4 = sh_o4;
                     if (sc.n_lights > 0 && !invalid_mtrl) {
                         int32_t li = (int32_t)(cmj_next(smp) * (float)sc.n_lights);
                         li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
@@ -468,11 +468,13 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                             lightcontrib = (throughput * radiance) * albedo;
                             shadow_active = true;
                         }
-                        pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
+                        // kept in registers until the path is known to survive this bounce: only then is the shadow ray
+                        // traced (HitShadowRay, pathtracing_impl.h:362-368) and its 48 bytes of state written
+                        sh_o4 = make_float4(so.x, so.y, so.z, distToLight);
                         // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
-                        pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z,
-                                                    __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)));
-                        pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, 0.0F);
+                        sh_d4 = make_float4(dirToLight.x, dirToLight.y, dirToLight.z,
+                                            __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)));
+                        sh_c4 = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, sh_d4.w);     // (the light bits again: all finish() needs)
                         bin_shadow = dir_octant(dirToLight);
                     }
 
@@ -510,17 +512,19 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
                         pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
                         pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
+                        wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
                         bin_next = dir_octant(nd);
                     }
                     // HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     push_shadow = shadow_active && !(flags & F_TERMINATED);
+                    if (push_shadow) { pb.sh_o[slot] = sh_o4; pb.sh_d[slot] = sh_d4; pb.sh_c[slot] = sh_c4; }
                 }
             }
-            if (!push_next) {
-                // path ends here (terminated, or depth exhausted): keep flags for the sample epilogue
-                const float4 d = pb.ray_d[slot];
-                pb.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(flags));
+            if (!push_next && !wrote_ray) {
+                // path ends here (terminated; a path that merely ran out of depth stored its flags with its last ray):
+                // keep the flags for the sample epilogue
+                pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
             }
             pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
             if (contrib_changed) {
@@ -584,9 +588,10 @@ struct ShadowJob {
     {
         const uint32_t slot = payload & kShadowSlotMask;
         const uint32_t lookups = (payload >> 27) & 15u;
-        const float4 so = pb.sh_o[slot], sd = pb.sh_d[slot];
-        const float distToLight = so.w;
-        const uint32_t lbits = __float_as_uint(sd.w);
+        // one 16-byte read settles the common case: the light contribution carries the light bits; the distance and
+        // the ray itself are read only by the branches that need them
+        const float4 lc = pb.sh_c[slot];
+        const uint32_t lbits = __float_as_uint(lc.w);
         const atn_light_param* lp = &sc.lights[lbits & 0xffffffu];
         const int32_t ltype = lp->type, lobj = lp->arealight_objid;
         const uint32_t lattr = lp->attrib;
@@ -597,7 +602,7 @@ struct ShadowJob {
         bool visible;
         if (same_obj) visible = true;
         else if (lattr & ATN_LIGHT_ATTR_INFINITE) visible = !isHit;
-        else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > distToLight;
+        else if (lattr & ATN_LIGHT_ATTR_SINGULAR) visible = h.t > pb.sh_o[slot].w;     // distToLight
         else visible = false;
         if (ALPHA && sc.any_alpha && isHit) {
             const bool need_stencil = (lbits & kShadowStencilFlag) != 0u;
@@ -624,7 +629,8 @@ struct ShadowJob {
                 if (ignore) {
                     if (lookups + 1u >= max_lookups) return false;      // budget spent: is_hit_to_light stays false
                     // r = ray(rec.p, original_ray.dir, normal facing along the ray), :319-330
-                    const f3 odir = normalize(mk3(sd));
+                    const float distToLight = pb.sh_o[slot].w;
+                    const f3 odir = normalize(mk3(pb.sh_d[slot]));
                     const bool is_same_facing = dot(hit_n, odir) > 0.0F;
                     const f3 on = is_same_facing ? hit_n : -hit_n;
                     const f3 o = ray_offset(hit_p, on);
@@ -638,7 +644,6 @@ struct ShadowJob {
         }
         if (visible) {
             const float4 c = pb.contrib[slot];
-            const float4 lc = pb.sh_c[slot];
             pb.contrib[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
         }
         return false;

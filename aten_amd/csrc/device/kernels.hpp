@@ -174,6 +174,32 @@ ATN_DEV void block_append2_binned(BlockBinShared& sh, uint32_t* qA, uint32_t* cn
 
 ATN_DEV uint32_t dir_octant(const f3& d) { return (d.x < 0.0F ? 1u : 0u) | (d.y < 0.0F ? 2u : 0u) | (d.z < 0.0F ? 4u : 0u); }
 
+// Streamed path state in k_shade: ATN_SHADE_NT = 1 reads it with the non-temporal hint (each record is read once per
+// bounce and should not push the scene's triangles / materials / texels out of the 4 MiB per-XCD L2), 2 also writes the
+// records k_shade produces that way.  Experiment knob: see DESIGN.md section 7 for what was measured.
+#ifndef ATN_SHADE_NT
+#define ATN_SHADE_NT 0
+#endif
+typedef float atn_v4f __attribute__((ext_vector_type(4)));
+ATN_DEV float4 ld_state(const float4* p)
+{
+#if ATN_SHADE_NT >= 1
+    const atn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const atn_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+ATN_DEV void st_state(float4* p, const float4& v)
+{
+#if ATN_SHADE_NT >= 2
+    atn_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<atn_v4f*>(p));
+#else
+    *p = v;
+#endif
+}
+
 ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
 {
     // wave reduction, one atomic per wave
@@ -328,13 +354,13 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 
         if (valid) {
             slot = q[j];
-            const float4 ro4 = pb.ray_o[slot], rd4 = pb.ray_d[slot];
+            const float4 ro4 = ld_state(&pb.ray_o[slot]), rd4 = ld_state(&pb.ray_d[slot]);
             const f3 ray_org = mk3(ro4), ray_dir = mk3(rd4);
             float pdfb = ro4.w;
             uint32_t flags = __float_as_uint(rd4.w);
-            const float4 is4 = pb.isect[slot];
+            const float4 is4 = ld_state(&pb.isect[slot]);
             const int32_t hit_objid = __float_as_int(is4.x);
-            const float4 thr4 = pb.thr[slot];
+            const float4 thr4 = ld_state(&pb.thr[slot]);
             f3 throughput = mk3(thr4);
             bool wrote_ray = false;
             f3 contrib_add = mk3(0.0F);         // contrib is read-modify-written only by the paths that add to it
@@ -510,23 +536,23 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         }
                         const f3 no = ray_offset(rec.p, ray_along_normal);
                         const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
-                        pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
-                        pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
+                        st_state(&pb.ray_o[slot], make_float4(no.x, no.y, no.z, pdfb));
+                        st_state(&pb.ray_d[slot], make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags)));
                         wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
                         bin_next = dir_octant(nd);
                     }
                     // HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     push_shadow = shadow_active && !(flags & F_TERMINATED);
-                    if (push_shadow) { pb.sh_o[slot] = sh_o4; pb.sh_d[slot] = sh_d4; pb.sh_c[slot] = sh_c4; }
+                    if (push_shadow) { st_state(&pb.sh_o[slot], sh_o4); st_state(&pb.sh_d[slot], sh_d4); st_state(&pb.sh_c[slot], sh_c4); }
                 }
             }
             if (!push_next && !wrote_ray) {
                 // path ends here (terminated; a path that merely ran out of depth stored its flags with its last ray):
                 // keep the flags for the sample epilogue
-                pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
+                st_state(&pb.ray_d[slot], make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags)));
             }
-            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+            st_state(&pb.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim)));
             if (contrib_changed) {
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);

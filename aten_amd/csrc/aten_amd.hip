@@ -18,6 +18,7 @@
 #include "device/kernels.hpp"
 #include "device/svgf.hpp"
 #include "host/scene_upload.hpp"
+#include "host/ibl_precompute.hpp"
 
 namespace atn {
 
@@ -86,6 +87,14 @@ public:
     uint32_t top_base = 0, n_host_matrices = 0;
     uint64_t n_bottom_nodes = 0;
     atn_camera_param camera{};
+
+    // optional samplers (atn_set_sampling_options)
+    std::vector<atn_vec4> env_host;         // host copy of the environment map (the tables are built on demand)
+    int32_t env_w = 0, env_h = 0;
+    float env_multiplyer = 1.0F;
+    DevBuf<float> ibl_cdf_v, ibl_cdf_u;
+    bool ibl_tables_ready = false;
+    int32_t opt_ibl_importance = 0, opt_tex_bilinear = 0;
 
     // sampler
     DevBuf<uint32_t> seeds;
@@ -251,6 +260,19 @@ public:
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         has_scene = true;
+        env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;
+        {
+            const int32_t ei = s->config.bg.envmap_tex_idx;
+            if (ei >= 0 && (uint32_t)ei < s->n_textures && s->config.bg.enable_env_map) {
+                const atn_texture_desc& t = s->textures[ei];
+                env_host.assign(t.texels, t.texels + (size_t)t.width * t.height);
+                env_w = t.width; env_h = t.height; env_multiplyer = s->config.bg.multiplyer;
+            }
+        }
+        {
+            int orc = apply_sampling_options();
+            if (orc) return orc;
+        }
         list_root_link = img.list_root_link;
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
         n_bottom_nodes = img.n_nodes - s->bvh_lists[0].count;
@@ -260,6 +282,46 @@ public:
         flavour_forced = false;
         if (env_flavour >= 0) { use_refill = env_flavour == 1; flavour_forced = true; }
         return ATN_OK;
+    }
+
+    // Optional samplers, both OFF by default because they leave the sample stream of aten::PathTracing (the parity
+    // path): the IBL light sampled from ImageBasedLight::preCompute's tables (light/ibl.cpp:10-118,180-230) and
+    // texture::AtWithBilinear (image/texture.cpp:77-125) instead of texture::at for every texture lookup.
+    int apply_sampling_options()
+    {
+        scene.tex_bilinear = opt_tex_bilinear;
+        scene.ibl_importance = 0;
+        scene.ibl_cdf_v = nullptr; scene.ibl_cdf_u = nullptr; scene.ibl_w = 0; scene.ibl_h = 0;
+        if (!opt_ibl_importance || env_host.empty()) return ATN_OK;
+        if (!ibl_tables_ready) {
+            IblTables t;
+            const int32_t w = env_w, h = env_h;
+            const atn_vec4* tex = env_host.data();
+            const float mul = env_multiplyer;
+            ibl_precompute(t, w, h, [&](int32_t x, int32_t y, float& r, float& g, float& b) {
+                // SampleFromUVWithTexture(u, v) = texture::at(u, v) * multiplyer at the texel centre (ibl.cpp:57-60)
+                const float u = (float)(x + 0.5) / w, v = (float)(y + 0.5) / h;
+                int32_t iu = (int32_t)(u * (float)(w - 1)), iv = (int32_t)(v * (float)(h - 1));
+                iu = iu < 0 ? 0 : (iu > w - 1 ? w - 1 : iu); iv = iv < 0 ? 0 : (iv > h - 1 ? h - 1 : iv);
+                const atn_vec4& c = tex[(size_t)iv * w + iu];
+                r = c.x * mul; g = c.y * mul; b = c.z * mul;
+            });
+            ATN_HIP(ibl_cdf_v.upload(t.cdf_v, stream));
+            ATN_HIP(ibl_cdf_u.upload(t.cdf_u, stream));
+            ATN_HIP(hipStreamSynchronize(stream));
+            ibl_tables_ready = true;
+        }
+        scene.ibl_cdf_v = ibl_cdf_v.p; scene.ibl_cdf_u = ibl_cdf_u.p; scene.ibl_w = env_w; scene.ibl_h = env_h;
+        scene.ibl_importance = 1;
+        return ATN_OK;
+    }
+    int set_sampling_options(int32_t ibl_importance, int32_t tex_bilinear)
+    {
+        ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
+        opt_ibl_importance = ibl_importance ? 1 : 0;
+        opt_tex_bilinear = tex_bilinear ? 1 : 0;
+        return has_scene ? apply_sampling_options() : ATN_OK;
     }
 
     // ≙ idaten::Renderer::updateBVH, src/libidaten/kernel/renderer.cpp:133-153: new object parameters and matrices
@@ -954,6 +1016,32 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n)
     ctx->r.n_batches = n;
     ctx->r.batches_forced = n == 1;     // 1 = strictly serial; larger values stay subject to the size policy
     return ATN_OK;
+}
+
+int atn_set_sampling_options(atn_ctx* ctx, int32_t ibl_importance, int32_t tex_bilinear)
+{
+    CTX_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.set_sampling_options(ibl_importance, tex_bilinear); });
+}
+
+// texture::at / texture::AtWithBilinear probe (parity tests): n lookups of texture `texid` at uv[2n] -> out[4n]
+int atn_sample_texture(atn_ctx* ctx, int32_t texid, uint32_t n, const float* uv_host, float* out_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    if (texid < 0 || texid >= r.scene.n_textures || n == 0 || !uv_host || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "bad texture id / count");
+    return guarded(ctx, [&]() -> int {
+        C_HIP(r, hipSetDevice(r.device));
+        atn::DevBuf<float> duv, dout;
+        C_HIP(r, duv.resize(2 * (size_t)n)); C_HIP(r, dout.resize(4 * (size_t)n));
+        C_HIP(r, hipMemcpyAsync(duv.p, uv_host, 8 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        hipLaunchKernelGGL(atn::k_sample_texture, dim3((n + 255) / 256), dim3(256), 0, r.stream, r.scene, texid, n, (const float*)duv.p, dout.p);
+        C_HIP(r, hipGetLastError());
+        C_HIP(r, hipMemcpyAsync(out_host, dout.p, 16 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+        C_HIP(r, hipStreamSynchronize(r.stream));
+        return ATN_OK;
+    });
 }
 
 int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n)

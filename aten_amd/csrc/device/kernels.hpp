@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         // ImageBasedLight::samplePdf, light/ibl.h:46-58
                         float pdfLight = luminance(emit.x, emit.y, emit.z) / sc.avgIllum;
                         pdfLight /= (2.0f * kPi);
+                        if (sc.ibl_importance) pdfLight = ibl_direction_pdf(sc, dir);   // optional table sampler: its own density
                         misW = pdfb / (pdfLight + pdfb);
                     }
                     f3 c = 1.0F * mk3(mul4(misW, emit)) + mk3(0.0F);   // ApplyAlphaBlend (transmission 1, throughput 0)
@@ -864,6 +865,14 @@ __global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim
         Cmj s; s.idx = index; s.dim = dim; s.scramble = scramble;
         for (int i = 0; i < n; i++) out[i] = cmj_next(s);
     }
+}
+
+__global__ void __launch_bounds__(256) k_sample_texture(DevScene sc, int32_t texid, uint32_t n, const float* __restrict__ uv, float* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = sample_texture(sc, texid, uv[2 * i], uv[2 * i + 1], make_float4(0, 0, 0, 0));
+    out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
 }
 
 // BSDF table: for case i sample at (n, wi) with sampler (index, dim 0, scramble), then re-evaluate pdf/bsdf at the sampled dir

@@ -94,6 +94,12 @@ struct DevScene {
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
+    // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
+    const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
+    const float* ibl_cdf_u;             // [ibl_h][ibl_w]
+    int32_t ibl_w, ibl_h;
+    int32_t ibl_importance;             // 1 = sample the IBL light from those tables (ImageBasedLight::sample, ibl.cpp:180-230)
+    int32_t tex_bilinear;               // 1 = texture::AtWithBilinear (image/texture.cpp:77-125) instead of texture::at
 };
 
 } // namespace atn

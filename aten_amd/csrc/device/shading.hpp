@@ -71,14 +71,8 @@ ATN_DEV int32_t wrap_repeat(int32_t value, int32_t wrap_size)
     else if (value < 0) { int32_t n = abs(value / wrap_size); value += (n + 1) * wrap_size; }
     return value;
 }
-ATN_DEV float4 sample_texture(const DevScene& sc, int32_t texid, float u, float v, const float4& def)
+ATN_DEV float4 fetch_texel(const DevScene& sc, const DevTexture& t, int32_t x, int32_t y)
 {
-    if (texid < 0 || texid >= sc.n_textures) return def;
-    const DevTexture t = sc.textures[texid];
-    const int32_t iu = (int32_t)(u * (float)(t.width - 1));
-    const int32_t iv = (int32_t)(v * (float)(t.height - 1));
-    const int32_t x = wrap_repeat(iu, t.width - 1);
-    const int32_t y = wrap_repeat(iv, t.height - 1);
     const uint32_t idx = t.offset + (uint32_t)(y * t.width + x);
     if (t.format) {
         // the same IEEE operation the caller's 8-bit -> float conversion made (which one: checked per texel at upload)
@@ -89,6 +83,39 @@ ATN_DEV float4 sample_texture(const DevScene& sc, int32_t texid, float u, float 
         return make_float4(r * norm, g * norm, b * norm, a * norm);
     }
     return sc.texels[idx];
+}
+ATN_DEV float4 lerp4(const float4& a, const float4& b, float f)      // aten::lerp, math/math.h:190-194
+{
+    return add4(mul4(1.0F - f, a), mul4(f, b));
+}
+ATN_DEV float4 sample_texture(const DevScene& sc, int32_t texid, float u, float v, const float4& def)
+{
+    if (texid < 0 || texid >= sc.n_textures) return def;
+    const DevTexture t = sc.textures[texid];
+    if (sc.tex_bilinear) {
+        // texture::AtWithBilinear, image/texture.cpp:77-125, as the reference writes it (its "nearest" neighbour and
+        // weight rule included); texel coordinates are clamped into the image, which the reference leaves to the caller
+        const float fx = u * (float)(t.width - 1);
+        const float fy = v * (float)(t.height - 1);
+        float frac_x = (fx - 0.5F) - (float)(int32_t)fx;
+        float frac_y = (fy - 0.5F) - (float)(int32_t)fy;
+        int32_t x = (int32_t)fx, y = (int32_t)fy;
+        int32_t nx, ny;
+        if (frac_x >= 0.5F) nx = x + 1; else { nx = x - 1; frac_x = 1.0F - frac_x; }
+        if (frac_y >= 0.5F) ny = y + 1; else { ny = y - 1; frac_y = 1.0F - frac_y; }
+        nx = nx < 0 ? 0 : (nx > t.width - 1 ? t.width - 1 : nx);
+        ny = ny < 0 ? 0 : (ny > t.height - 1 ? t.height - 1 : ny);
+        x = x < 0 ? 0 : (x > t.width - 1 ? t.width - 1 : x);
+        y = y < 0 ? 0 : (y > t.height - 1 ? t.height - 1 : y);
+        const float4 c00 = fetch_texel(sc, t, x, y), c10 = fetch_texel(sc, t, nx, y);
+        const float4 c01 = fetch_texel(sc, t, x, ny), c11 = fetch_texel(sc, t, nx, ny);
+        return lerp4(lerp4(c00, c10, frac_x), lerp4(c01, c11, frac_x), frac_y);
+    }
+    const int32_t iu = (int32_t)(u * (float)(t.width - 1));
+    const int32_t iv = (int32_t)(v * (float)(t.height - 1));
+    const int32_t x = wrap_repeat(iu, t.width - 1);
+    const int32_t y = wrap_repeat(iv, t.height - 1);
+    return fetch_texel(sc, t, x, y);
 }
 
 // applyNormalMap, material/sample_texture.h:62-87
@@ -732,6 +759,58 @@ ATN_DEV f3 area_light_color(const atn_light_param& p, float area)   // light/are
     return mk3(p.light_color[0], p.light_color[1], p.light_color[2]) * lum;
 }
 
+// samplePdfAndCdf, light/ibl.cpp:133-176: binary search of a CDF normalised to [0, 1]; returns the cell and its probability
+ATN_DEV int32_t ibl_sample_cdf(float r, const float* __restrict__ cdf, int32_t n, float& out_pdf)
+{
+    if (n < 2) { out_pdf = n == 1 ? cdf[0] : 0.0F; return 0; }     // (the reference's loop needs two cells)
+    int32_t top = 0, tail = n - 1;
+    for (;;) {
+        const int32_t mid = (top + tail) >> 1;
+        if (r < cdf[mid]) tail = mid; else top = mid;
+        if (tail - top == 1) {
+            const float top_c = cdf[top], tail_c = cdf[tail];
+            if (r <= top_c) { out_pdf = top_c; return top; }
+            out_pdf = tail_c - top_c;
+            return tail;
+        }
+    }
+}
+// Background::ConvertUVToDirection, renderer/background.h:64-86
+ATN_DEV f3 uv_to_direction(float u, float v)
+{
+    const float phi = (2 * kPi) * u;
+    const float theta = (1 - v) * kPi;
+    f3 dir;
+    dir.y = cosf(theta);
+    const float xz = sqrtf(1 - dir.y * dir.y);
+    dir.x = xz * sinf(phi);
+    dir.z = xz * cosf(phi);
+    return normalize(dir);
+}
+// Solid-angle density of the table sampler for texel (x, y): P(x, y) * w * h / (2 pi^2 sin(theta_y)).
+// (ImageBasedLight::sample writes pi^2 where the texel's solid angle (2 pi / w)(pi / h) sin(theta) calls for 2 pi^2; with
+// its constant the estimator is half as bright as the scene.  This is an optional sampler, not a parity path: the
+// density used here is the true one, and the SAME function prices both the light sample and the BSDF-sampled miss.)
+ATN_DEV float ibl_texel_pdf(const DevScene& sc, float pdf_u, float pdf_v, int32_t y)
+{
+    const float v = (float)((double)y + 0.5) / (float)sc.ibl_h;
+    const float theta = kPi * v;
+    const float pi2 = kPi * kPi;
+    return (pdf_u * pdf_v) * ((float)(sc.ibl_w * sc.ibl_h) / ((2.0F * pi2) * sinf(theta)));
+}
+ATN_DEV float ibl_direction_pdf(const DevScene& sc, const f3& dir)
+{
+    float u, v;
+    direction_to_uv(dir, u, v);
+    int32_t x = (int32_t)(u * (float)sc.ibl_w), y = (int32_t)(v * (float)sc.ibl_h);
+    x = x < 0 ? 0 : (x > sc.ibl_w - 1 ? sc.ibl_w - 1 : x);
+    y = y < 0 ? 0 : (y > sc.ibl_h - 1 ? sc.ibl_h - 1 : y);
+    const float* __restrict__ cu = sc.ibl_cdf_u + (size_t)y * sc.ibl_w;
+    const float pu = x > 0 ? cu[x] - cu[x - 1] : cu[0];
+    const float pv = y > 0 ? sc.ibl_cdf_v[y] - sc.ibl_cdf_v[y - 1] : sc.ibl_cdf_v[0];
+    return ibl_texel_pdf(sc, pu, pv, y);
+}
+
 // Light::sample (light/light_impl.h:12-43) and the per-type samplers it dispatches to
 ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const DevScene& sc, const f3& org, const f3& nml, Cmj& smp)
 {
@@ -812,6 +891,22 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
     }
     case ATN_LIGHT_IBL: {       // ImageBasedLight::sample, light/ibl.h:71-133
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+        if (sc.ibl_importance) {
+            // the table sampler, ImageBasedLight::sample(ctxt, org, nml, sampler), light/ibl.cpp:180-230
+            float pdf_u, pdf_v;
+            const int32_t y = ibl_sample_cdf(r1, sc.ibl_cdf_v, sc.ibl_h, pdf_v);
+            const int32_t x = ibl_sample_cdf(r2, sc.ibl_cdf_u + (size_t)y * sc.ibl_w, sc.ibl_w, pdf_u);
+            const float u = (float)((double)x + 0.5) / (float)sc.ibl_w;
+            const float v = (float)((double)y + 0.5) / (float)sc.ibl_h;
+            res.pdf = ibl_texel_pdf(sc, pdf_u, pdf_v, y);
+            res.dir = uv_to_direction(u, v);
+            const float4 lum = mul4(sc.multiplyer, sample_texture(sc, lp.envmapidx, u, v, make_float4(1, 1, 1, 1)));
+            res.color = mk3(mul4(lp.scale, lum));
+            res.pos = org + sc.ibl_scene_radius * res.dir;      // (the reference leaves pos unset there: "currently not used")
+            res.nml = -normalize(res.dir);
+            res.dist = 1.0F;
+            break;
+        }
         res.dir = diffuse_dir(nml, r1, r2);
         float u, v;
         direction_to_uv(res.dir, u, v);

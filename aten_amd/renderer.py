@@ -86,6 +86,15 @@ class PathTracing:
     def set_frames_in_flight(self, n):
         self._check(self._l.atn_set_frames_in_flight(self._ctx, n))
 
+    def set_sampling_options(self, ibl_importance=False, tex_bilinear=False):
+        self._check(self._l.atn_set_sampling_options(self._ctx, int(ibl_importance), int(tex_bilinear)))
+
+    def sample_texture(self, texid, uv):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 4), np.float32)
+        self._check(self._l.atn_sample_texture(self._ctx, texid, len(uv), uv.ctypes.data, out.ctypes.data))
+        return out
+
     def reset(self):
         self._check(self._l.atn_reset(self._ctx))
 

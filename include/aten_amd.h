@@ -136,6 +136,18 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n);
  * every other entry point first waits for all frames in flight. */
 int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n);
 
+/* Optional samplers, both off by default: they change the sample stream, i.e. they leave the parity path of
+ * aten::PathTracing (every default-mode result still matches the CPU renderer).
+ *   ibl_importance != 0: the IBL light is sampled from the luminance tables of the environment map --
+ *       ImageBasedLight::preCompute (src/libaten/light/ibl.cpp:10-118) and the table sampler ImageBasedLight::sample
+ *       (ibl.cpp:180-230) -- instead of light/ibl.h:98-100's cosine-hemisphere sampling; BSDF-sampled misses are weighted
+ *       with the same density.
+ *   tex_bilinear != 0: every texture lookup is aten::texture::AtWithBilinear (src/libaten/image/texture.cpp:77-125)
+ *       instead of texture::at (the CUDA backend filters with tex2DLod, material/sample_texture.h:18-40). */
+int atn_set_sampling_options(atn_ctx* ctx, int32_t ibl_importance, int32_t tex_bilinear);
+/* Stage probe: n lookups of texture `texid` at uv_host[2n] -> out_host[4n], with the current texture mode. */
+int atn_sample_texture(atn_ctx* ctx, int32_t texid, uint32_t n, const float* uv_host, float* out_host);
+
 /* ---- one node, every GPU ------------------------------------------------------------------------
  * The reference renderer is single-device (idaten::Renderer, src/libidaten/kernel/renderer.h:17-179; its caller
  * src/device_renderer/main.cpp:133-149,196-204 makes one UpdateSceneData and one render(dst) per frame).  An

@@ -137,11 +137,44 @@ struct orc_destination {    // aten::Destination (renderer/renderer.h:15-23) + e
 // aten::PathTracing::OnRender, renderer/pathtracing/pathtracing.cpp:269-366.
 // film: vec4[w*h], row 0 = bottom.  counters_out (may be null): {closest rays, shadow rays, hits,
 // node visits, triangle tests}.
+// Optional samplers of the product (atn_set_sampling_options), so that they too have a CPU twin to be compared with.
+void orc_set_sampling_options(int32_t ibl_importance, int32_t tex_bilinear)
+{
+    sampling_options().ibl_importance = ibl_importance;
+    sampling_options().tex_bilinear = tex_bilinear;
+}
+
+// texture::at / texture::AtWithBilinear for n lookups of one texture (current texture mode)
+void orc_sample_texture(const atn_scene_desc* scene, int32_t texid, uint32_t n, const float* uv, float* out)
+{
+    Scene ctxt(scene);
+    for (uint32_t i = 0; i < n; i++) {
+        const v4 c = sampleTexture(ctxt, texid, uv[2 * i], uv[2 * i + 1], v4(0.0F));
+        out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
+    }
+}
+
+// ImageBasedLight::preCompute's tables (cdfV[h], cdfU[h*w]) for the scene's environment map
+int32_t orc_ibl_tables(const atn_scene_desc* scene, float* cdf_v, float* cdf_u)
+{
+    Scene ctxt(scene);
+    if (ctxt.cfg().bg.envmap_tex_idx < 0) return -1;
+    SamplingOptions& o = sampling_options();
+    IBL_preCompute(o, ctxt);
+    for (int32_t y = 0; y < o.h; y++) {
+        cdf_v[y] = o.cdfV[y];
+        for (int32_t x = 0; x < o.w; x++) cdf_u[(size_t)y * o.w + x] = o.cdfU[y][x];
+    }
+    return 0;
+}
+
 void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
     const uint32_t* seeds, uint32_t n_seeds, const orc_destination* dst, atn_vec4* film,
     uint64_t* counters_out)
 {
     Scene ctxt(scene);
+    if (sampling_options().ibl_importance && ctxt.cfg().bg.envmap_tex_idx >= 0 && ctxt.cfg().bg.enable_env_map)
+        IBL_preCompute(sampling_options(), ctxt);
     const int32_t width = dst->width, height = dst->height;
     const uint32_t samples = (uint32_t)dst->sample;
     int32_t maxDepth = dst->maxDepth;

@@ -110,6 +110,18 @@ def render(scene, cam, seeds, width, height, max_depth=5, rr_depth=3, spp=1, fra
     return (film, cnt) if counters else film
 
 
+def set_sampling_options(ibl_importance=False, tex_bilinear=False):
+    """The product's optional samplers (atn_set_sampling_options) on the CPU twin.  Global: reset after use."""
+    lib().orc_set_sampling_options(C.c_int32(int(ibl_importance)), C.c_int32(int(tex_bilinear)))
+
+
+def sample_texture(scene, texid, uv):
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    out = np.zeros((len(uv), 4), np.float32)
+    lib().orc_sample_texture(scene.ref(), C.c_int32(texid), C.c_uint32(len(uv)), C.c_void_p(uv.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
 class Svgf:
     """aten::SVGFRenderer on the CPU oracle (oracle/orc_svgf.h): frame-persistent AOV / moment buffers."""
     BUFFERS = dict(normal_depth=0, albedo_meshid=1, color_variance=2, moment_temporalweight=3,

@@ -449,10 +449,48 @@ inline v4 texture_at(const atn_texture_desc& tex, float u, float v)
     return v4(c.x, c.y, c.z, c.w);
 }
 
+// Optional samplers (off = the parity path of aten::PathTracing): see include/aten_amd.h, atn_set_sampling_options.
+struct SamplingOptions {
+    int ibl_importance = 0, tex_bilinear = 0;
+    // ImageBasedLight::preCompute tables (light/ibl.cpp:10-118), rebuilt whenever the envmap pointer / size changes
+    const atn_vec4* env = nullptr; int32_t w = 0, h = 0; float multiplyer = 0.0F;
+    std::vector<float> cdfV; std::vector<std::vector<float>> cdfU;
+};
+inline SamplingOptions& sampling_options() { static SamplingOptions o; return o; }
+
+// texture::AtWithBilinear, image/texture.cpp:77-125 (texel coordinates clamped into the image)
+inline v4 texture_at_bilinear(const atn_texture_desc& tex, float u, float v)
+{
+    const int32_t width_ = tex.width, height_ = tex.height;
+    const float fx = u * (width_ - 1);
+    const float fy = v * (height_ - 1);
+    float frac_x = fx - 0.5F - static_cast<int32_t>(fx);
+    float frac_y = fy - 0.5F - static_cast<int32_t>(fy);
+    auto x = static_cast<int32_t>(fx);
+    auto y = static_cast<int32_t>(fy);
+    auto nearest_x = x;
+    if (frac_x >= 0.5F) { nearest_x = x + 1; }
+    else { nearest_x = x - 1; frac_x = 1.0F - frac_x; }
+    auto nearest_y = y;
+    if (frac_y >= 0.5F) { nearest_y = y + 1; }
+    else { nearest_y = y - 1; frac_y = 1.0F - frac_y; }
+    nearest_x = std::min(std::max(nearest_x, 0), width_ - 1);
+    nearest_y = std::min(std::max(nearest_y, 0), height_ - 1);
+    x = std::min(std::max(x, 0), width_ - 1);
+    y = std::min(std::max(y, 0), height_ - 1);
+    auto at = [&](int32_t xx, int32_t yy) { const atn_vec4& c = tex.texels[(uint32_t)(yy * width_ + xx)]; return v4(c.x, c.y, c.z, c.w); };
+    const v4 c00 = at(x, y), c10 = at(nearest_x, y), c01 = at(x, nearest_y), c11 = at(nearest_x, nearest_y);
+    auto lerp = [](const v4& a, const v4& b, float f) { return a * (1.0F - f) + b * f; };
+    const v4 c0 = lerp(c00, c10, frac_x);
+    const v4 c1 = lerp(c01, c11, frac_x);
+    return lerp(c0, c1, frac_y);
+}
+
 inline v4 sampleTexture(const Scene& ctxt, int32_t texid, float u, float v, const v4& defaultValue)
 {
     v4 ret = defaultValue;
     if (texid >= 0 && (uint32_t)texid < ctxt.d->n_textures && ctxt.d->textures[texid].texels) {
+        if (sampling_options().tex_bilinear) return texture_at_bilinear(ctxt.d->textures[texid], u, v);
         ret = texture_at(ctxt.d->textures[texid], u, v);
     }
     return ret;

@@ -868,10 +868,109 @@ inline float scene_radius_for_ibl(const Scene& ctxt)    // ibl.h:106-111, math/a
     return scene_radius;
 }
 
+// ---- optional table sampler: ImageBasedLight::preCompute + sample(ctxt, org, nml, sampler), light/ibl.cpp:10-230
+inline void IBL_preCompute(SamplingOptions& o, const Scene& ctxt)
+{
+    const auto& bg = ctxt.cfg().bg;
+    const atn_texture_desc& envmap = ctxt.d->textures[bg.envmap_tex_idx];
+    if (o.env == envmap.texels && o.w == envmap.width && o.h == envmap.height && o.multiplyer == bg.multiplyer) return;
+    o.env = envmap.texels; o.w = envmap.width; o.h = envmap.height; o.multiplyer = bg.multiplyer;
+    const int32_t width = envmap.width, height = envmap.height;
+    o.cdfV.clear(); o.cdfU.assign(height, std::vector<float>());
+    for (int32_t y = 0; y < height; y++) {
+        float scale = std::sin(PI * (float)(y + 0.5) / height);
+        float pdfV = 0;
+        std::vector<float>& pdfU = o.cdfU[y];
+        for (int32_t x = 0; x < width; x++) {
+            float u = (float)(x + 0.5) / width;
+            float v = (float)(y + 0.5) / height;
+            const v4 t = texture_at(envmap, u, v);
+            const v3 clr = v3(t.x, t.y, t.z) * bg.multiplyer;      // SampleFromUVWithTexture, ibl.h:147-153
+            const float illum = luminance(clr);
+            pdfV += illum * scale;
+            pdfU.push_back(illum * scale);
+        }
+        o.cdfV.push_back(pdfV);
+    }
+    auto normalise = [](std::vector<float>& c) {
+        float sum = 0;
+        for (size_t i = 0; i < c.size(); i++) { sum += c[i]; if (i > 0) c[i] += c[i - 1]; }
+        if (sum > 0) {
+            float invSum = 1 / sum;
+            for (size_t i = 0; i < c.size(); i++) { c[i] *= invSum; c[i] = std::min(std::max(c[i], 0.0F), 1.0F); }
+        }
+    };
+    normalise(o.cdfV);
+    for (auto& row : o.cdfU) normalise(row);
+}
+inline int32_t IBL_samplePdfAndCdf(float r, const std::vector<float>& cdf, float& outPdf)     // ibl.cpp:133-176
+{
+    outPdf = 0;
+    if (cdf.size() < 2) { outPdf = cdf.empty() ? 0.0F : cdf[0]; return 0; }
+    int32_t idxTop = 0, idxTail = (int32_t)cdf.size() - 1;
+    for (;;) {
+        int32_t idxMid = (idxTop + idxTail) >> 1;
+        if (r < cdf[idxMid]) idxTail = idxMid; else idxTop = idxMid;
+        if ((idxTail - idxTop) == 1) {
+            const float topCdf = cdf[idxTop], tailCdf = cdf[idxTail];
+            if (r <= topCdf) { outPdf = topCdf; return idxTop; }
+            outPdf = tailCdf - topCdf;
+            return idxTail;
+        }
+    }
+}
+// the true solid-angle density of the table sampler (the reference writes pi^2 where the texel's solid angle calls for
+// 2 pi^2: see csrc/device/shading.hpp, ibl_texel_pdf)
+inline float IBL_texel_pdf(const SamplingOptions& o, float pdfU, float pdfV, int32_t y)
+{
+    const float v = (float)(y + 0.5) / o.h;
+    const float theta = PI * v;
+    const float pi2 = PI * PI;
+    return (pdfU * pdfV) * ((float)(o.w * o.h) / ((2.0F * pi2) * std::sin(theta)));
+}
+inline v3 ConvertUVToDirection(float u, float v)       // renderer/background.h:64-86
+{
+    float phi = 2 * PI * u;
+    float theta = (1 - v) * PI;
+    v3 dir;
+    dir.y = std::cos(theta);
+    float xz = std::sqrt(1 - dir.y * dir.y);
+    dir.x = xz * std::sin(phi);
+    dir.z = xz * std::cos(phi);
+    return normalize(dir);
+}
+inline float IBL_direction_pdf(const Scene& ctxt, const v3& dir)
+{
+    SamplingOptions& o = sampling_options();
+    const v3 uv = ConvertDirectionToUV(dir);
+    int32_t x = (int32_t)(uv.x * (float)o.w), y = (int32_t)(uv.y * (float)o.h);
+    x = std::min(std::max(x, 0), o.w - 1); y = std::min(std::max(y, 0), o.h - 1);
+    const std::vector<float>& cu = o.cdfU[y];
+    const float pu = x > 0 ? cu[x] - cu[x - 1] : cu[0];
+    const float pv = y > 0 ? o.cdfV[y] - o.cdfV[y - 1] : o.cdfV[0];
+    return IBL_texel_pdf(o, pu, pv, y);
+}
+
 inline void IBL_sample(LightSampleResult& result, const atn_light_param& param, const Scene& ctxt, const v3& org, const v3& nml, CMJ* sampler)
 {
     const float r1 = sampler->nextSample();
     const float r2 = sampler->nextSample();
+    SamplingOptions& o = sampling_options();
+    if (o.ibl_importance && ctxt.cfg().bg.envmap_tex_idx >= 0 && ctxt.cfg().bg.enable_env_map) {
+        float pdfU, pdfV;
+        const int32_t y = IBL_samplePdfAndCdf(r1, o.cdfV, pdfV);
+        const int32_t x = IBL_samplePdfAndCdf(r2, o.cdfU[y], pdfU);
+        const float u = (float)(x + 0.5) / o.w;
+        const float v = (float)(y + 0.5) / o.h;
+        result.pdf = IBL_texel_pdf(o, pdfU, pdfV, y);
+        result.dir = ConvertUVToDirection(u, v);
+        const v4 lum = sampleTexture(ctxt, param.envmapidx, u, v, v4(1.0F)) * ctxt.cfg().bg.multiplyer;
+        result.light_color = (param.scale * lum).xyz();
+        result.pos = org + scene_radius_for_ibl(ctxt) * result.dir;
+        result.nml = -normalize(result.dir);
+        result.dist_to_light = 1.0F;
+        return;
+    }
     result.dir = Diffuse::SampleDirection(nml, r1, r2);
     const v3 uv = ConvertDirectionToUV(result.dir);
     float scene_radius = scene_radius_for_ibl(ctxt);
@@ -1232,6 +1331,8 @@ inline void ShadeMiss(int32_t ix, int32_t iy, int32_t width, int32_t height, int
         }
         else {
             float pdfLight = IBL_samplePdf(emit.xyz(), ctxt.cfg().bg.avgIllum);
+            if (sampling_options().ibl_importance && ctxt.cfg().bg.envmap_tex_idx >= 0 && ctxt.cfg().bg.enable_env_map)
+                pdfLight = IBL_direction_pdf(ctxt, dir);
             misW = path.pdfb / (pdfLight + path.pdfb);
         }
         // ApplyAlphaBlend: transmission(1) * c + throughput(0)

@@ -639,6 +639,223 @@ ATN_DEV void microfacet_refraction_sample(MtrlSample& r, const DevScene& sc, con
     }
 }
 
+// Retroreflective, material/retroreflective.cpp:17-612 (prismatic-sheet model: Beckman surface reflection + retroreflection
+// lobe around -wi + diffuse, mixed by Fresnel F and the effective retroreflective area E of the refracted direction).
+// kEraTable: {incident angle inside the sheet in degrees, effective retroreflective area} -- measured data the model
+// interpolates (retroreflective.cpp:59-161), angle literals as the reference spells them.
+struct EraEntry { float deg, area; };
+__device__ const EraEntry kEraTable[101] = {
+    { 0.00000F, 0.64754F }, { 0.90000F, 0.65542F }, { 1.80000F, 0.65597F }, { 2.70000F, 0.65809F },
+    { 3.60000F, 0.65676F }, { 4.50000F, 0.65617F }, { 5.40000F, 0.65473F }, { 6.30000F, 0.65207F },
+    { 7.20000F, 0.64913F }, { 8.10000F, 0.64519F }, { 9.00000F, 0.64118F }, { 9.90000F, 0.63707F },
+    { 10.80000F, 0.63161F }, { 11.70000F, 0.62889F }, { 12.60000F, 0.62211F }, { 13.50000F, 0.61503F },
+    { 14.40000F, 0.60473F }, { 15.30000F, 0.59359F }, { 16.20000F, 0.58159F }, { 17.10000F, 0.56907F },
+    { 18.00000F, 0.55633F }, { 18.90000F, 0.54344F }, { 19.80000F, 0.53001F }, { 20.70000F, 0.51531F },
+    { 21.60000F, 0.49711F }, { 22.50000F, 0.47744F }, { 23.40000F, 0.45818F }, { 24.30000F, 0.43884F },
+    { 25.20000F, 0.41917F }, { 26.10000F, 0.39954F }, { 27.00000F, 0.37793F }, { 27.90000F, 0.35501F },
+    { 28.80000F, 0.33171F }, { 29.70000F, 0.30684F }, { 30.60000F, 0.28187F }, { 31.50000F, 0.25732F },
+    { 32.40000F, 0.22999F }, { 33.30000F, 0.20212F }, { 34.20000F, 0.17373F }, { 35.10000F, 0.14399F },
+    { 36.00000F, 0.11725F }, { 36.90000F, 0.09801F }, { 37.80000F, 0.08237F }, { 38.70000F, 0.06934F },
+    { 39.60000F, 0.05785F }, { 40.50000F, 0.04836F }, { 41.40001F, 0.03978F }, { 42.30000F, 0.03220F },
+    { 43.20000F, 0.02613F }, { 44.10000F, 0.02063F }, { 45.00000F, 0.01595F }, { 45.90000F, 0.01213F },
+    { 46.80000F, 0.00893F }, { 47.70000F, 0.00630F }, { 48.60000F, 0.00445F }, { 49.50000F, 0.00273F },
+    { 50.40000F, 0.00157F }, { 51.30000F, 0.00081F }, { 52.20000F, 0.00036F }, { 53.10000F, 0.00012F },
+    { 54.00000F, 0.00001F }, { 54.90000F, 0.00000F }, { 55.80000F, 0.00000F }, { 56.70000F, 0.00000F },
+    { 57.60000F, 0.00000F }, { 58.50000F, 0.00000F }, { 59.40000F, 0.00000F }, { 60.30000F, 0.00000F },
+    { 61.20000F, 0.00000F }, { 62.10001F, 0.00000F }, { 63.00000F, 0.00000F }, { 63.90001F, 0.00000F },
+    { 64.80000F, 0.00000F }, { 65.70000F, 0.00000F }, { 66.60001F, 0.00000F }, { 67.50000F, 0.00000F },
+    { 68.39999F, 0.00000F }, { 69.30000F, 0.00000F }, { 70.20000F, 0.00000F }, { 71.10000F, 0.00000F },
+    { 72.00000F, 0.00000F }, { 72.90000F, 0.00000F }, { 73.80000F, 0.00000F }, { 74.70000F, 0.00000F },
+    { 75.60000F, 0.00000F }, { 76.50000F, 0.00000F }, { 77.40000F, 0.00000F }, { 78.30000F, 0.00000F },
+    { 79.20000F, 0.00000F }, { 80.10001F, 0.00000F }, { 81.00001F, 0.00000F }, { 81.90000F, 0.00000F },
+    { 82.80001F, 0.00000F }, { 83.70000F, 0.00000F }, { 84.60000F, 0.00000F }, { 85.50001F, 0.00000F },
+    { 86.40000F, 0.00000F }, { 87.30000F, 0.00000F }, { 88.20000F, 0.00000F }, { 89.10001F, 0.00000F },
+    { 90.00000F, 0.00000F },
+};
+ATN_DEV float deg2rad(float d) { return (kPi * (d) / 180.0F); }           // aten::Deg2Rad, math/math.h:18-21
+ATN_DEV float retro_era(const f3& into_sheet_dir, const f3& surface_normal)    // GetEffectiveRetroreflectiveArea, :167-202
+{
+    const float c = dot(into_sheet_dir, -surface_normal);
+    if (c < 0.0F) return 0.0F;
+    const float theta = acosf(c);
+    const float step = deg2rad(90.00000F) / (float)(101 - 1);
+    const uint32_t idx = (uint32_t)(theta / step);
+    if (idx >= 101u) return 0.0F;
+    const float d = deg2rad(kEraTable[idx].deg);
+    const float t = smin(1.0F, fabsf(d - theta) / step);
+    const float a = kEraTable[idx].area;
+    const float b = idx < 100u ? kEraTable[idx + 1].area : 0.0F;
+    return a * (1 - t) + b * t;
+}
+ATN_DEV float retro_roughness(float roughness, float ni, float nt, const f3& wi, const f3& wn)    // ComputeRoughness, :204-231
+{
+    const f3 uo = -wi;
+    const f3 ut = refract_vector(ni, nt, wi, wn);
+    const float n = nt / ni;
+    const float J1_denom = dot(-wi, wn) + n * dot(ut, wn);
+    const float J1 = J1_denom > 0 ? fabsf(dot(uo, wn)) / sqr(J1_denom) : 0.0F;
+    const float J2_denom = -n * dot(ut, wn) + dot(uo, wn);
+    const float J2 = J2_denom > 0 ? fabsf(dot(uo, wn)) / sqr(J2_denom) : 0.0F;
+    const float a2 = roughness * roughness;
+    const float a0 = (J1 > 0 ? a2 / J1 : 0.0F) + (J2 > 0 ? a2 / J2 : 0.0F);
+    return sqrtf(a0);
+}
+ATN_DEV f3 retro_rr_brdf(float roughness, float ior, const f3& wn, const f3& wi, const f3& wo, float& used_E, float& used_F)   // :233-274
+{
+    const float ni = 1.0F, nt = ior;
+    const f3 uo = -wi;
+    const f3 ut = refract_vector(ni, nt, wi, wn);
+    const float E = retro_era(ut, wn);
+    used_E = E;
+    const float a = retro_roughness(roughness, ni, nt, wi, wn);
+    const float D = beckman_D(wo, uo, a);
+    float F = (1.0F - schlick_fresnel(ni, nt, -wi, wn));
+    F *= (1.0F - schlick_fresnel(ni, nt, wo, wn));
+    used_F = F;
+    float G = beckman_G1(roughness, wi, ut);
+    G *= beckman_G1(roughness, ut, wo);
+    const float c = fabsf(dot(wo, wn));
+    return mk3(c > 0 ? (((E * F) * G) * D) / c : 0.0F);
+}
+ATN_DEV float retro_rr_pdf(float roughness, float ni, float nt, const f3& wn, const f3& wi, const f3& wo)     // :276-292
+{
+    const f3 uo = -wi;
+    const float a = retro_roughness(roughness, ni, nt, wi, wn);
+    const float D = beckman_D(wo, uo, a);
+    return D * fabsf(dot(uo, wo));
+}
+ATN_DEV f3 retro_rr_dir(float r1, float r2, float roughness, float ni, float nt, const f3& wi, const f3& wn)    // :294-327
+{
+    const f3 uo = -wi;
+    const float a = retro_roughness(roughness, ni, nt, wi, wn);
+    const float a2 = a * a;
+    const float theta = atanf(sqrtf(-a2 * logf(1.0F - r1 * 0.99F)));
+    const float phi = kPi2 * r2;
+    f3 t, b;
+    tangent_coordinate(uo, t, b);
+    const float costheta = cosf(theta), sintheta = sinf(theta);
+    const float cosphi = cosf(phi), sinphi = sinf(phi);
+    const f3 wo = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + uo * costheta;
+    return normalize(wo);
+}
+ATN_DEV f3 retro_diffuse_brdf(float E, float F, float ni, float nt)      // RetroreflectiveDiffuse::EvalBRDF, :332-358
+{
+    const float kd = 1.0F;
+    const float brdf_0 = ((F * (1.0F - E)) * sqr(ni / nt)) * (kd / kPi);
+    float f0 = (ni - nt) / (ni + nt);
+    f0 = f0 * f0;
+    const float Fd = (1.0F - f0) * (-160.0F / 21.0F);
+    return mk3(brdf_0 / (1.0F - kd * Fd));
+}
+ATN_DEV float retro_diffuse_pdf(const f3& n, const f3& wo) { return 1.0F / (1.0F - diffuse_pdf(n, wo)); }      // :360-369
+struct RetroW { float r, rr, d; };
+ATN_DEV RetroW retro_weights(float ni, float nt, const f3& wi, const f3& n)      // ComputeWeights, :379-407
+{
+    RetroW w;
+    const float F = schlick_fresnel(ni, nt, -wi, n);
+    w.r = F;
+    const f3 ut = refract_vector(ni, nt, wi, n);
+    const float E = retro_era(ut, n);
+    w.rr = (1 - F) * E;
+    w.d = (1 - F) * (1 - E);
+    float norm = 0.0F;
+    norm += w.r; norm += w.rr; norm += w.d;
+    w.r /= norm; w.rr /= norm; w.d /= norm;
+    return w;
+}
+// the E / F the diffuse term takes when the retroreflection lobe was not evaluated (:470-478, :559-567)
+ATN_DEV void retro_EF(float ni, float nt, const f3& wi, const f3& n, const f3& wo, float& E, float& F)
+{
+    const f3 ut = refract_vector(ni, nt, wi, n);
+    E = retro_era(ut, n);
+    F = (1.0F - schlick_fresnel(ni, nt, -wi, n));
+    F *= (1.0F - schlick_fresnel(ni, nt, wo, n));
+}
+ATN_DEV float retro_pdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)      // :419-446
+{
+    const float roughness = m.roughness, ni = 1.0F, nt = m.ior;
+    const RetroW w = retro_weights(ni, nt, wi, n);
+    float pdf = 0.0F;
+    if (w.r > 0.0F) pdf += w.r * beckman_pdf(roughness, n, wi, wo);
+    if (w.rr > 0.0F) pdf += w.rr * retro_rr_pdf(roughness, ni, nt, n, wi, wo);
+    if (w.d > 0.0F) pdf += w.d * retro_diffuse_pdf(n, wo);
+    return pdf;
+}
+ATN_DEV MtrlSample retro_bsdf(const DevMaterial& m, const f3& n, const f3& wi, const f3& wo)      // :448-500
+{
+    const float roughness = m.roughness, ior = m.ior, ni = 1.0F, nt = ior;
+    const RetroW w = retro_weights(ni, nt, wi, n);
+    f3 f_r = mk3(0.0F), f_rr = mk3(0.0F), f_d = mk3(0.0F);
+    float pdf = 0.0F;
+    if (w.r > 0.0F) {
+        f_r = beckman_brdf(roughness, ior, n, wi, wo);
+        pdf += beckman_pdf(roughness, n, wi, wo) * w.r;
+    }
+    float used_E = 0.0F, used_F = 0.0F;
+    if (w.rr > 0.0F) {
+        f_rr = retro_rr_brdf(roughness, ior, n, wi, wo, used_E, used_F);
+        pdf += retro_rr_pdf(roughness, ni, nt, n, wi, wo) * w.rr;
+    }
+    else retro_EF(ni, nt, wi, n, wo, used_E, used_F);
+    if (w.d > 0.0F) {
+        f_d = retro_diffuse_brdf(used_E, used_F, ni, nt);
+        pdf += retro_diffuse_pdf(n, wo) * w.d;
+    }
+    MtrlSample r;
+    r.bsdf = (f_r + f_rr) + f_d;
+    r.pdf = pdf;
+    r.dir = wo;
+    return r;
+}
+ATN_DEV void retro_sample(MtrlSample& res, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp)      // :502-611
+{
+    const float r1 = cmj_next(smp), r2 = cmj_next(smp), r3 = cmj_next(smp);
+    const float roughness = m.roughness, ior = m.ior, ni = 1.0F, nt = ior;
+    RetroW w = retro_weights(ni, nt, wi, n);
+    const float c0 = w.r, c1 = c0 + w.rr;         // GetCDF, :409-417
+    f3 f_r = mk3(0.0F), f_rr = mk3(0.0F), f_d = mk3(0.0F);
+    float pdf = 0.0F;
+    f3 wo = mk3(0.0F);
+    float used_E = 0.0F, used_F = 0.0F;
+    if (r3 < c0) {
+        wo = reflect_vector(wi, beckman_sample_m(roughness, n, r1, r2));
+        f_r = beckman_brdf(roughness, ior, n, wi, wo);
+        pdf += beckman_pdf(roughness, n, wi, wo) * w.r;
+        w.r = 0.0F;
+    }
+    else if (r3 < c1) {
+        wo = retro_rr_dir(r1, r2, roughness, ni, nt, wi, n);
+        f_rr = retro_rr_brdf(roughness, ior, n, wi, wo, used_E, used_F);
+        pdf += retro_rr_pdf(roughness, ni, nt, n, wi, wo) * w.rr;
+        w.rr = 0.0F;
+    }
+    else {
+        // the reference evaluates F with `wo` BEFORE it assigns it (:559-565; `aten::vec3 wo;` is still unset there):
+        // both sides of the parity test take the unset vector as (0, 0, 0)
+        retro_EF(ni, nt, wi, n, wo, used_E, used_F);
+        wo = diffuse_dir(n, r1, r2);
+        f_d = retro_diffuse_brdf(used_E, used_F, ni, nt);
+        pdf += retro_diffuse_pdf(n, wo) * w.d;
+        w.d = 0.0F;
+    }
+    if (w.r > 0.0F) {
+        f_r = beckman_brdf(roughness, ior, n, wi, wo);
+        pdf += beckman_pdf(roughness, n, wi, wo) * w.r;
+    }
+    if (w.rr > 0.0F) {
+        f_rr = retro_rr_brdf(roughness, ior, n, wi, wo, used_E, used_F);
+        pdf += retro_rr_pdf(roughness, ni, nt, n, wi, wo) * w.rr;
+    }
+    if (w.d > 0.0F) {
+        retro_EF(ni, nt, wi, n, wo, used_E, used_F);
+        f_d = retro_diffuse_brdf(used_E, used_F, ni, nt);
+        pdf += retro_diffuse_pdf(n, wo) * w.d;
+    }
+    res.pdf = pdf;
+    res.bsdf = (f_r + f_rr) + f_d;
+    res.dir = wo;
+}
+
 // material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
 ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
                              const f3& wi, Cmj& smp, float u, float v)
@@ -683,6 +900,9 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
     case ATN_MTRL_MICROFACET_REFRACTION:
         microfacet_refraction_sample(r, sc, m, normal, wi, smp, u, v);
         break;
+    case ATN_MTRL_RETROREFLECTIVE:
+        retro_sample(r, m, normal, wi, smp);
+        break;
     case ATN_MTRL_OREN_NAYAR: {
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
         r.dir = diffuse_dir(normal, r1, r2);
@@ -710,6 +930,7 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
     case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;
     case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
+    case ATN_MTRL_RETROREFLECTIVE: return retro_pdf(m, normal, wi, wo);
     default: return diffuse_pdf(normal, wo);
     }
 }
@@ -725,6 +946,7 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
     case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = mk3(0.0F); break;
     case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
+    case ATN_MTRL_RETROREFLECTIVE: r = retro_bsdf(m, normal, wi, wo); break;
     default: r.bsdf = diffuse_brdf(); break;
     }
     return r;

@@ -131,6 +131,10 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None, extra_ma
             return b.add_material(name, L.MTRL_MICROFACET_REFRACTION, (0.9, 0.9, 0.9), ior=1.5, roughness=0.2)
         if extra_materials == "rough" and name == "rightWall":
             return b.add_material(name, L.MTRL_VELVET, clr, roughness=0.4)
+        if extra_materials == "retro" and name == "rightWall":   # prismatic-sheet retroreflector (retroreflective.cpp)
+            return b.add_material(name, L.MTRL_RETROREFLECTIVE, clr, roughness=0.3, ior=1.5)
+        if extra_materials == "retro" and name == "tallBox":
+            return b.add_material(name, L.MTRL_RETROREFLECTIVE, (0.9, 0.9, 0.9), roughness=0.1, ior=1.33)
         if extra_materials and name == "backWall":
             return b.add_material(name, L.MTRL_BECKMAN, (0.7, 0.7, 0.7), roughness=0.25, ior=0.2)
         return b.add_material(name, mtype, clr)

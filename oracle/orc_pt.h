@@ -522,6 +522,225 @@ inline void sample(MaterialSampling* res, const Scene& ctxt, const atn_material_
 }
 } // namespace Beckman
 
+// ---- Retroreflective: material/retroreflective.cpp:17-612 -------------------------------------------------
+namespace Retroreflective {
+struct EraEntry { float deg, area; };
+// {angle in degrees, effective retroreflective area}: the measured table the model interpolates (retroreflective.cpp:59-161)
+static const EraEntry ERATable[101] = {
+    { 0.00000F, 0.64754F }, { 0.90000F, 0.65542F }, { 1.80000F, 0.65597F }, { 2.70000F, 0.65809F },
+    { 3.60000F, 0.65676F }, { 4.50000F, 0.65617F }, { 5.40000F, 0.65473F }, { 6.30000F, 0.65207F },
+    { 7.20000F, 0.64913F }, { 8.10000F, 0.64519F }, { 9.00000F, 0.64118F }, { 9.90000F, 0.63707F },
+    { 10.80000F, 0.63161F }, { 11.70000F, 0.62889F }, { 12.60000F, 0.62211F }, { 13.50000F, 0.61503F },
+    { 14.40000F, 0.60473F }, { 15.30000F, 0.59359F }, { 16.20000F, 0.58159F }, { 17.10000F, 0.56907F },
+    { 18.00000F, 0.55633F }, { 18.90000F, 0.54344F }, { 19.80000F, 0.53001F }, { 20.70000F, 0.51531F },
+    { 21.60000F, 0.49711F }, { 22.50000F, 0.47744F }, { 23.40000F, 0.45818F }, { 24.30000F, 0.43884F },
+    { 25.20000F, 0.41917F }, { 26.10000F, 0.39954F }, { 27.00000F, 0.37793F }, { 27.90000F, 0.35501F },
+    { 28.80000F, 0.33171F }, { 29.70000F, 0.30684F }, { 30.60000F, 0.28187F }, { 31.50000F, 0.25732F },
+    { 32.40000F, 0.22999F }, { 33.30000F, 0.20212F }, { 34.20000F, 0.17373F }, { 35.10000F, 0.14399F },
+    { 36.00000F, 0.11725F }, { 36.90000F, 0.09801F }, { 37.80000F, 0.08237F }, { 38.70000F, 0.06934F },
+    { 39.60000F, 0.05785F }, { 40.50000F, 0.04836F }, { 41.40001F, 0.03978F }, { 42.30000F, 0.03220F },
+    { 43.20000F, 0.02613F }, { 44.10000F, 0.02063F }, { 45.00000F, 0.01595F }, { 45.90000F, 0.01213F },
+    { 46.80000F, 0.00893F }, { 47.70000F, 0.00630F }, { 48.60000F, 0.00445F }, { 49.50000F, 0.00273F },
+    { 50.40000F, 0.00157F }, { 51.30000F, 0.00081F }, { 52.20000F, 0.00036F }, { 53.10000F, 0.00012F },
+    { 54.00000F, 0.00001F }, { 54.90000F, 0.00000F }, { 55.80000F, 0.00000F }, { 56.70000F, 0.00000F },
+    { 57.60000F, 0.00000F }, { 58.50000F, 0.00000F }, { 59.40000F, 0.00000F }, { 60.30000F, 0.00000F },
+    { 61.20000F, 0.00000F }, { 62.10001F, 0.00000F }, { 63.00000F, 0.00000F }, { 63.90001F, 0.00000F },
+    { 64.80000F, 0.00000F }, { 65.70000F, 0.00000F }, { 66.60001F, 0.00000F }, { 67.50000F, 0.00000F },
+    { 68.39999F, 0.00000F }, { 69.30000F, 0.00000F }, { 70.20000F, 0.00000F }, { 71.10000F, 0.00000F },
+    { 72.00000F, 0.00000F }, { 72.90000F, 0.00000F }, { 73.80000F, 0.00000F }, { 74.70000F, 0.00000F },
+    { 75.60000F, 0.00000F }, { 76.50000F, 0.00000F }, { 77.40000F, 0.00000F }, { 78.30000F, 0.00000F },
+    { 79.20000F, 0.00000F }, { 80.10001F, 0.00000F }, { 81.00001F, 0.00000F }, { 81.90000F, 0.00000F },
+    { 82.80001F, 0.00000F }, { 83.70000F, 0.00000F }, { 84.60000F, 0.00000F }, { 85.50001F, 0.00000F },
+    { 86.40000F, 0.00000F }, { 87.30000F, 0.00000F }, { 88.20000F, 0.00000F }, { 89.10001F, 0.00000F },
+    { 90.00000F, 0.00000F },
+};
+inline float GetEffectiveRetroreflectiveArea(const v3& into_prismatic_sheet_dir, const v3& surface_normal)
+{
+    const float c = dot(into_prismatic_sheet_dir, -surface_normal);
+    if (c < 0.0F) return 0.0F;
+    const float theta = std::acos(c);
+    const float Step = Deg2Rad(90.00000F) / (101 - 1);
+    const size_t idx = static_cast<size_t>(theta / Step);
+    float a = 0.0F, b = 0.0F, t = 0.0F;
+    if (idx >= 101) return 0.0F;
+    const float d = Deg2Rad(ERATable[idx].deg);
+    t = fmin_(1.0F, std::abs(d - theta) / Step);
+    a = ERATable[idx].area;
+    if (idx < 101 - 1) b = ERATable[idx + 1].area;
+    return a * (1 - t) + b * t;
+}
+inline float ComputeRoughness(float roughness, float ni, float nt, const v3& wi, const v3& wn)
+{
+    const v3 uo = -wi;
+    const v3 ut = Refraction::ComputeRefractVector(ni, nt, wi, wn);
+    const float n = nt / ni;
+    const float J1_denom = dot(-wi, wn) + n * dot(ut, wn);
+    const float J1 = J1_denom > 0 ? std::abs(dot(uo, wn)) / sqr(J1_denom) : 0.0F;
+    const float J2_denom = -n * dot(ut, wn) + dot(uo, wn);
+    const float J2 = J2_denom > 0 ? std::abs(dot(uo, wn)) / sqr(J2_denom) : 0.0F;
+    const float a = roughness;
+    const float a2 = a * a;
+    float a0 = (J1 > 0 ? a2 / J1 : 0.0F) + (J2 > 0 ? a2 / J2 : 0.0F);
+    a0 = std::sqrt(a0);
+    return a0;
+}
+inline v3 RR_EvalBRDF(float roughness, float ior, const v3& wn, const v3& wi, const v3& wo, float* used_E, float* used_F)
+{
+    const float ni = 1.0F, nt = ior;
+    const v3 uo = -wi;
+    const v3 ut = Refraction::ComputeRefractVector(ni, nt, wi, wn);
+    const float E = GetEffectiveRetroreflectiveArea(ut, wn);
+    *used_E = E;
+    const float a = ComputeRoughness(roughness, ni, nt, wi, wn);
+    const float D = Beckman::ComputeDistribution(wo, uo, a);
+    float F = (1.0F - ComputeSchlickFresnel(ni, nt, -wi, wn));
+    F *= (1.0F - ComputeSchlickFresnel(ni, nt, wo, wn));
+    *used_F = F;
+    float G = Beckman::ComputeG1(roughness, wi, ut);
+    G *= Beckman::ComputeG1(roughness, ut, wo);
+    const float c = std::abs(dot(wo, wn));
+    const float brdf = c > 0 ? E * F * G * D / c : 0.0F;
+    return v3(brdf);
+}
+inline float RR_EvalPDF(float roughness, float ni, float nt, const v3& wn, const v3& wi, const v3& wo)
+{
+    const v3 uo = -wi;
+    const float a = ComputeRoughness(roughness, ni, nt, wi, wn);
+    const float D = Beckman::ComputeDistribution(wo, uo, a);
+    return D * std::abs(dot(uo, wo));
+}
+inline v3 RR_SampleDirection(float r1, float r2, float roughness, float ni, float nt, const v3& wi, const v3& wn)
+{
+    const v3 uo = -wi;
+    const float a = ComputeRoughness(roughness, ni, nt, wi, wn);
+    const float a2 = a * a;
+    const float theta = std::atan(std::sqrt(-a2 * std::log(1.0F - r1 * 0.99F)));
+    const float phi = PI_2 * r2;
+    v3 t, b;
+    GetTangentCoordinate(uo, t, b);
+    const float costheta = std::cos(theta), sintheta = std::sin(theta);
+    const float cosphi = std::cos(phi), sinphi = std::sin(phi);
+    v3 wo = t * sintheta * cosphi + b * sintheta * sinphi + uo * costheta;
+    return normalize(wo);
+}
+inline v3 D_EvalBRDF(float E, float F, float ni, float nt)
+{
+    constexpr float kd = 1.0F;
+    const float brdf_0 = F * (1.0F - E) * sqr(ni / nt) * (kd / PI);
+    float f0 = (ni - nt) / (ni + nt);
+    f0 = f0 * f0;
+    const float Fd = (1.0F - f0) * (-160.0F / 21.0F);
+    return v3(brdf_0 / (1.0F - kd * Fd));
+}
+inline float D_EvalPDF(const v3& n, const v3& wo) { return 1.0F / (1.0F - Diffuse::ComputePDF(n, wo)); }
+inline void ComputeWeights(float w[3], float ni, float nt, const v3& wi, const v3& n)
+{
+    const float F = ComputeSchlickFresnel(ni, nt, -wi, n);
+    w[0] = F;
+    const v3 ut = Refraction::ComputeRefractVector(ni, nt, wi, n);
+    const float E = GetEffectiveRetroreflectiveArea(ut, n);
+    w[1] = (1 - F) * E;
+    w[2] = (1 - F) * (1 - E);
+    float norm = 0.0F;
+    for (int i = 0; i < 3; i++) norm += w[i];
+    for (int i = 0; i < 3; i++) w[i] /= norm;
+}
+inline void EF_without_lobe(float ni, float nt, const v3& wi, const v3& n, const v3& wo, float& used_E, float& used_F)
+{
+    const v3 ut = Refraction::ComputeRefractVector(ni, nt, wi, n);
+    used_E = GetEffectiveRetroreflectiveArea(ut, n);
+    float F = (1.0F - ComputeSchlickFresnel(ni, nt, -wi, n));
+    F *= (1.0F - ComputeSchlickFresnel(ni, nt, wo, n));
+    used_F = F;
+}
+inline float pdf(const atn_material_param& param, const v3& n, const v3& wi, const v3& wo)
+{
+    const float roughness = param.u.standard.roughness, ni = 1.0F, nt = param.u.standard.ior;
+    float w[3];
+    ComputeWeights(w, ni, nt, wi, n);
+    float p = 0.0F;
+    if (w[0] > 0.0F) p += w[0] * Beckman::ComputePDF(roughness, n, wi, wo);
+    if (w[1] > 0.0F) p += w[1] * RR_EvalPDF(roughness, ni, nt, n, wi, wo);
+    if (w[2] > 0.0F) p += w[2] * D_EvalPDF(n, wo);
+    return p;
+}
+inline MaterialSampling bsdf(const atn_material_param& param, const v3& n, const v3& wi, const v3& wo)
+{
+    const float roughness = param.u.standard.roughness, ior = param.u.standard.ior, ni = 1.0F, nt = ior;
+    float w[3];
+    ComputeWeights(w, ni, nt, wi, n);
+    v3 f_r(0.0F), f_rr(0.0F), f_d(0.0F);
+    float p = 0.0F;
+    if (w[0] > 0.0F) {
+        f_r = Beckman::ComputeBRDF(roughness, ior, n, wi, wo);
+        p += Beckman::ComputePDF(roughness, n, wi, wo) * w[0];
+    }
+    float used_E = 0.0F, used_F = 0.0F;
+    if (w[1] > 0.0F) {
+        f_rr = RR_EvalBRDF(roughness, ior, n, wi, wo, &used_E, &used_F);
+        p += RR_EvalPDF(roughness, ni, nt, n, wi, wo) * w[1];
+    }
+    else EF_without_lobe(ni, nt, wi, n, wo, used_E, used_F);
+    if (w[2] > 0.0F) {
+        f_d = D_EvalBRDF(used_E, used_F, ni, nt);
+        p += D_EvalPDF(n, wo) * w[2];
+    }
+    MaterialSampling result;
+    result.bsdf = f_r + f_rr + f_d;
+    result.pdf = p;
+    return result;
+}
+inline void sample(MaterialSampling& result, const atn_material_param& param, const v3& n, const v3& wi, CMJ* sampler)
+{
+    const float r1 = sampler->nextSample();
+    const float r2 = sampler->nextSample();
+    const float r3 = sampler->nextSample();
+    const float roughness = param.u.standard.roughness, ior = param.u.standard.ior, ni = 1.0F, nt = ior;
+    float w[3];
+    ComputeWeights(w, ni, nt, wi, n);
+    const float cdf0 = w[0], cdf1 = cdf0 + w[1];
+    v3 f_r(0.0F), f_rr(0.0F), f_d(0.0F);
+    float p = 0.0F;
+    v3 wo;      // the reference reads it unset in the diffuse branch below (retroreflective.cpp:559-565): (0, 0, 0) here
+    float used_E = 0.0F, used_F = 0.0F;
+    if (r3 < cdf0) {
+        wo = ComputeReflectVector(wi, Beckman::SampleMicrosurfaceNormal(roughness, n, r1, r2));
+        f_r = Beckman::ComputeBRDF(roughness, ior, n, wi, wo);
+        p += Beckman::ComputePDF(roughness, n, wi, wo) * w[0];
+        w[0] = 0.0F;
+    }
+    else if (r3 < cdf1) {
+        wo = RR_SampleDirection(r1, r2, roughness, ni, nt, wi, n);
+        f_rr = RR_EvalBRDF(roughness, ior, n, wi, wo, &used_E, &used_F);
+        p += RR_EvalPDF(roughness, ni, nt, n, wi, wo) * w[1];
+        w[1] = 0.0F;
+    }
+    else {
+        EF_without_lobe(ni, nt, wi, n, wo, used_E, used_F);
+        wo = Diffuse::SampleDirection(n, r1, r2);
+        f_d = D_EvalBRDF(used_E, used_F, ni, nt);
+        p += D_EvalPDF(n, wo) * w[2];
+        w[2] = 0.0F;
+    }
+    if (w[0] > 0.0F) {
+        f_r = Beckman::ComputeBRDF(roughness, ior, n, wi, wo);
+        p += Beckman::ComputePDF(roughness, n, wi, wo) * w[0];
+    }
+    if (w[1] > 0.0F) {
+        f_rr = RR_EvalBRDF(roughness, ior, n, wi, wo, &used_E, &used_F);
+        p += RR_EvalPDF(roughness, ni, nt, n, wi, wo) * w[1];
+    }
+    if (w[2] > 0.0F) {
+        EF_without_lobe(ni, nt, wi, n, wo, used_E, used_F);
+        f_d = D_EvalBRDF(used_E, used_F, ni, nt);
+        p += D_EvalPDF(n, wo) * w[2];
+    }
+    result.pdf = p;
+    result.bsdf = f_r + f_rr + f_d;
+    result.dir = wo;
+}
+} // namespace Retroreflective
+
 // ---- OrenNayar: material/oren_nayar.cpp:8-140 ------------------------------------------------------
 namespace OrenNayar {
 inline float pdf(const v3& normal, const v3& wo)
@@ -687,6 +906,7 @@ inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const at
     case ATN_MTRL_MICROFACET_REFRACTION: MicrofacetRefraction::sample(*result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_GGX: GGX::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
     case ATN_MTRL_DISNEY: Disney::sample(*result, *mtrl, normal, wi, sampler); break;
+    case ATN_MTRL_RETROREFLECTIVE: Retroreflective::sample(*result, *mtrl, normal, wi, sampler); break;
     case ATN_MTRL_EMISSIVE:     // emissive::sample == Diffuse (material/emissive.h:70-83)
     case ATN_MTRL_DIFFUSE:
     default: Diffuse::sample(result, normal, sampler); break;
@@ -703,6 +923,7 @@ inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const 
     case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;     // asserts and returns 1 (microfacet_refraction.cpp:13-22); singular: NEE never asks
     case ATN_MTRL_GGX: return GGX::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
+    case ATN_MTRL_RETROREFLECTIVE: return Retroreflective::pdf(*mtrl, normal, wi, wo);
     default: return Diffuse::ComputePDF(normal, wo);
     }
 }
@@ -718,6 +939,7 @@ inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* 
     case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = v3(0.0F); break;
     case ATN_MTRL_GGX: r.bsdf = GGX::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
     case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
+    case ATN_MTRL_RETROREFLECTIVE: r = Retroreflective::bsdf(*mtrl, normal, wi, wo); break;
     default: r.bsdf = Diffuse::ComputeBRDF(); break;
     }
     return r;

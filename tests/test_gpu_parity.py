@@ -227,16 +227,19 @@ def test_material_tables(gpu, orc, cornell, sponza_disney, which):
           % (which, relerr(gs[:, :3], ws[:, :3]), relerr(gs[:, 3:], ws[:, 3:]), relerr(ge, we)))
 
 
-@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar", "velvet", "microfacet_refraction"])
+@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar", "velvet", "microfacet_refraction", "retroreflective"])
 def test_material_tables_next_tier(gpu, orc, which):
-    """BSDFs beyond the BASELINE set: refraction.cpp, beckman.cpp, oren_nayar.cpp."""
+    """BSDFs beyond the BASELINE set: refraction.cpp, beckman.cpp, oren_nayar.cpp, velvet.cpp,
+    microfacet_refraction.cpp, retroreflective.cpp."""
     from aten_amd import layout as L
     from aten_amd.scene import scenedefs
     scene = scenedefs.cornell_box_variant(lights="area", move_boxes=False,
-                                          extra_materials="rough" if which in ("velvet", "microfacet_refraction") else True)
+                                          extra_materials="retro" if which == "retroreflective" else
+                                          ("rough" if which in ("velvet", "microfacet_refraction") else True))
     fs, c, _ = _setup(gpu, orc, scene, 64, 64)
     want_type = {"refraction": L.MTRL_REFRACTION, "beckman": L.MTRL_BECKMAN, "oren_nayar": L.MTRL_OREN_NAYAR,
-                 "velvet": L.MTRL_VELVET, "microfacet_refraction": L.MTRL_MICROFACET_REFRACTION}[which]
+                 "velvet": L.MTRL_VELVET, "microfacet_refraction": L.MTRL_MICROFACET_REFRACTION,
+                 "retroreflective": L.MTRL_RETROREFLECTIVE}[which]
     mid = int(np.nonzero(fs.arrays["materials"]["type"] == want_type)[0][0])
     rng = np.random.default_rng(11)
     n = 512
@@ -271,7 +274,7 @@ def test_material_tables_next_tier(gpu, orc, which):
     assert relerr(ge, we) <= 2e-3
 
 
-@pytest.mark.parametrize("extra", [True, "rough"])
+@pytest.mark.parametrize("extra", [True, "rough", "retro"])
 def test_next_tier_materials_frames(gpu, orc, extra):
     from aten_amd.scene import scenedefs
     scene = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials=extra)

@@ -74,7 +74,7 @@ public:
     int env_shade_items = 0, env_flavour = -1;
 
     // scene (HBM-resident after UpdateSceneData)
-    DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels;
+    DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint;
     DevBuf<atn_triangle_param> tris;
     DevBuf<atn_object_param> objects;
     DevBuf<DevMaterial> materials;
@@ -250,6 +250,7 @@ public:
         ATN_HIP(objects.upload(img.objects, stream));
         ATN_HIP(matrices.upload(img.matrices, stream));
         ATN_HIP(materials.upload(img.materials, stream));
+        ATN_HIP(carpaint.upload(img.carpaint, stream));
         ATN_HIP(lights.upload(img.lights, stream));
         ATN_HIP(texels.upload(img.texels, stream));
         ATN_HIP(texels8.upload(img.texels8, stream));
@@ -257,7 +258,7 @@ public:
         ATN_HIP(hipStreamSynchronize(stream));      // `img` is pageable host memory
         scene = img.params;
         scene.nodes = nodes.p; scene.tris = tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
-        scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p;
+        scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         has_scene = true;
         env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;
@@ -533,6 +534,17 @@ public:
         }
     }
 
+    template <bool SVGF>
+    void launch_shade(uint32_t g_shade, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, int32_t b, const SvgfShade& sv)
+    {
+        const dim3 g(g_shade), t(256);
+        switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
+        case 0: hipLaunchKernelGGL((k_shade<SVGF, 0>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        case 1: hipLaunchKernelGGL((k_shade<SVGF, 1>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        default: hipLaunchKernelGGL((k_shade<SVGF, 2>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        }
+    }
+
     void prof_begin(bool on, int kind, hipStream_t st = nullptr)
     {
         if (!st) st = stream;
@@ -619,7 +631,7 @@ public:
                         launch_trace<false>(pb, g_trace, count, b, st);
                         prof_end(prof);
                         prof_begin(prof, ATN_K_SHADE, st);
-                        hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_shade), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                        launch_shade<SVGF>(g_shade, st, pb, fp, b, sv);
                         prof_end(prof);
                         prof_begin(prof, ATN_K_TRACE_SHADOW, st);
                         launch_trace<true>(pb, g_trace, count, b, st);
@@ -645,7 +657,7 @@ public:
                         prof_end(prof);
                         if (b < d->maxDepth) {
                             prof_begin(prof, ATN_K_SHADE, st);
-                            hipLaunchKernelGGL((k_shade<SVGF>), dim3(g_shade), dim3(256), 0, st, pb, scene, fp, camera, b, sv);
+                            launch_shade<SVGF>(g_shade, st, pb, fp, b, sv);
                             prof_end(prof);
                         }
                     }
@@ -1137,6 +1149,23 @@ int atn_download_film(atn_ctx* ctx, atn_vec4* out_host)
     C_HIP(r, hipMemcpyAsync(out_host, r.film.p, (size_t)r.film_w * r.film_h * sizeof(float4), hipMemcpyDeviceToHost, r.stream));
     C_HIP(r, hipStreamSynchronize(r.stream));
     return ATN_OK;
+}
+
+// Resume: the film of an earlier run (atn_download_film) becomes the state the next progressive frame continues from --
+// FilmProgressive keeps {running mean, sample count in .w} per pixel (src/libaten/renderer/film.cpp:61-71).
+int atn_upload_film(atn_ctx* ctx, int32_t width, int32_t height, const atn_vec4* film_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!film_host || width <= 0 || height <= 0) return r.fail(ATN_ERR_INVALID_ARG, "atn_upload_film: bad size / null film");
+    return guarded(ctx, [&]() -> int {
+        C_HIP(r, hipSetDevice(r.device));
+        C_HIP(r, r.film.resize((size_t)width * height));
+        C_HIP(r, hipMemcpyAsync(r.film.p, film_host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, r.stream));
+        C_HIP(r, hipStreamSynchronize(r.stream));
+        r.film_w = width; r.film_h = height;        // the next render of this size keeps the film instead of clearing it
+        return ATN_OK;
+    });
 }
 
 int atn_get_stats(atn_ctx* ctx, uint64_t out[8])

@@ -330,7 +330,8 @@ struct SvgfShade {
 // Returns updated flags; fills the next ray and the shadow ray.
 // SVGF = true is SVGFRenderer::Shade + ShadeMiss with AOV spans: AOVs at bounce 0 (and at bounce 1 behind a Specular
 // hit), albedo read with default (1,1,1,1) and demodulated where the AOV took it.
-template <bool SVGF>
+// MS: the material set of the scene (DevScene::material_set, shading.hpp): BSDFs outside it are compiled out.
+template <bool SVGF, int MS>
 __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     __shared__ BlockAppendShared sh;
@@ -474,7 +475,9 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 
                 if (!shaded_out) {
                     if (!(m.attrib & ATN_MTRL_ATTR_TRANSLUCENT) && isBackfacing) orienting_normal = -orienting_normal;
-                    orienting_normal = apply_normal_map(sc, m.normalMap, orienting_normal, rec.u, rec.v);
+                    // material::applyNormal: the normal map -- or, for CarPaint, the flake normal and the random number it shares
+                    const int32_t mtrl_slot = mtrlid >= 0 ? mtrlid : sc.n_materials;
+                    const float pre_r = apply_normal<MS>(sc, m, mtrl_slot, orienting_normal, rec.u, rec.v, ray_dir, smp);
 
                     // ---- FillShadowRay / SampleLight, pathtracing_impl.h:178-264
                     const bool invalid_mtrl = (m.attrib & (ATN_MTRL_ATTR_SINGULAR | ATN_MTRL_ATTR_TRANSLUCENT)) != 0;
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
                         const f3 so = ray_offset(rec.p, orienting_normal);
                         f3 radiance;
                         f3 lightcontrib = mk3(0.0F);
-                        if (radiance_nee(radiance, sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls)) {
+                        if (radiance_nee<MS>(radiance, sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r)) {
                             lightcontrib = (throughput * radiance) * albedo;
                             shadow_active = true;
                         }
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, Fram
 
                     // ---- sampleMaterial + PrepareForNextBounce, pathtracing_impl.h:700-743
                     MtrlSample ms;
-                    sample_material(ms, sc, m, orienting_normal, ray_dir, smp, rec.u, rec.v);
+                    sample_material<MS>(ms, sc, m, orienting_normal, ray_dir, smp, rec.u, rec.v, mtrl_slot, pre_r);
                     const f3 next_dir = normalize(ms.dir);
                     const f3 ray_along_normal = dot(orienting_normal, next_dir) >= 0.0f ? orienting_normal : -orienting_normal;
                     const float c = dot(ray_along_normal, next_dir);
@@ -884,14 +887,16 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
     if (i >= n) return;
     const DevMaterial m = sc.materials[mtrl_id];
     Cmj s; s.idx = index[i]; s.dim = 0; s.scramble = scramble[i];
-    const f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
     const f3 WI = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    // CarPaint: material::applyNormal runs first, as in shade (it draws the shared random number and may swap the normal)
+    const float pre_r = m.type == ATN_MTRL_CARPAINT ? apply_normal<2>(sc, m, mtrl_id, N, uv[2 * i], uv[2 * i + 1], WI, s) : 0.0F;
     MtrlSample ms;
-    sample_material(ms, sc, m, N, WI, s, uv[2 * i], uv[2 * i + 1]);
+    sample_material(ms, sc, m, N, WI, s, uv[2 * i], uv[2 * i + 1], mtrl_id, pre_r);
     float* o = out_sample + 7 * i;
     o[0] = ms.dir.x; o[1] = ms.dir.y; o[2] = ms.dir.z; o[3] = ms.bsdf.x; o[4] = ms.bsdf.y; o[5] = ms.bsdf.z; o[6] = ms.pdf;
-    const float p = material_pdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
-    const MtrlSample ev = material_bsdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+    const float p = material_pdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1], mtrl_id);
+    const MtrlSample ev = material_bsdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1], mtrl_id, pre_r);
     float* e = out_eval + 5 * i;
     e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
 }

@@ -75,6 +75,7 @@ struct DevScene {
     const atn_object_param* objects;
     const float4* matrices;             // 4 rows per mat4
     const DevMaterial* materials;
+    const float4* carpaint;             // 4 per material: CarPaintMaterialParameter (the union member of MaterialParameter, material.h:163-176)
     const atn_light_param* lights;
     const float4* texels;
     const uint32_t* texels8;            // packed r | g << 8 | b << 16 | a << 24
@@ -91,6 +92,7 @@ struct DevScene {
     int32_t enable_env_map;
     int32_t any_alpha;          // some material carries kAttrMaybeAlpha or kAttrStencilStencil: a shadow-ray hit may be "ignored"
     int32_t enable_alpha_blending;      // scene_rendering_config.enable_alpha_blending
+    int32_t material_set;               // 0 = BASELINE BSDFs only, 1 = + the other analytic ones, 2 = + CarPaint: which k_shade is launched
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS

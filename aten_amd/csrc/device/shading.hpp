@@ -856,10 +856,252 @@ ATN_DEV void retro_sample(MtrlSample& res, const DevMaterial& m, const f3& n, co
     res.dir = wo;
 }
 
-// material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
-ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
-                             const f3& wi, Cmj& smp, float u, float v)
+// CarPaint, material/car_paint.cpp:14-236 + FlakesNormal (material/FlakesNormal.cpp:5-185, FlakesNormal.h:20-52): clearcoat
+// (Beckman) over procedural metal flakes over a diffuse base, chosen by one random number that material::applyNormal
+// draws BEFORE next-event estimation ("pre_sampled_r") and that the light evaluation and the direction sampling share.
+struct CarPaintP {
+    f3 clearcoat_color; float clearcoat_ior;
+    f3 flakes_color; float clearcoat_roughness;
+    f3 diffuse_color; float flake_scale;
+    float flake_size, flake_size_variance, flake_normal_orientation, flake_color_multiplier;
+};
+ATN_DEV CarPaintP carpaint_params(const DevScene& sc, int32_t mtrl_id)
 {
+    const float4 a = sc.carpaint[4 * mtrl_id], b = sc.carpaint[4 * mtrl_id + 1], c = sc.carpaint[4 * mtrl_id + 2], d = sc.carpaint[4 * mtrl_id + 3];
+    CarPaintP p;
+    p.clearcoat_color = mk3(a); p.clearcoat_ior = a.w;
+    p.flakes_color = mk3(b); p.clearcoat_roughness = b.w;
+    p.diffuse_color = mk3(c); p.flake_scale = c.w;
+    p.flake_size = d.x; p.flake_size_variance = d.y; p.flake_normal_orientation = d.z; p.flake_color_multiplier = d.w;
+    return p;
+}
+ATN_DEV float compute_fresnel(float ni, float nt, const f3& wi, const f3& normal)     // material::computeFresnel, material.h:445-467
+{
+    float cosi = dot(normal, wi);
+    if (cosi < 0) { const float t = ni; ni = nt; nt = t; cosi = -cosi; }
+    const float nnt = ni / nt;
+    const float sini2 = 1.0F - cosi * cosi;
+    const float sint2 = (nnt * nnt) * sini2;
+    const float cost = sqrtf(smax(0.0F, 1.0F - sint2));
+    const float rp = (nt * cosi - ni * cost) / (nt * cosi + ni * cost);
+    const float rs = (ni * cosi - nt * cost) / (ni * cosi + nt * cost);
+    return (rp * rp + rs * rs) * 0.5F;
+}
+ATN_DEV float flake_density(float flake_size, float aspect_wh)     // FlakesNormal::computeFlakeDensity, FlakesNormal.h:20-52
+{
+    const float aspect = 1.0F / aspect_wh;
+    const float D = ((kPi * flake_size) * flake_size) * aspect;
+    return smin(D, 1.0F);
+}
+// Bob Jenkins' lookup3 mix / final (public domain), as FlakesNormal.cpp:12-44 uses them
+ATN_DEV uint32_t rotl32(uint32_t v, uint32_t h) { return (v << h) | (v >> (32u - h)); }
+ATN_DEV uint32_t flake_inthash(const float k[4])
+{
+    // float -> uint32 of possibly NEGATIVE cell coordinates: the reference's x86-64 build converts through a 64-bit
+    // integer and keeps the low 32 bits (two's-complement wrap); v_cvt_u32_f32 would clamp to 0, so spell the wrap out
+    const uint32_t len = 4;
+    uint32_t a = 0xdeadbeefu + (len << 2) + 13u, b = a, c = a;
+    a += (uint32_t)(long long)k[0];
+    b += (uint32_t)(long long)k[1];
+    c += (uint32_t)(long long)k[2];
+    a -= c; a ^= rotl32(c, 4); c += b;
+    b -= a; b ^= rotl32(a, 6); a += c;
+    c -= b; c ^= rotl32(b, 8); b += a;
+    a -= c; a ^= rotl32(c, 16); c += b;
+    b -= a; b ^= rotl32(a, 19); a += c;
+    c -= b; c ^= rotl32(b, 4); b += a;
+    a += (uint32_t)(long long)k[3];
+    c ^= b; c -= rotl32(b, 14);
+    a ^= c; a -= rotl32(c, 11);
+    b ^= a; b -= rotl32(a, 25);
+    c ^= b; c -= rotl32(b, 16);
+    a ^= c; a -= rotl32(c, 4);
+    b ^= a; b -= rotl32(a, 14);
+    c ^= b; c -= rotl32(b, 24);
+    return c;
+}
+ATN_DEV f3 flake_cellnoise(const f3& p)      // cellnoise + hash3, FlakesNormal.cpp:93-123
+{
+    float iv[4] = { floorf(p.x), floorf(p.y), floorf(p.z), 0.0F };
+    const float to01 = 1.0F / (float)0xffffffffu;
+    f3 r;
+    iv[3] = 0.0F; r.x = (float)flake_inthash(iv) * to01;
+    iv[3] = 1.0F; r.y = (float)flake_inthash(iv) * to01;
+    iv[3] = 2.0F; r.z = (float)flake_inthash(iv) * to01;
+    return r;
+}
+ATN_DEV float4 flakes_normal_gen(float u, float v, float flake_scale, float flake_size, float flake_size_variance, float flake_normal_orientation)
+{
+    // FlakesNormal::gen, FlakesNormal.cpp:125-183
+    const float safe_var = sclamp(flake_size_variance, 0.1F, 1.0F);
+    const float cx[9] = { 0.5F, 1.5F, 1.5F, 0.5F, -0.5F, -0.5F, -0.5F, 0.5F, 1.5F };
+    const float cy[9] = { 0.5F, 0.5F, 1.5F, 1.5F, 1.5F, 0.5F, -0.5F, -0.5F, -0.5F };
+    const f3 position = flake_scale * mk3(u, v, 0.0F);
+    const f3 base = mk3(floorf(position.x), floorf(position.y), floorf(position.z));
+    f3 nearest = mk3(0.0F, 0.0F, 1.0F);
+    int32_t nearest_idx = -1;
+#pragma unroll 1
+    for (int32_t i = 0; i < 9; ++i) {
+        f3 center = base + mk3(cx[i], cy[i], 0.0F);
+        f3 off = flake_cellnoise(center) * 2.0F + (-1.0F);
+        off.z *= safe_var;
+        off = normalize(off);
+        center = center + 0.5F * off;
+        const float dist = length(position - center);        // glm::distance
+        if (dist < flake_size && center.z < nearest.z) { nearest = center; nearest_idx = i; }
+    }
+    f3 result = mk3(0.5F, 0.5F, 1.0F);
+    float alpha = 0.0F;
+    if (nearest_idx != -1) {
+        f3 rn = flake_cellnoise((base + mk3(cx[nearest_idx], cy[nearest_idx], 0.0F)) + mk3(0.0F, 0.0F, 1.5F));
+        rn = 2.0F * rn + (-1.0F);
+        // glm::faceforward(N, I, Nref) = dot(Nref, I) < 0 ? N : -N with N = Nref = rn, I = (0, 0, 1)
+        rn = dot(rn, mk3(0.0F, 0.0F, 1.0F)) < 0.0F ? rn : -rn;
+        rn = normalize(mix3(rn, mk3(0.0F, 0.0F, 1.0F), flake_normal_orientation));
+        result = rn;
+        alpha = 1.0F;
+    }
+    return make_float4(result.x, result.y, result.z, alpha);
+}
+// material::applyNormal (material_impl.h:208-230): CarPaint::applyNormalMap (car_paint.cpp:195-236) draws the shared
+// random number and may replace the normal by a flake's; every other material takes its normal map and returns -1.
+// MS < 2 compiles CarPaint out (see the material sets at sample_material).
+template <int MS>
+ATN_DEV float apply_normal(const DevScene& sc, const DevMaterial& m, int32_t mtrl_id, f3& nml, float u, float v, const f3& wi, Cmj& smp)
+{
+    if (MS < 2 || m.type != ATN_MTRL_CARPAINT) {
+        nml = apply_normal_map(sc, m.normalMap, nml, u, v);
+        return -1.0F;
+    }
+    const CarPaintP p = carpaint_params(sc, mtrl_id);
+    const f3 V = -wi;
+    const f3 N = normalize(nml);
+    const float r0 = cmj_next(smp);
+    const float fresnel = compute_fresnel(1.0F, p.clearcoat_ior, V, N);
+    f3 out = N;
+    if (!(r0 < fresnel)) {
+        const float4 fl = flakes_normal_gen(u, v, p.flake_scale, p.flake_size, p.flake_size_variance, p.flake_normal_orientation);
+        if (fl.w > 0.0F) {
+            // applyTangentSpaceCoord, car_paint.cpp:14-23
+            const f3 n = normalize(nml);
+            f3 t, b;
+            tangent_coordinate(n, t, b);
+            out = normalize((fl.z * n + fl.x * t) + fl.y * b);
+        }
+    }
+    nml = out;
+    return r0;
+}
+ATN_DEV float carpaint_pdf(const CarPaintP& p, const f3& normal, const f3& wi, const f3& wo)      // car_paint.cpp:25-57
+{
+    const f3 V = -wi;
+    const float fresnel = compute_fresnel(1.0F, p.clearcoat_ior, V, normal);
+    const float bp = beckman_pdf(p.clearcoat_roughness, normal, wi, wo);
+    const float fbp = beckman_pdf(1.0F, normal, wi, wo);
+    const float dens = flake_density(p.flake_size, 1.0F);
+    const float dp = diffuse_pdf(normal, wo);
+    const float pdf = fresnel * bp + (1.0F - fresnel) * (dens * fbp + (1 - dens) * dp);
+    return sclamp(pdf, 0.0F, 1.0F);
+}
+ATN_DEV f3 carpaint_dir(const CarPaintP& p, const f3& normal, const f3& wi, Cmj& smp, float pre_r)      // car_paint.cpp:59-109
+{
+    const f3 V = -wi;
+    float r0 = pre_r;
+    float r1 = cmj_next(smp);
+    const float fresnel = compute_fresnel(1.0F, p.clearcoat_ior, V, normal);
+    const float dens = flake_density(p.flake_size, 1.0F);
+    if (r0 < fresnel) {
+        r0 /= fresnel;
+        return reflect_vector(wi, beckman_sample_m(p.clearcoat_roughness, normal, r0, r1));
+    }
+    r0 -= fresnel;
+    r0 /= (1.0F - fresnel);
+    if (r1 < dens) {
+        r1 /= dens;
+        return reflect_vector(wi, beckman_sample_m(1.0F, normal, r0, r1));
+    }
+    r1 -= dens;
+    r1 /= (1.0F - dens);
+    return diffuse_dir(normal, r0, r1);
+}
+ATN_DEV f3 carpaint_bsdf(const DevScene& sc, const DevMaterial& m, const CarPaintP& p, const f3& normal, const f3& wi, const f3& wo,
+                         float u, float v, float pre_r)      // car_paint.cpp:111-176
+{
+    const f3 albedo = mk3(sample_texture(sc, m.albedoMap, u, v, make_float4(1.0F, 1.0F, 1.0F, 1.0F)));
+    const f3 V = -wi;
+    const float fresnel = compute_fresnel(1.0F, p.clearcoat_ior, V, normal);
+    f3 bsdf;
+    if (pre_r < fresnel) {
+        bsdf = beckman_brdf(p.clearcoat_roughness, p.clearcoat_ior, normal, wi, wo);
+        bsdf = bsdf * p.clearcoat_color;
+    }
+    else {
+        const bool on_flakes = flakes_normal_gen(u, v, p.flake_scale, p.flake_size, p.flake_size_variance, p.flake_normal_orientation).w > 0.0F;
+        if (on_flakes) {
+            bsdf = beckman_brdf(1.0F, 10.0F, normal, wi, wo);
+            bsdf = bsdf * (p.flakes_color * p.flake_color_multiplier);
+        }
+        else {
+            bsdf = p.diffuse_color / kPi;
+        }
+    }
+    return albedo * bsdf;
+}
+
+// material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
+// Material set MS of a k_shade instantiation (chosen by the host from the uploaded materials, DevScene::material_set):
+//   0 = the BASELINE set: Emissive, Diffuse, Specular, GGX, Disney          (the other BSDFs are compiled out: every one
+//   1 = + Refraction, Beckman, OrenNayar, Velvet, MicrofacetRefraction,       of them costs registers in a kernel that
+//         Retroreflective                                                     runs at 3 waves per SIMD; measured: shade
+//   2 = + CarPaint (flake noise, its own parameter block)                      1.32 -> 1.35 -> 1.65 ms per frame)
+// mtrl_id / pre_r: only CarPaint reads them (its parameter block and the random number material::applyNormal drew).
+template <int MS = 2>
+ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
+                             const f3& wi, Cmj& smp, float u, float v, int32_t mtrl_id = 0, float pre_r = 0.0F)
+{
+    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) {       // CarPaint::sample, car_paint.cpp:178-193
+        const CarPaintP p = carpaint_params(sc, mtrl_id);
+        r.dir = carpaint_dir(p, normal, wi, smp, pre_r);
+        r.pdf = carpaint_pdf(p, normal, wi, r.dir);
+        r.bsdf = carpaint_bsdf(sc, m, p, normal, wi, r.dir, u, v, pre_r);
+        return;
+    }
+    if (MS >= 1) {
+        switch (m.type) {
+        case ATN_MTRL_REFRACTION:
+            refraction_sample(r, m, normal, wi, smp);
+            return;
+        case ATN_MTRL_BECKMAN: {
+            const float rough = ggx_roughness(sc, m, u, v);
+            const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+            r.dir = reflect_vector(wi, beckman_sample_m(rough, normal, r1, r2));
+            r.pdf = beckman_pdf(rough, normal, wi, r.dir);
+            r.bsdf = beckman_brdf(rough, m.ior, normal, wi, r.dir);
+            return;
+        }
+        case ATN_MTRL_VELVET: {
+            const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+            r.dir = diffuse_dir(normal, r1, r2);
+            r.pdf = diffuse_pdf(normal, r.dir);
+            r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+            return;
+        }
+        case ATN_MTRL_MICROFACET_REFRACTION:
+            microfacet_refraction_sample(r, sc, m, normal, wi, smp, u, v);
+            return;
+        case ATN_MTRL_RETROREFLECTIVE:
+            retro_sample(r, m, normal, wi, smp);
+            return;
+        case ATN_MTRL_OREN_NAYAR: {
+            const float r1 = cmj_next(smp), r2 = cmj_next(smp);
+            r.dir = diffuse_dir(normal, r1, r2);
+            r.pdf = oren_nayar_pdf(normal, r.dir);
+            r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+            return;
+        }
+        default: break;
+        }
+    }
     switch (m.type) {
     case ATN_MTRL_SPECULAR: {
         r.dir = reflect_vector(wi, normal);
@@ -879,37 +1121,6 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
     case ATN_MTRL_DISNEY:
         disney_sample(r, m, normal, wi, smp);
         break;
-    case ATN_MTRL_REFRACTION:
-        refraction_sample(r, m, normal, wi, smp);
-        break;
-    case ATN_MTRL_BECKMAN: {
-        const float rough = ggx_roughness(sc, m, u, v);
-        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-        r.dir = reflect_vector(wi, beckman_sample_m(rough, normal, r1, r2));
-        r.pdf = beckman_pdf(rough, normal, wi, r.dir);
-        r.bsdf = beckman_brdf(rough, m.ior, normal, wi, r.dir);
-        break;
-    }
-    case ATN_MTRL_VELVET: {
-        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-        r.dir = diffuse_dir(normal, r1, r2);
-        r.pdf = diffuse_pdf(normal, r.dir);
-        r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
-        break;
-    }
-    case ATN_MTRL_MICROFACET_REFRACTION:
-        microfacet_refraction_sample(r, sc, m, normal, wi, smp, u, v);
-        break;
-    case ATN_MTRL_RETROREFLECTIVE:
-        retro_sample(r, m, normal, wi, smp);
-        break;
-    case ATN_MTRL_OREN_NAYAR: {
-        const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-        r.dir = diffuse_dir(normal, r1, r2);
-        r.pdf = oren_nayar_pdf(normal, r.dir);
-        r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
-        break;
-    }
     default: {  // Diffuse, Emissive (emissive.h:70-83) and the reference's fallback
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
         r.dir = diffuse_dir(normal, r1, r2);
@@ -919,34 +1130,50 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
     }
     }
 }
-ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v)
+template <int MS = 2>
+ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
+                           int32_t mtrl_id = 0)
 {
+    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) return carpaint_pdf(carpaint_params(sc, mtrl_id), normal, wi, wo);
+    if (MS >= 1) {
+        switch (m.type) {
+        case ATN_MTRL_REFRACTION: return 1.0F;
+        case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
+        case ATN_MTRL_OREN_NAYAR: return oren_nayar_pdf(normal, wo);
+        case ATN_MTRL_VELVET: return diffuse_pdf(normal, wo);
+        case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;
+        case ATN_MTRL_RETROREFLECTIVE: return retro_pdf(m, normal, wi, wo);
+        default: break;
+        }
+    }
     switch (m.type) {
     case ATN_MTRL_SPECULAR: return 1.0F;
-    case ATN_MTRL_REFRACTION: return 1.0F;
-    case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
-    case ATN_MTRL_OREN_NAYAR: return oren_nayar_pdf(normal, wo);
-    case ATN_MTRL_VELVET: return diffuse_pdf(normal, wo);
-    case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;
     case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
-    case ATN_MTRL_RETROREFLECTIVE: return retro_pdf(m, normal, wi, wo);
     default: return diffuse_pdf(normal, wo);
     }
 }
-ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v)
+template <int MS = 2>
+ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
+                                 int32_t mtrl_id = 0, float pre_r = 0.0F)
 {
     MtrlSample r; r.pdf = 0.0F; r.dir = wo; r.bsdf = mk3(0.0F);
+    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) { r.bsdf = carpaint_bsdf(sc, m, carpaint_params(sc, mtrl_id), normal, wi, wo, u, v, pre_r); return r; }
+    if (MS >= 1) {
+        switch (m.type) {
+        case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); return r;
+        case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); return r;
+        case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
+        case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
+        case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = mk3(0.0F); return r;
+        case ATN_MTRL_RETROREFLECTIVE: return retro_bsdf(m, normal, wi, wo);
+        default: break;
+        }
+    }
     switch (m.type) {
     case ATN_MTRL_SPECULAR: { const float c = dot(normal, wo); r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c); break; }
     case ATN_MTRL_GGX: r.bsdf = ggx_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
-    case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); break;
-    case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
-    case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
-    case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); break;
-    case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = mk3(0.0F); break;
     case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
-    case ATN_MTRL_RETROREFLECTIVE: r = retro_bsdf(m, normal, wi, wo); break;
     default: r.bsdf = diffuse_brdf(); break;
     }
     return r;
@@ -1195,12 +1422,13 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
 }
 
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
+template <int MS = 2>
 ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
-                          float hu, float hv, float light_select_prob, const LightSample& ls)
+                          float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F)
 {
     const float cosShadow = dot(nml, ls.dir);
-    float path_pdf = material_pdf(sc, m, nml, wi, ls.dir, hu, hv);
-    const MtrlSample ev = material_bsdf(sc, m, nml, wi, ls.dir, hu, hv);
+    float path_pdf = material_pdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id);
+    const MtrlSample ev = material_bsdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id, pre_r);
     if (ev.pdf > 0) path_pdf = ev.pdf;
     const float cosLight = dot(ls.nml, -ls.dir);
     float dist2 = sqr(ls.dist);

@@ -20,6 +20,7 @@ struct HostSceneImage {
     std::vector<atn_object_param> objects;
     std::vector<float4> matrices;
     std::vector<DevMaterial> materials;
+    std::vector<float4> carpaint;
     std::vector<atn_light_param> lights;
     std::vector<float4> texels;
     std::vector<uint32_t> texels8;
@@ -302,6 +303,11 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         for (size_t j = 0; j < n; j++) if (t.texels[j].w < 1.0F) { tex_has_alpha[i] = 1; break; }
     }
     img.materials.resize(s->n_materials);
+    img.carpaint.assign((size_t)(s->n_materials + 1) * 4, make_float4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < s->n_materials; i++) {
+        const float* c = s->materials[i].u.carpaint;
+        for (int k = 0; k < 4; k++) img.carpaint[4 * (size_t)i + k] = make_float4(c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+    }
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const atn_material_param& m = s->materials[i];
         DevMaterial& d = img.materials[i];
@@ -377,6 +383,13 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     p.any_alpha = 0;
     for (const DevMaterial& dm : img.materials) if (dm.attrib & (kAttrMaybeAlpha | kAttrStencilStencil)) p.any_alpha = 1;
     p.enable_alpha_blending = s->config.enable_alpha_blending ? 1 : 0;
+    p.material_set = 0;
+    for (const DevMaterial& dm : img.materials) {
+        const int32_t t = dm.type;
+        const bool core = t == ATN_MTRL_EMISSIVE || t == ATN_MTRL_DIFFUSE || t == ATN_MTRL_SPECULAR || t == ATN_MTRL_GGX || t == ATN_MTRL_DISNEY;
+        const int32_t need = t == ATN_MTRL_CARPAINT ? 2 : (core ? 0 : 1);
+        if (need > p.material_set) p.material_set = need;
+    }
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /
     // ComputeDistanceToCoverBoundingSphere, math/aabb.h:176-180,231-234,346-362), evaluated once on the host.
     {

@@ -90,6 +90,7 @@ MTRL_ATTRIB = {
     MTRL_REFRACTION: ATTR_SINGULAR | ATTR_TRANSLUCENT | ATTR_GLOSSY,
     MTRL_DISNEY: ATTR_GLOSSY,
     MTRL_RETROREFLECTIVE: ATTR_GLOSSY,      # MaterialAttributeMicrofacet (retroreflective.h:26-31)
+    MTRL_CARPAINT: ATTR_GLOSSY,             # MaterialAttributeMicrofacet (car_paint.h:16-44)
 }
 LIGHT_AREA, LIGHT_IBL, LIGHT_DIRECTION, LIGHT_POINT, LIGHT_SPOT = range(5)
 LATTR_SINGULAR, LATTR_INFINITE, LATTR_IBL = 1, 2, 4

@@ -122,6 +122,13 @@ class PathTracing:
         self._check(self._l.atn_download_film(self._ctx, out.ctypes.data))
         return out
 
+    def upload_film(self, film):
+        """Resume from a film returned by download_film / render (running mean + sample count)."""
+        film = np.ascontiguousarray(film, np.float32)
+        h, w = film.shape[:2]
+        self._check(self._l.atn_upload_film(self._ctx, w, h, film.ctypes.data))
+        self.width, self.height = w, h
+
     def stats(self):
         s = np.zeros(8, np.uint64)
         self._check(self._l.atn_get_stats(self._ctx, s.ctypes.data))

@@ -84,6 +84,21 @@ class SceneBuilder:
         self.materials.append((name, m))
         return len(self.materials) - 1
 
+    def add_carpaint_material(self, name, base_color=(1.0, 1.0, 1.0), albedo_map=-1, **cp):
+        """aten::CarPaint: CarPaintMaterialParameter (material.h:163-198, defaults of Init()) in the union next to `standard`."""
+        mid = self.add_material(name, L.MTRL_CARPAINT, base_color, albedo_map=albedo_map)
+        p = dict(clearcoat_color=(1.0, 1.0, 1.0), clearcoat_ior=3.0, flakes_color=(1.0, 1.0, 0.0), clearcoat_roughness=0.25,
+                 diffuse_color=(1.0, 0.0, 1.0), flake_scale=400.0, flake_size=0.25, flake_size_variance=0.7,
+                 flake_normal_orientation=0.5, flake_color_multiplier=1.0)
+        p.update(cp)
+        v = (list(p["clearcoat_color"]) + [p["clearcoat_ior"]] + list(p["flakes_color"]) + [p["clearcoat_roughness"]]
+             + list(p["diffuse_color"]) + [p["flake_scale"], p["flake_size"], p["flake_size_variance"],
+                                           p["flake_normal_orientation"], p["flake_color_multiplier"]])
+        m = self.materials[mid][1]
+        m["standard"] = v[:12]
+        m["_union_tail"] = v[12:]
+        return mid
+
     def find_material(self, name):
         for i, (n, _) in enumerate(self.materials):
             if n == name:

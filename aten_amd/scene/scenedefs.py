@@ -131,6 +131,11 @@ def cornell_box_variant(lights="area", move_boxes=True, asset_dir=None, extra_ma
             return b.add_material(name, L.MTRL_MICROFACET_REFRACTION, (0.9, 0.9, 0.9), ior=1.5, roughness=0.2)
         if extra_materials == "rough" and name == "rightWall":
             return b.add_material(name, L.MTRL_VELVET, clr, roughness=0.4)
+        if extra_materials == "carpaint" and name == "shortBox":   # clearcoat over flakes over diffuse (car_paint.cpp)
+            return b.add_carpaint_material(name, (1.0, 1.0, 1.0))
+        if extra_materials == "carpaint" and name == "backWall":
+            return b.add_carpaint_material(name, (0.9, 0.9, 0.9), diffuse_color=(0.1, 0.3, 0.8), flakes_color=(0.9, 0.9, 1.0),
+                                           flake_size=0.4, clearcoat_ior=1.6, flake_scale=60.0)
         if extra_materials == "retro" and name == "rightWall":   # prismatic-sheet retroreflector (retroreflective.cpp)
             return b.add_material(name, L.MTRL_RETROREFLECTIVE, clr, roughness=0.3, ior=1.5)
         if extra_materials == "retro" and name == "tallBox":

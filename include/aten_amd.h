@@ -105,6 +105,10 @@ int atn_assemble_tiles(atn_ctx* ctx, const void* gathered_dev, int32_t world, vo
  * on a communication stream while the context's stream already renders frame f + 1. */
 int atn_assemble_tiles_on(atn_ctx* ctx, const void* gathered_dev, int32_t world, void* film_dev_out, void* hip_stream);
 int atn_download_film(atn_ctx* ctx, atn_vec4* out_host);
+/* Checkpoint / resume of the progressive film (FilmProgressive's running mean + sample count in .w,
+ * src/libaten/renderer/film.cpp:61-71): what atn_download_film returned is put back, and the next progressive
+ * atn_render of that size continues from it exactly as if the earlier frames had run on this context. */
+int atn_upload_film(atn_ctx* ctx, int32_t width, int32_t height, const atn_vec4* film_host);
 
 /* Counters of the last atn_render with count_stats = 1:
  * {closest rays, shadow rays, shaded hits, closest node visits, closest triangle tests,

@@ -116,12 +116,18 @@ void orc_material_table(const atn_scene_desc* scene, int32_t mtrl_id, uint32_t n
         CMJ s; s.init(index[i], 0, scramble[i]);
         MaterialSampling ms;
         v3 N = ld3(nrm + 3 * i), WI = ld3(wi + 3 * i);
-        sampleMaterial(&ms, ctxt, &m, N, WI, &s, uv[2 * i], uv[2 * i + 1]);
+        float pre_r = 0.0F;
+        if (m.type == ATN_MTRL_CARPAINT) {      // material::applyNormal runs first, as in shade
+            v3 nn;
+            pre_r = applyNormal(ctxt, m, N, nn, uv[2 * i], uv[2 * i + 1], WI, &s);
+            N = nn;
+        }
+        sampleMaterial(&ms, ctxt, &m, N, WI, &s, uv[2 * i], uv[2 * i + 1], pre_r);
         float* o = out_sample + 7 * i;
         o[0] = ms.dir.x; o[1] = ms.dir.y; o[2] = ms.dir.z;
         o[3] = ms.bsdf.x; o[4] = ms.bsdf.y; o[5] = ms.bsdf.z; o[6] = ms.pdf;
         float p = samplePDF(ctxt, &m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
-        MaterialSampling ev = sampleBSDF(ctxt, &m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1]);
+        MaterialSampling ev = sampleBSDF(ctxt, &m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1], pre_r);
         float* e = out_eval + 5 * i;
         e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
     }

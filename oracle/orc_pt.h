@@ -741,6 +741,228 @@ inline void sample(MaterialSampling& result, const atn_material_param& param, co
 }
 } // namespace Retroreflective
 
+// ---- CarPaint: material/car_paint.cpp:14-236, FlakesNormal.cpp:5-185, FlakesNormal.h:20-52, material.h:445-467 ------
+namespace CarPaint {
+struct Param {      // CarPaintMaterialParameter, material.h:163-176 (the union member next to `standard`)
+    v3 clearcoat_color; float clearcoat_ior;
+    v3 flakes_color; float clearcoat_roughness;
+    v3 diffuse_color; float flake_scale;
+    float flake_size, flake_size_variance, flake_normal_orientation, flake_color_multiplier;
+};
+inline Param param_of(const atn_material_param& m)
+{
+    const float* c = m.u.carpaint;
+    Param p;
+    p.clearcoat_color = v3(c[0], c[1], c[2]); p.clearcoat_ior = c[3];
+    p.flakes_color = v3(c[4], c[5], c[6]); p.clearcoat_roughness = c[7];
+    p.diffuse_color = v3(c[8], c[9], c[10]); p.flake_scale = c[11];
+    p.flake_size = c[12]; p.flake_size_variance = c[13]; p.flake_normal_orientation = c[14]; p.flake_color_multiplier = c[15];
+    return p;
+}
+inline float computeFresnel(float ni, float nt, const v3& wi, const v3& normal)
+{
+    float cosi = dot(normal, wi);
+    if (cosi < 0) { std::swap(ni, nt); cosi = -cosi; }
+    const float nnt = ni / nt;
+    const float sini2 = float(1.0) - cosi * cosi;
+    const float sint2 = nnt * nnt * sini2;
+    const float cost = std::sqrt(fmax_(float(0.0), float(1.0) - sint2));
+    const float rp = (nt * cosi - ni * cost) / (nt * cosi + ni * cost);
+    const float rs = (ni * cosi - nt * cost) / (ni * cosi + nt * cost);
+    return (rp * rp + rs * rs) * float(0.5);
+}
+inline float computeFlakeDensity(float flake_size, float flakeMapAspect)
+{
+    float aspect = float(1) / flakeMapAspect;
+    float D = PI * flake_size * flake_size * aspect;
+    D = fmin_(D, float(1));
+    return D;
+}
+inline float bits_to_01(uint32_t bits) { uint32_t div = 0xffffffff; return bits * (1.0f / float(div)); }
+inline uint32_t rotl32(uint32_t var, uint32_t hops) { return (var << hops) | (var >> (32 - hops)); }
+inline void bjmix(uint32_t& a, uint32_t& b, uint32_t& c)
+{
+    a -= c;  a ^= rotl32(c, 4);  c += b;
+    b -= a;  b ^= rotl32(a, 6);  a += c;
+    c -= b;  c ^= rotl32(b, 8);  b += a;
+    a -= c;  a ^= rotl32(c, 16);  c += b;
+    b -= a;  b ^= rotl32(a, 19);  a += c;
+    c -= b;  c ^= rotl32(b, 4);  b += a;
+}
+inline uint32_t bjfinal(uint32_t a, uint32_t b, uint32_t c)
+{
+    c ^= b; c -= rotl32(b, 14);
+    a ^= c; a -= rotl32(c, 11);
+    b ^= a; b -= rotl32(a, 25);
+    c ^= b; c -= rotl32(b, 16);
+    a ^= c; a -= rotl32(c, 4);
+    b ^= a; b -= rotl32(a, 14);
+    c ^= b; c -= rotl32(b, 24);
+    return c;
+}
+// `(uint32_t)k[i]` of a NEGATIVE float is undefined in C++; the reference's x86-64 build converts through a 64-bit
+// integer and keeps the low 32 bits.  That behaviour is spelled out here and on the device.
+inline uint32_t f2u_wrap(float f) { return (uint32_t)(int64_t)f; }
+inline uint32_t inthash(const float k[4])
+{
+    uint32_t len = 4;
+    uint32_t a = 0xdeadbeef + (len << 2) + 13;
+    uint32_t b = 0xdeadbeef + (len << 2) + 13;
+    uint32_t c = 0xdeadbeef + (len << 2) + 13;
+    a += f2u_wrap(k[0]);
+    b += f2u_wrap(k[1]);
+    c += f2u_wrap(k[2]);
+    bjmix(a, b, c);
+    a += f2u_wrap(k[3]);
+    c = bjfinal(a, b, c);
+    return c;
+}
+inline v3 cellnoise(const v3& p)
+{
+    float iv[4] = { std::floor(p.x), std::floor(p.y), std::floor(p.z), 0.0F };
+    v3 result;
+    iv[3] = 0; result.x = bits_to_01(inthash(iv));
+    iv[3] = 1; result.y = bits_to_01(inthash(iv));
+    iv[3] = 2; result.z = bits_to_01(inthash(iv));
+    return result;
+}
+inline v4 FlakesNormal_gen(float u, float v, float flake_scale, float flake_size, float flake_size_variance, float flake_normal_orientation)
+{
+    float safe_flake_size_variance = clamp_(flake_size_variance, float(0.1), float(1.0));
+    const v3 cellCenters[9] = {
+        v3(0.5, 0.5, 0.0), v3(1.5, 0.5, 0.0), v3(1.5, 1.5, 0.0), v3(0.5, 1.5, 0.0), v3(-0.5, 1.5, 0.0),
+        v3(-0.5, 0.5, 0.0), v3(-0.5, -0.5, 0.0), v3(0.5, -0.5, 0.0), v3(1.5, -0.5, 0.0)
+    };
+    v3 position(u, v, 0.0);
+    position = flake_scale * position;
+    v3 base(std::floor(position.x), std::floor(position.y), std::floor(position.z));
+    v3 nearestCell(0.0, 0.0, 1.0);
+    int32_t nearestCellIndex = -1;
+    for (int32_t cellIndex = 0; cellIndex < 9; ++cellIndex) {
+        v3 cellCenter = base + cellCenters[cellIndex];
+        v3 centerOffset = cellnoise(cellCenter) * float(2.0) - v3(float(1.0));
+        centerOffset.z *= safe_flake_size_variance;
+        centerOffset = normalize(centerOffset);
+        cellCenter = cellCenter + float(0.5) * centerOffset;
+        float cellDistance = length(position - cellCenter);      // glm::distance
+        if (cellDistance < flake_size && cellCenter.z < nearestCell.z) {
+            nearestCell = cellCenter;
+            nearestCellIndex = cellIndex;
+        }
+    }
+    v3 result(0.5, 0.5, 1.0);
+    float alpha = 0.0;
+    v3 I(0, 0, 1);
+    if (nearestCellIndex != -1) {
+        v3 randomNormal = cellnoise(base + cellCenters[nearestCellIndex] + v3(0.0, 0.0, 1.5));
+        randomNormal = float(2.0) * randomNormal - v3(float(1.0));
+        randomNormal = dot(randomNormal, I) < 0.0F ? randomNormal : -randomNormal;     // glm::faceforward(N, I, Nref = N)
+        randomNormal = normalize(mix(randomNormal, v3(0.0, 0.0, 1.0), flake_normal_orientation));
+        result = randomNormal;
+        alpha = 1.0;
+    }
+    return v4(result.x, result.y, result.z, alpha);
+}
+inline float pdf(const atn_material_param& m, const v3& normal, const v3& wi, const v3& wo)
+{
+    const Param p = param_of(m);
+    const v3 V = -wi, N = normal;
+    float fresnel = computeFresnel(float(1), p.clearcoat_ior, V, N);
+    float beckman_pdf = Beckman::ComputePDF(p.clearcoat_roughness, N, wi, wo);
+    float flakes_beckman_pdf = Beckman::ComputePDF(float(1), N, wi, wo);
+    float flakes_density = computeFlakeDensity(p.flake_size, float(1));
+    float diffuse_pdf = Diffuse::ComputePDF(N, wo);
+    float r = fresnel * beckman_pdf + (float(1) - fresnel) * (flakes_density * flakes_beckman_pdf + (1 - flakes_density) * diffuse_pdf);
+    return clamp_(r, float(0), float(1));
+}
+inline v3 sampleDirection(const atn_material_param& m, const v3& normal, const v3& wi, CMJ* sampler, float pre_sampled_r)
+{
+    const Param p = param_of(m);
+    const v3 V = -wi, N = normal;
+    float r0 = pre_sampled_r;
+    float r1 = sampler->nextSample();
+    float fresnel = computeFresnel(float(1), p.clearcoat_ior, V, N);
+    float flakes_density = computeFlakeDensity(p.flake_size, float(1));
+    v3 dir;
+    if (r0 < fresnel) {
+        r0 /= fresnel;
+        dir = ComputeReflectVector(wi, Beckman::SampleMicrosurfaceNormal(p.clearcoat_roughness, N, r0, r1));
+    }
+    else {
+        r0 -= fresnel;
+        r0 /= (float(1) - fresnel);
+        if (r1 < flakes_density) {
+            r1 /= flakes_density;
+            dir = ComputeReflectVector(wi, Beckman::SampleMicrosurfaceNormal(float(1), N, r0, r1));
+        }
+        else {
+            r1 -= flakes_density;
+            r1 /= (float(1) - flakes_density);
+            dir = Diffuse::SampleDirection(N, r0, r1);
+        }
+    }
+    return dir;
+}
+inline v3 bsdf(const Scene& ctxt, const atn_material_param& m, const v3& normal, const v3& wi, const v3& wo, float u, float v, float pre_sampled_r)
+{
+    const Param p = param_of(m);
+    const v3 albedo = sampleTexture(ctxt, m.albedoMap, u, v, v4(float(1))).xyz();
+    const v3 V = -wi, N = normal;
+    float fresnel = computeFresnel(float(1), p.clearcoat_ior, V, N);
+    v3 r;
+    if (pre_sampled_r < fresnel) {
+        r = Beckman::ComputeBRDF(p.clearcoat_roughness, p.clearcoat_ior, N, wi, wo);
+        r = r * p.clearcoat_color;
+    }
+    else {
+        const bool is_on_flakes = FlakesNormal_gen(u, v, p.flake_scale, p.flake_size, p.flake_size_variance, p.flake_normal_orientation).w > float(0);
+        if (is_on_flakes) {
+            r = Beckman::ComputeBRDF(float(1), float(10), N, wi, wo);
+            r = r * (p.flakes_color * p.flake_color_multiplier);
+        }
+        else {
+            r = p.diffuse_color / PI;
+        }
+    }
+    return albedo * r;
+}
+inline float applyNormalMap(const atn_material_param& m, const v3& orgNml, v3& newNml, float u, float v, const v3& wi, CMJ* sampler)
+{
+    const Param p = param_of(m);
+    const v3 V = -wi;
+    const v3 N = normalize(orgNml);
+    float r0 = sampler->nextSample();
+    float fresnel = computeFresnel(float(1), p.clearcoat_ior, V, N);
+    if (r0 < fresnel) {
+        newNml = N;
+    }
+    else {
+        v4 flakes_nml = FlakesNormal_gen(u, v, p.flake_scale, p.flake_size, p.flake_size_variance, p.flake_normal_orientation);
+        if (flakes_nml.w > float(0)) {
+            // applyTangentSpaceCoord, car_paint.cpp:14-23
+            v3 n = normalize(orgNml);
+            v3 t, b;
+            GetTangentCoordinate(n, t, b);
+            newNml = flakes_nml.z * n + flakes_nml.x * t + flakes_nml.y * b;
+            newNml = normalize(newNml);
+        }
+        else {
+            newNml = N;
+        }
+    }
+    return r0;
+}
+} // namespace CarPaint
+
+// material::applyNormal, material_impl.h:208-230
+inline float applyNormal(const Scene& ctxt, const atn_material_param& mtrl, const v3& orgNml, v3& newNml, float u, float v,
+    const v3& wi, CMJ* sampler)
+{
+    if (mtrl.type == ATN_MTRL_CARPAINT) return CarPaint::applyNormalMap(mtrl, orgNml, newNml, u, v, wi, sampler);
+    applyNormalMap(ctxt, mtrl.normalMap, orgNml, newNml, u, v);
+    return float(-1);
+}
+
 // ---- OrenNayar: material/oren_nayar.cpp:8-140 ------------------------------------------------------
 namespace OrenNayar {
 inline float pdf(const v3& normal, const v3& wo)
@@ -895,9 +1117,14 @@ inline void sample(MaterialSampling& result, const Scene& ctxt, const atn_materi
 // ---- dispatch: material/material_impl.h:24-206 (types outside the BASELINE configs fall
 //      to the reference's own default branch: Diffuse) --------------------------------------
 inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const atn_material_param* mtrl,
-    const v3& normal, const v3& wi, CMJ* sampler, float u, float v)
+    const v3& normal, const v3& wi, CMJ* sampler, float u, float v, float pre_sampled_r = 0.0F)
 {
     switch (mtrl->type) {
+    case ATN_MTRL_CARPAINT:     // CarPaint::sample, car_paint.cpp:178-193
+        result->dir = CarPaint::sampleDirection(*mtrl, normal, wi, sampler, pre_sampled_r);
+        result->pdf = CarPaint::pdf(*mtrl, normal, wi, result->dir);
+        result->bsdf = CarPaint::bsdf(ctxt, *mtrl, normal, wi, result->dir, u, v, pre_sampled_r);
+        break;
     case ATN_MTRL_SPECULAR: Specular::sample(result, normal, wi); break;
     case ATN_MTRL_REFRACTION: Refraction::sample(*result, sampler, *mtrl, normal, wi); break;
     case ATN_MTRL_BECKMAN: Beckman::sample(result, ctxt, *mtrl, normal, wi, sampler, u, v); break;
@@ -924,10 +1151,12 @@ inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const 
     case ATN_MTRL_GGX: return GGX::ComputePDF(GGX::roughness_of(ctxt, *mtrl, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
     case ATN_MTRL_RETROREFLECTIVE: return Retroreflective::pdf(*mtrl, normal, wi, wo);
+    case ATN_MTRL_CARPAINT: return CarPaint::pdf(*mtrl, normal, wi, wo);
     default: return Diffuse::ComputePDF(normal, wo);
     }
 }
-inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* mtrl, const v3& normal, const v3& wi, const v3& wo, float u, float v)
+inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* mtrl, const v3& normal, const v3& wi, const v3& wo, float u, float v,
+    float pre_sampled_r = 0.0F)
 {
     MaterialSampling r;     // pdf = 0 unless the BSDF returns its own (Disney)
     switch (mtrl->type) {
@@ -940,6 +1169,7 @@ inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* 
     case ATN_MTRL_GGX: r.bsdf = GGX::ComputeBRDF(GGX::roughness_of(ctxt, *mtrl, u, v), mtrl->u.standard.ior, normal, wi, wo); break;
     case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
     case ATN_MTRL_RETROREFLECTIVE: r = Retroreflective::bsdf(*mtrl, normal, wi, wo); break;
+    case ATN_MTRL_CARPAINT: r.bsdf = CarPaint::bsdf(ctxt, *mtrl, normal, wi, wo, u, v, pre_sampled_r); break;
     default: r.bsdf = Diffuse::ComputeBRDF(); break;
     }
     return r;
@@ -1304,11 +1534,11 @@ inline void GeneratePath(Ray& generated_ray, int32_t ix, int32_t iy, int32_t sam
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
 inline bool ComputeRadianceNEE(v3& out, const Scene& ctxt, const v3& wi, const v3& surface_nml,
     const atn_material_param& surface_mtrl, float hit_u, float hit_v, float light_select_prob,
-    const LightSampleResult& ls)
+    const LightSampleResult& ls, float pre_sampled_random = 0.0F)
 {
     float cosShadow = dot(surface_nml, ls.dir);
     float path_pdf = samplePDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v);
-    MaterialSampling ev = sampleBSDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v);
+    MaterialSampling ev = sampleBSDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v, pre_sampled_random);
     if (ev.pdf > 0) path_pdf = ev.pdf;
     const v3& bsdf = ev.bsdf;
     const v3& emit = ls.light_color;
@@ -1331,7 +1561,7 @@ inline bool ComputeRadianceNEE(v3& out, const Scene& ctxt, const v3& wi, const v
 // SampleLight + FillShadowRay, pathtracing_impl.h:178-264
 inline void FillShadowRay(ShadowRay& shadow_ray, const Scene& ctxt, PathState& path,
     const atn_material_param& mtrl, const Ray& ray, const v3& hit_pos, const v3& hit_nml,
-    float hit_u, float hit_v, const v4& external_albedo)
+    float hit_u, float hit_v, const v4& external_albedo, float pre_sampled_r = 0.0F)
 {
     shadow_ray.isActive = false;
     const int32_t lightnum = ctxt.GetLightNum();
@@ -1353,7 +1583,7 @@ inline void FillShadowRay(ShadowRay& shadow_ray, const Scene& ctxt, PathState& p
     shadow_ray.lightcontrib = v3(0);
 
     v3 radiance;
-    if (ComputeRadianceNEE(radiance, ctxt, ray.dir, hit_nml, mtrl, hit_u, hit_v, lightSelectPdf, sampleres)) {
+    if (ComputeRadianceNEE(radiance, ctxt, ray.dir, hit_nml, mtrl, hit_u, hit_v, lightSelectPdf, sampleres, pre_sampled_r)) {
         // vec3 * vec3 * vec4 (component-wise; .w dropped on store)
         shadow_ray.lightcontrib = path.throughput * radiance * external_albedo.xyz();
         shadow_ray.isActive = true;
@@ -1519,19 +1749,20 @@ inline void shade(PathState& path, const Scene& ctxt, Ray& ray, ShadowRay& shado
 
     if (!attr_translucent(mtrl) && isBackfacing) orienting_normal = -orienting_normal;
 
-    // material::applyNormal -> applyNormalMap (CarPaint out of scope)
+    // material::applyNormal (pathtracing.cpp:181-188): normal map, or CarPaint's flake normal + shared random number
+    float pre_sampled_r;
     {
         v3 nn;
-        applyNormalMap(ctxt, mtrl.normalMap, orienting_normal, nn, rec.u, rec.v);
+        pre_sampled_r = applyNormal(ctxt, mtrl, orienting_normal, nn, rec.u, rec.v, ray_in.dir, &path.sampler);
         orienting_normal = nn;
     }
 
-    FillShadowRay(shadow_ray, ctxt, path, mtrl, ray_in, rec.p, orienting_normal, rec.u, rec.v, albedo);
+    FillShadowRay(shadow_ray, ctxt, path, mtrl, ray_in, rec.p, orienting_normal, rec.u, rec.v, albedo, pre_sampled_r);
 
     const float russianProb = ComputeRussianProbability(bounce, rrDepth, path);
 
     MaterialSampling sampling;
-    sampleMaterial(&sampling, ctxt, &mtrl, orienting_normal, ray_in.dir, &path.sampler, rec.u, rec.v);
+    sampleMaterial(&sampling, ctxt, &mtrl, orienting_normal, ray_in.dir, &path.sampler, rec.u, rec.v, pre_sampled_r);
 
     PrepareForNextBounce(rec, russianProb, orienting_normal, mtrl, sampling, albedo.xyz(), path, ray);
 }

@@ -170,15 +170,16 @@ inline void Shade(PathState& path, const Scene& ctxt, Ray& ray, ShadowRay& shado
     if (HitImplicitLight(ctxt, isect.objid, isBackfacing, bounce, path, ray_in, rec, mtrl)) return;
 
     if (!attr_translucent(mtrl) && isBackfacing) orienting_normal = -orienting_normal;
+    float pre_sampled_r;
     {
         v3 nn;
-        applyNormalMap(ctxt, mtrl.normalMap, orienting_normal, nn, rec.u, rec.v);
+        pre_sampled_r = applyNormal(ctxt, mtrl, orienting_normal, nn, rec.u, rec.v, ray_in.dir, &path.sampler);
         orienting_normal = nn;
     }
-    FillShadowRay(shadow_ray, ctxt, path, mtrl, ray_in, rec.p, orienting_normal, rec.u, rec.v, albedo);
+    FillShadowRay(shadow_ray, ctxt, path, mtrl, ray_in, rec.p, orienting_normal, rec.u, rec.v, albedo, pre_sampled_r);
     const float russianProb = ComputeRussianProbability(bounce, rrDepth, path);
     MaterialSampling sampling;
-    sampleMaterial(&sampling, ctxt, &mtrl, orienting_normal, ray_in.dir, &path.sampler, rec.u, rec.v);
+    sampleMaterial(&sampling, ctxt, &mtrl, orienting_normal, ray_in.dir, &path.sampler, rec.u, rec.v, pre_sampled_r);
     PrepareForNextBounce(rec, russianProb, orienting_normal, mtrl, sampling, albedo.xyz(), path, ray);
 }
 

@@ -188,3 +188,40 @@ def test_all_rays_miss_and_no_lights(gpu, orc, cornell):
     want = orc.render(fs2, c2, seeds, w, h, 5, 3)
     d = np.abs(got[..., :3] - want[..., :3])
     assert np.all(d <= 1e-3 * np.maximum(1.0, np.abs(want[..., :3])))
+
+
+def test_film_checkpoint_and_resume(orc, cornell):
+    """Download the progressive film after 3 frames, restore it into a FRESH context and render frames 3..5 there: the
+    result equals 6 uninterrupted frames byte for byte (FilmProgressive state = running mean + count, film.cpp:61-71)."""
+    fs, cam = cornell
+    w, h = 80, 48
+    c = make_camera(orc, cam, w, h)
+
+    def fresh():
+        g = _fresh()
+        g.UpdateSceneData(fs); g.updateCamera(c); g.initSampler(w, h, 0)
+        return g
+    a = fresh()
+    try:
+        for f in range(6):
+            want = a.render(w, h, 5, 3, frame=f)
+    finally:
+        a.close()
+    b = fresh()
+    try:
+        for f in range(3):
+            ckpt = b.render(w, h, 5, 3, frame=f)
+    finally:
+        b.close()
+    assert np.all(ckpt[..., 3] == 3.0)
+    r = fresh()
+    try:
+        r.upload_film(ckpt)
+        for f in range(3, 6):
+            got = r.render(w, h, 5, 3, frame=f)
+        assert got.tobytes() == want.tobytes()
+        from aten_amd.renderer import AtenAmdError
+        import ctypes as C
+        assert r._l.atn_upload_film(r._ctx, 0, 4, ckpt.ctypes.data) != 0
+    finally:
+        r.close()

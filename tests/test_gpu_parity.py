@@ -227,19 +227,21 @@ def test_material_tables(gpu, orc, cornell, sponza_disney, which):
           % (which, relerr(gs[:, :3], ws[:, :3]), relerr(gs[:, 3:], ws[:, 3:]), relerr(ge, we)))
 
 
-@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar", "velvet", "microfacet_refraction", "retroreflective"])
+@pytest.mark.parametrize("which", ["refraction", "beckman", "oren_nayar", "velvet", "microfacet_refraction", "retroreflective", "carpaint"])
 def test_material_tables_next_tier(gpu, orc, which):
     """BSDFs beyond the BASELINE set: refraction.cpp, beckman.cpp, oren_nayar.cpp, velvet.cpp,
-    microfacet_refraction.cpp, retroreflective.cpp."""
+    microfacet_refraction.cpp, retroreflective.cpp, car_paint.cpp + FlakesNormal.cpp (for CarPaint the table runs
+    material::applyNormal first -- it draws the random number the sampler and the evaluation share and may swap in a flake
+    normal -- exactly as shade does)."""
     from aten_amd import layout as L
     from aten_amd.scene import scenedefs
     scene = scenedefs.cornell_box_variant(lights="area", move_boxes=False,
-                                          extra_materials="retro" if which == "retroreflective" else
+                                          extra_materials="carpaint" if which == "carpaint" else "retro" if which == "retroreflective" else
                                           ("rough" if which in ("velvet", "microfacet_refraction") else True))
     fs, c, _ = _setup(gpu, orc, scene, 64, 64)
     want_type = {"refraction": L.MTRL_REFRACTION, "beckman": L.MTRL_BECKMAN, "oren_nayar": L.MTRL_OREN_NAYAR,
                  "velvet": L.MTRL_VELVET, "microfacet_refraction": L.MTRL_MICROFACET_REFRACTION,
-                 "retroreflective": L.MTRL_RETROREFLECTIVE}[which]
+                 "retroreflective": L.MTRL_RETROREFLECTIVE, "carpaint": L.MTRL_CARPAINT}[which]
     mid = int(np.nonzero(fs.arrays["materials"]["type"] == want_type)[0][0])
     rng = np.random.default_rng(11)
     n = 512
@@ -274,7 +276,7 @@ def test_material_tables_next_tier(gpu, orc, which):
     assert relerr(ge, we) <= 2e-3
 
 
-@pytest.mark.parametrize("extra", [True, "rough", "retro"])
+@pytest.mark.parametrize("extra", [True, "rough", "retro", "carpaint"])
 def test_next_tier_materials_frames(gpu, orc, extra):
     from aten_amd.scene import scenedefs
     scene = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials=extra)

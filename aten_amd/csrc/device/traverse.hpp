@@ -151,6 +151,7 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
 #endif
 constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
 
+
 // One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
 // 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
 // leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.

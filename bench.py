@@ -87,6 +87,22 @@ def usable_cpus():
     return n
 
 
+def needs_self_launch(gpus, mgpu, env):
+    """True when bench.py was started as a plain process but asked for several GPUs in the one-rank-per-GPU mode."""
+    return gpus > 1 and not mgpu and "WORLD_SIZE" not in env
+
+
+def launcher_cmd(gpus, argv, port=None):
+    """The command the driver itself uses for N > 1: torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main_mgpu(args):
     """One process drives every GPU through atn_mgpu_* (no torch.distributed): the path a C++ aten application takes."""
     import torch
@@ -163,15 +179,9 @@ def main():
     elif args.config == "c5":
         args.svgf = True
 
-    if args.gpus > 1 and not args.mgpu and "WORLD_SIZE" not in os.environ:
+    if needs_self_launch(args.gpus, args.mgpu, os.environ):
         # `python bench.py --gpus N` on its own: become the launcher the contract describes (one rank per GPU)
-        import socket
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        os.execv(sys.executable, cmd)
+        os.execv(sys.executable, launcher_cmd(args.gpus, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -482,6 +492,7 @@ def main():
     if final_img is not None:
         np.save(args.dump, final_img)
 
+    out = None
     if rank == 0:
         out = {
             "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5) and not args.svgf)
@@ -502,10 +513,12 @@ def main():
             "svgf": svgf_info,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
     r.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)      # the one JSON line, after every library has had its say
 
 
 if __name__ == "__main__":

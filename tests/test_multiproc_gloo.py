@@ -48,3 +48,26 @@ def test_tiling_maps_are_a_partition():
             assert len(xs) == tiling.slots_per_rank(w, h, world)
             seen[ys[valid], xs[valid]] += 1
         assert np.all(seen == 1)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 (the command line the driver uses); under a launcher, with --mgpu or with one GPU it does not."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.needs_self_launch(8, False, {})
+    assert not b.needs_self_launch(8, False, {"WORLD_SIZE": "8"})
+    assert not b.needs_self_launch(8, True, {})
+    assert not b.needs_self_launch(1, False, {})
+    cmd = b.launcher_cmd(4, ["--gpus", "4", "--steps", "7"], port=29511)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    free = b.launcher_cmd(2, [])
+    assert int(free[free.index("--master-port") + 1]) > 0

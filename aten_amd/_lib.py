@@ -18,7 +18,7 @@ SYMBOLS = [
     "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset", "atn_set_path_batches",
     "atn_set_frames_in_flight", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
     "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
-    "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_denoise", "atn_svgf_upload",
+    "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
     "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_kernel_times",
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples",
@@ -69,6 +69,7 @@ def lib():
         l.atn_svgf_reset.argtypes = [vp]
         l.atn_svgf_set_atrous_iterations.argtypes = [vp, C.c_int32]
         l.atn_svgf_download.argtypes = [vp, C.c_int32, vp]
+        l.atn_svgf_set_dilate_temporal_weight.argtypes = [vp, C.c_int32]
         l.atn_svgf_denoise.argtypes = [vp, vp, C.c_int32, vp, vp]
         l.atn_svgf_upload.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
         l.atn_svgf_output_device.argtypes = [vp]

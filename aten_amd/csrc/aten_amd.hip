@@ -735,6 +735,8 @@ public:
     float4* sv_spare = nullptr;
     int32_t sv_w = 0, sv_h = 0, sv_curr = 0, sv_atrous_iters = 5;
     bool sv_motion_set = false;
+    DevBuf<float> sv_weight;        // scalar plane of the optional temporal-weight dilation
+    int32_t sv_dilate_weight = 0;
     size_t sv_motion_count = 0;     // elements of the last atn_svgf_set_motion_depth / upload (sv_motion.n is the capacity)
     float sv_W2V[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
     float sv_V2C[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
@@ -892,6 +894,11 @@ public:
         if (d->frame > 0) {
             prof_begin(prof, ATN_K_SVGF_TEMPORAL);
             hipLaunchKernelGGL(k_svgf_temporal, gp, tp, 0, stream, sf, 0.98f, 0.05f);
+            if (sv_dilate_weight) {
+                ATN_HIP(sv_weight.resize((size_t)d->width * d->height));
+                hipLaunchKernelGGL(k_svgf_dilate_weight, gp, tp, 0, stream, sf, sv_weight.p);
+                hipLaunchKernelGGL(k_svgf_store_weight, gp, tp, 0, stream, sf, (const float*)sv_weight.p);
+            }
             prof_end(prof);
         }
         else if (sf.stages) {
@@ -1074,6 +1081,12 @@ int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n)
     CTX_OR_FAIL(ctx);
     if (n < 1 || n > 8) return ctx->r.fail(ATN_ERR_INVALID_ARG, "a-trous iteration count out of range");
     ctx->r.sv_atrous_iters = n;
+    return ATN_OK;
+}
+int atn_svgf_set_dilate_temporal_weight(atn_ctx* ctx, int32_t on)
+{
+    CTX_OR_FAIL(ctx);
+    ctx->r.sv_dilate_weight = on ? 1 : 0;
     return ATN_OK;
 }
 int atn_svgf_download(atn_ctx* ctx, int32_t which, atn_vec4* out_host)

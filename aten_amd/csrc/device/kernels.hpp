@@ -331,8 +331,13 @@ struct SvgfShade {
 // SVGF = true is SVGFRenderer::Shade + ShadeMiss with AOV spans: AOVs at bounce 0 (and at bounce 1 behind a Specular
 // hit), albedo read with default (1,1,1,1) and demodulated where the AOV took it.
 // MS: the material set of the scene (DevScene::material_set, shading.hpp): BSDFs outside it are compiled out.
+#ifdef ATN_SHADE_WPE
+#define ATN_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(ATN_SHADE_WPE, ATN_SHADE_WPE)))
+#else
+#define ATN_SHADE_ATTR
+#endif
 template <bool SVGF, int MS>
-__global__ void __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+__global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     __shared__ BlockAppendShared sh;
     __shared__ BlockBinShared shb;

@@ -124,6 +124,37 @@ __global__ void __launch_bounds__(256) k_svgf_prepare(SvgfFrame sf)
     }
 }
 
+// RecomputeTemporalWeightFromSurroundingPixels (svgf_impl.h:386-423): the temporal weight of a non-background pixel becomes
+// the minimum over its 3x3 neighbourhood.  Only the CUDA twin runs it, right after temporal reprojection and IN PLACE
+// (src/libidaten/svgf/svgf_tp.cu:150-216), so neighbours race; here every tap reads the weight the pass started with
+// (two launches through a scalar plane).  Optional: atn_svgf_set_dilate_temporal_weight.
+__global__ void __launch_bounds__(256) k_svgf_dilate_weight(SvgfFrame sf, float* __restrict__ out)
+{
+    int32_t ix, iy;
+    if (!svgf_pixel(sf, ix, iy)) return;
+    const int32_t width = sf.width, height = sf.height;
+    const int32_t idx = ix + iy * width;
+    float w = sf.mt[idx].w;
+    if ((int32_t)sf.am[idx].w >= 0) {
+        for (int32_t y = -1; y <= 1; y++)
+            for (int32_t x = -1; x <= 1; x++) {
+                const int32_t xx = ix + x, yy = iy + y;
+                if ((0 <= xx) && (xx < width) && (0 <= yy) && (yy < height)) {
+                    const float nw = sf.mt[xx + yy * width].w;
+                    w = (nw < w) ? nw : w;      // aten::min
+                }
+            }
+    }
+    out[idx] = w;
+}
+__global__ void __launch_bounds__(256) k_svgf_store_weight(SvgfFrame sf, const float* __restrict__ in)
+{
+    int32_t ix, iy;
+    if (!svgf_pixel(sf, ix, iy)) return;
+    const int32_t idx = ix + iy * sf.width;
+    sf.mt[idx].w = in[idx];
+}
+
 // SVGFRenderer::TemporalReprojection (svgf.cpp:231-296) = ExtractCenterPixel + UpdateAOVIfBackgroundPixel +
 // svgf::TemporalReprojection + AccumulateMoments (svgf_impl.h:154-380).  No transcendental: bit-exact.
 __global__ void __launch_bounds__(256) k_svgf_temporal(SvgfFrame sf, float threshold_normal, float threshold_depth)

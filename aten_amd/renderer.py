@@ -175,6 +175,9 @@ class PathTracing:
     def svgf_reset(self):
         self._check(self._l.atn_svgf_reset(self._ctx))
 
+    def svgf_set_dilate_temporal_weight(self, on):
+        self._check(self._l.atn_svgf_set_dilate_temporal_weight(self._ctx, int(on)))
+
     def svgf_set_atrous_iterations(self, n):
         self._check(self._l.atn_svgf_set_atrous_iterations(self._ctx, n))
 

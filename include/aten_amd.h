@@ -211,6 +211,11 @@ int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32
 int atn_svgf_reset(atn_ctx* ctx);
 /* SVGFParams::atrous_iter_cnt (svgf_types.h:72), default 5. */
 int atn_svgf_set_atrous_iterations(atn_ctx* ctx, int32_t n);
+/* Optional pass, off by default (the CPU SVGFRenderer, the parity target, never runs it; the CUDA twin does, right after
+ * temporal reprojection: src/libidaten/svgf/svgf_tp.cu:150-216): RecomputeTemporalWeightFromSurroundingPixels
+ * (src/libaten/renderer/svgf/svgf_impl.h:386-423) -- a non-background pixel's temporal weight becomes the minimum over
+ * its 3x3 neighbourhood, every tap reading the weights the pass started with. */
+int atn_svgf_set_dilate_temporal_weight(atn_ctx* ctx, int32_t on);
 /* Parity probe.  which: 0-3 SVGFParams::GetCurrAovBuffer() as the state stands (OnRender toggles at its end, so
  * this is the set the NEXT frame writes: normal+depth, albedo+meshid, colour+variance, moments+temporal weight),
  * 4-7 GetPrevAovBuffer() (the set the last frame wrote), 8 temporary colour, 9 motion/depth, 10 primary hit

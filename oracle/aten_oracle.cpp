@@ -242,6 +242,7 @@ int orc_num_procs() { return omp_get_num_procs(); }
 void* orc_svgf_create() { return new svgf::Params(); }
 void orc_svgf_destroy(void* h) { delete static_cast<svgf::Params*>(h); }
 void orc_svgf_set_atrous_iterations(void* h, int32_t n) { static_cast<svgf::Params*>(h)->atrous_iter_cnt = n; }
+void orc_svgf_set_dilate_temporal_weight(void* h, int32_t on) { static_cast<svgf::Params*>(h)->dilate_temporal_weight = on; }
 
 // SVGFRenderer::SetMotionDepthBuffer (svgf.cpp:441-450): vec4 {motion.xy in screen fractions, depth, 1} per pixel
 void orc_svgf_set_motion_depth(void* h, const atn_vec4* md, uint32_t n)
@@ -343,6 +344,18 @@ void orc_svgf_render(void* h, const atn_scene_desc* scene, const atn_camera_para
             else temporal_projected_clr = v4(contribs[idx].x, contribs[idx].y, contribs[idx].z, 1.0f);   // vec4() then operator=(vec3): w stays 1
             put(1, idx, temporal_projected_clr);
         }
+    }
+
+    if (P.dilate_temporal_weight && dst->frame > 0) {
+        const std::vector<v4> mt_in = P.cur(svgf::MomentTemporalWeight);
+        std::vector<v4>& mt = P.cur(svgf::MomentTemporalWeight);
+#pragma omp parallel for
+        for (int32_t y = 0; y < height; y++)
+            for (int32_t x = 0; x < width; x++) {
+                float w;
+                if (svgf::RecomputeTemporalWeightFromSurroundingPixels(x, y, width, height, P.cur(svgf::AlbedoMeshId), mt_in, w))
+                    mt[y * width + x].w = w;
+            }
     }
 
     // Camera::ComputeScreenDistance (camera.h:216-221): tan() of half the vertical fov IN DEGREES, as written

@@ -143,6 +143,9 @@ class Svgf:
     def set_atrous_iterations(self, n):
         lib().orc_svgf_set_atrous_iterations(self._h, C.c_int32(n))
 
+    def set_dilate_temporal_weight(self, on):
+        lib().orc_svgf_set_dilate_temporal_weight(self._h, C.c_int32(int(on)))
+
     def set_motion_depth(self, md):
         md = np.ascontiguousarray(md, np.float32).reshape(-1, 4)
         lib().orc_svgf_set_motion_depth(self._h, C.c_void_p(md.ctypes.data), C.c_uint32(len(md)))

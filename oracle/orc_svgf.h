@@ -100,6 +100,7 @@ struct Params {         // SVGFParams<std::vector<vec4>> + the renderer's frame-
     int32_t width = 0, height = 0;
     int32_t curr_aov_pos = 0;
     int32_t atrous_iter_cnt = 5;
+    int32_t dilate_temporal_weight = 0;     // optional pass of the CUDA twin (svgf_tp.cu:150-216), off on the CPU path
     std::vector<v4> aovs[2][NumAov];
     std::vector<v4> atrous_clr_variance[2];
     std::vector<v4> temporary_color_buffer;
@@ -313,6 +314,28 @@ inline v4 TemporalReprojection(int32_t ix, int32_t iy, int32_t width, int32_t he
         cur_mt[idx].x = center_moment.x; cur_mt[idx].y = center_moment.y; cur_mt[idx].z = center_moment.z;
     }
     return curr_color;
+}
+
+// RecomputeTemporalWeightFromSurroundingPixels, svgf_impl.h:386-423; `mt_in` = the moment / temporal-weight plane as it was
+// when the pass began.  Returns false for a background pixel (std::nullopt).
+inline bool RecomputeTemporalWeightFromSurroundingPixels(int32_t ix, int32_t iy, int32_t width, int32_t height,
+    const std::vector<v4>& aov_texclr_meshid, const std::vector<v4>& mt_in, float& out)
+{
+    const int32_t idx = iy * width + ix;
+    const int32_t center_meshId = static_cast<int32_t>(aov_texclr_meshid[idx].w);
+    if (center_meshId < 0) return false;
+    float temporal_weight = mt_in[idx].w;
+    for (int32_t y = -1; y <= 1; y++) {
+        for (int32_t x = -1; x <= 1; x++) {
+            int32_t xx = ix + x, yy = iy + y;
+            if ((0 <= xx) && (xx < width) && (0 <= yy) && (yy < height)) {
+                float w = mt_in[yy * width + xx].w;
+                temporal_weight = fmin_(temporal_weight, w);
+            }
+        }
+    }
+    out = temporal_weight;
+    return true;
 }
 
 // svgf::EstimateVariance (svgf_impl.h:441-545); `cv_in` = aov_color_variance as it was when the pass began

@@ -126,6 +126,48 @@ def test_svgf_temporal_pass_bit_exact(gpu, orc, cornell):
         sv.close()
 
 
+def test_svgf_optional_temporal_weight_dilation_bit_exact(gpu, orc, cornell):
+    """RecomputeTemporalWeightFromSurroundingPixels (svgf_impl.h:386-423; run by the CUDA twin only, svgf_tp.cu:150-216)
+    behind atn_svgf_set_dilate_temporal_weight: integer compares and a 3x3 minimum, so with equal inputs and equal history
+    the moment / temporal-weight plane must agree with the oracle's twin to the last bit -- and differ from the plane
+    without the pass."""
+    fs, cam = cornell
+    w, h = 96, 64
+    c, seeds = _setup(gpu, orc, fs, cam, w, h)
+    sv = orc.Svgf()
+    planes = {}
+    try:
+        for dilate in (False, True):
+            gpu.svgf_reset()
+            gpu.svgf_set_dilate_temporal_weight(dilate)
+            sv.close(); sv = orc.Svgf()
+            sv.set_dilate_temporal_weight(dilate)
+
+            def feed(wst):
+                contribs = wst[0].copy()
+                contribs[..., 3] = 1.0
+                gpu.svgf_upload("contribs", contribs)
+                gpu.svgf_upload("normal_depth", sv.buffer("prev_normal_depth"))
+                gpu.svgf_upload("albedo_meshid", sv.buffer("prev_albedo_meshid"))
+                gpu.svgf_upload("primary_position", sv.buffer("primary_position"))
+            _, wst = sv.render(fs, c, seeds, w, h, 3, 3, frame=0, compute_motion=True, stages=True)
+            feed(wst)
+            gpu.svgf_denoise(w, h, frame=0, compute_motion=True)
+            for frame in (1, 2, 3):
+                for name in ("prev_normal_depth", "prev_albedo_meshid", "prev_color_variance", "prev_moment_temporalweight"):
+                    gpu.svgf_upload(name, sv.buffer(name))
+                _, wst = sv.render(fs, c, seeds, w, h, 3, 3, frame=frame, compute_motion=True, stages=True)
+                feed(wst)
+                gpu.svgf_denoise(w, h, frame=frame, compute_motion=True)
+                a, b = gpu.svgf_buffer("prev_moment_temporalweight"), sv.buffer("prev_moment_temporalweight")
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (dilate, frame)
+            planes[dilate] = a.copy()
+        assert not np.array_equal(planes[False][..., 3], planes[True][..., 3])
+    finally:
+        gpu.svgf_set_dilate_temporal_weight(False)
+        sv.close()
+
+
 def test_svgf_external_motion_buffer_and_camera_move(gpu, orc, sponza):
     """SetMotionDepthBuffer path (the reference's own interface) and a moving camera through the compute pass."""
     fs, cam = sponza

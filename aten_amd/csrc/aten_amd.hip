@@ -165,7 +165,9 @@ public:
     {
         ATN_HIP(hipStreamSynchronize(stream));
         for (int i = 0; i < n_spare_ready; i++) ATN_HIP(hipStreamSynchronize(spare[i].stream));
+        if (sv_stream) ATN_HIP(hipStreamSynchronize(sv_stream));
         last_gather = nullptr;
+        sv_prepare_recorded[0] = sv_prepare_recorded[1] = false;
         return ATN_OK;
     }
 
@@ -222,6 +224,8 @@ public:
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
+        for (auto& e : sv_ev_prepare) if (e) (void)hipEventDestroy(e);
+        if (sv_stream) (void)hipStreamDestroy(sv_stream);
         for (int i = 0; i < n_spare_ready; i++) {
             Bank& b = spare[i];
             for (int k = 0; k < kMaxBatches; k++) {
@@ -730,11 +734,19 @@ public:
     // SVGF (aten::SVGFRenderer, src/libaten/renderer/svgf/svgf.cpp): frame-persistent state = SVGFParams
     // (svgf_types.h:54-166) + MatricesForRendering (pt_params.h:150-185)
     // ------------------------------------------------------------------------------------------------
-    DevBuf<float4> sv_aov[2][4], sv_scratch, sv_atrous[2], sv_tmp, sv_motion, sv_primary, sv_contribs, sv_out, sv_stages;
+    DevBuf<float4> sv_aov[2][4], sv_scratch, sv_atrous[2], sv_tmp, sv_motion, sv_out, sv_stages;
+    // what the path pass hands to the filters, two slots so that frame f + 1's path pass can run while frame f is filtered:
+    // G-buffer staging (normal+depth, albedo+id), primary hit positions, contributions
+    DevBuf<float4> sv_gnd[2], sv_gam[2], sv_primary[2], sv_contribs[2];
+    int32_t sv_slot = 0, sv_last_slot = 0;      // slot of the next frame / of the last frame, upload or denoise
+    hipEvent_t sv_ev_prepare[2] = { nullptr, nullptr };     // the prepare pass that consumed slot k has finished
+    bool sv_prepare_recorded[2] = { false, false };
     float4* sv_cv[2] = { nullptr, nullptr };    // colour+variance of the two AOV sets (the variance pass swaps with sv_spare)
     float4* sv_spare = nullptr;
     int32_t sv_w = 0, sv_h = 0, sv_curr = 0, sv_atrous_iters = 5;
     bool sv_motion_set = false;
+    hipStream_t sv_stream = nullptr;        // filter stream of pipelined SVGF frames (frames in flight > 1)
+    bool w_or_h_changed(int32_t w, int32_t h) const { return w != sv_w || h != sv_h || w != film_w || h != film_h; }
     DevBuf<float> sv_weight;        // scalar plane of the optional temporal-weight dilation
     int32_t sv_dilate_weight = 0;
     size_t sv_motion_count = 0;     // elements of the last atn_svgf_set_motion_depth / upload (sv_motion.n is the capacity)
@@ -800,11 +812,14 @@ public:
             ATN_HIP(sv_scratch.resize(n)); svgf_fill(sv_scratch.p, n, init);
             for (auto& b : sv_atrous) { ATN_HIP(b.resize(n)); svgf_fill(b.p, n, init); }
             ATN_HIP(sv_tmp.resize(n)); svgf_fill(sv_tmp.p, n, init);
-            ATN_HIP(sv_primary.resize(n)); svgf_fill(sv_primary.p, n, make_float4(0, 0, 0, 0));
-            ATN_HIP(sv_contribs.resize(n)); ATN_HIP(sv_out.resize(n));
+            for (int k = 0; k < 2; k++) {
+                ATN_HIP(sv_primary[k].resize(n)); svgf_fill(sv_primary[k].p, n, make_float4(0, 0, 0, 0));
+                ATN_HIP(sv_contribs[k].resize(n)); ATN_HIP(sv_gnd[k].resize(n)); ATN_HIP(sv_gam[k].resize(n));
+            }
+            ATN_HIP(sv_out.resize(n));
             if (!sv_motion_set || sv_motion_count < n) { ATN_HIP(sv_motion.resize(n)); sv_motion_set = false; sv_motion_count = 0; }
             sv_cv[0] = sv_aov[0][2].p; sv_cv[1] = sv_aov[1][2].p; sv_spare = sv_scratch.p;
-            sv_w = w; sv_h = h; sv_curr = 0;
+            sv_w = w; sv_h = h; sv_curr = 0; sv_slot = 0; sv_last_slot = 0;
         }
         if (stages) ATN_HIP(sv_stages.resize(3 * n));
         return ATN_OK;
@@ -831,14 +846,17 @@ public:
         return ATN_OK;
     }
 
-    float4* svgf_buffer(int32_t which)
+    // uploads address the slot the NEXT frame / denoise call reads, downloads the slot the last one used
+    float4* svgf_buffer(int32_t which, bool for_upload = false)
     {
         const int32_t c = sv_curr, p = 1 - sv_curr;
+        const int32_t k = for_upload ? sv_slot : sv_last_slot;
+        if (for_upload && (which == 10 || which == 14)) sv_last_slot = sv_slot;
         if (which >= 0 && which < 4) return which == 2 ? sv_cv[c] : sv_aov[c][which].p;
         if (which < 8) return which == 6 ? sv_cv[p] : sv_aov[p][which - 4].p;
         switch (which) {
-        case 8: return sv_tmp.p; case 9: return sv_motion.p; case 10: return sv_primary.p;
-        case 11: return sv_atrous[0].p; case 12: return sv_atrous[1].p; case 13: return sv_out.p; case 14: return sv_contribs.p;
+        case 8: return sv_tmp.p; case 9: return sv_motion.p; case 10: return sv_primary[k].p;
+        case 11: return sv_atrous[0].p; case 12: return sv_atrous[1].p; case 13: return sv_out.p; case 14: return sv_contribs[k].p;
         }
         return nullptr;
     }
@@ -853,7 +871,25 @@ public:
         if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
         if (world != 1) return fail(ATN_ERR_UNSUPPORTED, "SVGF needs the whole frame on one GPU (filter footprints cross tiles)");
         ATN_HIP(hipSetDevice(device));
-        int rc = ensure_frame(d->width, d->height, d->maxDepth);
+        // Frames in flight (atn_set_frames_in_flight > 1): the path pass of frame f + 1 runs on the next bank's stream while
+        // frame f is still being traced and filtered.  The path pass writes only its bank and slot (f + 1) % 2 of the
+        // hand-over planes (G-buffer staging, primary positions, contributions), so all it waits for is the prepare pass
+        // that consumed that slot two frames ago; the filter passes run on one filter stream, frame after frame, each
+        // waiting for its own path pass.
+        const bool pipelined = frames_in_flight > 1 && path_pass;
+        int rc;
+        if (!pipelined && frames_in_flight > 1) { rc = quiesce(); if (rc) return rc; }
+        else if (w_or_h_changed(d->width, d->height)) { rc = quiesce(); if (rc) return rc; }
+        if (pipelined) {
+            if (!sv_stream) {
+                ATN_HIP(hipStreamCreateWithFlags(&sv_stream, hipStreamNonBlocking));
+                for (auto& e : sv_ev_prepare) ATN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            swap_bank(spare[frame_seq % (uint64_t)(frames_in_flight - 1)]);
+        }
+        frame_seq++;
+        hipStream_t fs = pipelined ? sv_stream : stream;       // the stream the filter passes run on
+        rc = ensure_frame(d->width, d->height, d->maxDepth);
         if (rc) return rc;
         rc = svgf_ensure(d->width, d->height, stages_host != nullptr);
         if (rc) return rc;
@@ -871,7 +907,10 @@ public:
         sf.pnd = sv_aov[prv][0].p; sf.pam = sv_aov[prv][1].p; sf.pcv = sv_cv[prv]; sf.pmt = sv_aov[prv][3].p;
         sf.cv_out = sv_spare;
         sf.atrous[0] = sv_atrous[0].p; sf.atrous[1] = sv_atrous[1].p;
-        sf.tmp = sv_tmp.p; sf.motion = sv_motion.p; sf.primary = sv_primary.p; sf.contribs = sv_contribs.p;
+        const int32_t slot = sv_slot;
+        sv_last_slot = slot;
+        sf.tmp = sv_tmp.p; sf.motion = sv_motion.p; sf.primary = sv_primary[slot].p; sf.contribs = sv_contribs[slot].p;
+        sf.g_nd = path_pass ? sv_gnd[slot].p : nullptr; sf.g_am = path_pass ? sv_gam[slot].p : nullptr;
         sf.out = sv_out.p; sf.stages = stages_host ? sv_stages.p : nullptr;
         mat_mul(sv_V2C, sv_W2V, sf.w2c);
         mat_mul(sv_V2C, sv_prevW2V, sf.prev_w2c);
@@ -880,51 +919,58 @@ public:
         sf.camera_distance = (float)d->height / (2.0f * std::tan(0.5f * camera.vfov));
         sf.compute_motion = compute_motion;
         SvgfShade sv{};
-        sv.nd = sf.nd; sv.am = sf.am; sv.primary = sf.primary;
+        sv.nd = sv_gnd[slot].p; sv.am = sv_gam[slot].p; sv.primary = sf.primary;
         sv.w2c3[0] = sf.w2c[12]; sv.w2c3[1] = sf.w2c[13]; sv.w2c3[2] = sf.w2c[14]; sv.w2c3[3] = sf.w2c[15];
 
         if (path_pass) {
+            if (pipelined && sv_prepare_recorded[slot]) ATN_HIP(hipStreamWaitEvent(stream, sv_ev_prepare[slot], 0));
             rc = run_paths<true>(d, fp, false, prof, sv, sf);
             if (rc) return rc;
+            if (pipelined) {
+                ATN_HIP(hipEventRecord(ev_gather, stream));         // this bank's "path pass done"
+                ATN_HIP(hipStreamWaitEvent(fs, ev_gather, 0));
+            }
         }
         const dim3 gp((((d->width + 7) / 8) + 7) / 8 * 8, (d->height + 31) / 32), tp(256);     // x: multiple of 8 (XCD strips)
-        prof_begin(prof, ATN_K_SVGF_PREPARE);
-        hipLaunchKernelGGL(k_svgf_prepare, gp, tp, 0, stream, sf);
+        prof_begin(prof, ATN_K_SVGF_PREPARE, fs);
+        hipLaunchKernelGGL(k_svgf_prepare, gp, tp, 0, fs, sf);
         prof_end(prof);
+        if (pipelined) { ATN_HIP(hipEventRecord(sv_ev_prepare[slot], fs)); sv_prepare_recorded[slot] = true; }    // the slot is free again
+        if (path_pass) sv_slot = 1 - sv_slot;
         if (d->frame > 0) {
-            prof_begin(prof, ATN_K_SVGF_TEMPORAL);
-            hipLaunchKernelGGL(k_svgf_temporal, gp, tp, 0, stream, sf, 0.98f, 0.05f);
+            prof_begin(prof, ATN_K_SVGF_TEMPORAL, fs);
+            hipLaunchKernelGGL(k_svgf_temporal, gp, tp, 0, fs, sf, 0.98f, 0.05f);
             if (sv_dilate_weight) {
                 ATN_HIP(sv_weight.resize((size_t)d->width * d->height));
-                hipLaunchKernelGGL(k_svgf_dilate_weight, gp, tp, 0, stream, sf, sv_weight.p);
-                hipLaunchKernelGGL(k_svgf_store_weight, gp, tp, 0, stream, sf, (const float*)sv_weight.p);
+                hipLaunchKernelGGL(k_svgf_dilate_weight, gp, tp, 0, fs, sf, sv_weight.p);
+                hipLaunchKernelGGL(k_svgf_store_weight, gp, tp, 0, fs, sf, (const float*)sv_weight.p);
             }
             prof_end(prof);
         }
         else if (sf.stages) {
             // frame 0: the temporal pass only re-puts the raw contribution (svgf.cpp:549-551)
-            ATN_HIP(hipMemcpyAsync(sf.stages + (size_t)d->width * d->height, sf.stages, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            ATN_HIP(hipMemcpyAsync(sf.stages + (size_t)d->width * d->height, sf.stages, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToDevice, fs));
         }
-        prof_begin(prof, ATN_K_SVGF_VARIANCE);
-        hipLaunchKernelGGL(k_svgf_variance, gp, tp, 0, stream, sf);
+        prof_begin(prof, ATN_K_SVGF_VARIANCE, fs);
+        hipLaunchKernelGGL(k_svgf_variance, gp, tp, 0, fs, sf);
         prof_end(prof);
         std::swap(sv_cv[cur], sv_spare);        // the pass wrote the new colour+variance into the spare buffer
         sf.cv = sv_cv[cur]; sf.cv_out = sv_spare;
         for (int32_t i = 0; i < sv_atrous_iters; i++) {
-            prof_begin(prof, ATN_K_SVGF_ATROUS);
-            hipLaunchKernelGGL(k_svgf_atrous, gp, tp, 0, stream, sf, i);
+            prof_begin(prof, ATN_K_SVGF_ATROUS, fs);
+            hipLaunchKernelGGL(k_svgf_atrous, gp, tp, 0, fs, sf, i);
             prof_end(prof);
         }
-        prof_begin(prof, ATN_K_SVGF_PREPARE);
-        hipLaunchKernelGGL(k_svgf_copy, gp, tp, 0, stream, sf);
+        prof_begin(prof, ATN_K_SVGF_PREPARE, fs);
+        hipLaunchKernelGGL(k_svgf_copy, gp, tp, 0, fs, sf);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
         sv_curr = 1 - sv_curr;
 
         const size_t n = (size_t)d->width * d->height;
-        if (out_host) ATN_HIP(hipMemcpyAsync(out_host, sv_out.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream));
-        if (stages_host) ATN_HIP(hipMemcpyAsync(stages_host, sv_stages.p, 3 * n * sizeof(float4), hipMemcpyDeviceToHost, stream));
-        if (out_host || stages_host) ATN_HIP(hipStreamSynchronize(stream));
+        if (out_host) ATN_HIP(hipMemcpyAsync(out_host, sv_out.p, n * sizeof(float4), hipMemcpyDeviceToHost, fs));
+        if (stages_host) ATN_HIP(hipMemcpyAsync(stages_host, sv_stages.p, 3 * n * sizeof(float4), hipMemcpyDeviceToHost, fs));
+        if (out_host || stages_host) ATN_HIP(hipStreamSynchronize(fs));
         return ATN_OK;
     }
 
@@ -1071,7 +1117,7 @@ int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n)
 
 int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)
 {
-    CTX_QUIET_OR_FAIL(ctx);
+    CTX_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.svgf_render(dst, compute_motion, out_host, stages_host); });
 }
 int atn_svgf_set_motion_depth(atn_ctx* ctx, const atn_vec4* motion_depth, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.svgf_set_motion_depth(motion_depth, n); }); }
@@ -1113,7 +1159,7 @@ int atn_svgf_upload(atn_ctx* ctx, int32_t which, int32_t width, int32_t height, 
     C_HIP(r, hipSetDevice(r.device));
     int rc = r.svgf_ensure(width, height, false);
     if (rc) return rc;
-    float4* p = r.svgf_buffer(which);
+    float4* p = r.svgf_buffer(which, true);
     if (!p) return r.fail(ATN_ERR_INVALID_ARG, "no such SVGF buffer");
     C_HIP(r, hipMemcpyAsync(p, host, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipStreamSynchronize(r.stream));

@@ -19,6 +19,8 @@ struct SvgfFrame {
     float4* atrous[2];      // atrous_clr_variance ping-pong
     float4* tmp;            // temporary_color_buffer
     float4* motion;         // motion_depth_buffer
+    const float4* g_nd;     // G-buffer staging written by the path pass (normal+depth, albedo+id); PrepareForDenoise's
+    const float4* g_am;     // kernel moves it into the current AOV set.  null = the caller uploaded the AOVs itself.
     float4* primary;        // world position of the bounce-0 hit, w = 1 (0 on a miss): input of the motion pass
     float4* contribs;       // Path.contrib as vec4: contrib.xyz, samples
     float4* out;            // what dst.buffer holds when OnRender returns
@@ -93,6 +95,13 @@ __global__ void __launch_bounds__(256) k_svgf_prepare(SvgfFrame sf)
     int32_t ix, iy;
     if (!svgf_pixel(sf, ix, iy)) return;
     const int32_t idx = ix + iy * sf.width;
+    if (sf.g_nd) {
+        // The path pass writes its AOVs (FillBasicAOVs, every pixel every frame) into a staging pair instead of the
+        // current AOV set, so that it never touches planes a filter pass of the PREVIOUS frame may still read: with
+        // frames in flight it runs while that frame is being filtered.  Same values, one extra 32-byte move per pixel.
+        sf.nd[idx] = sf.g_nd[idx];
+        sf.am[idx] = sf.g_am[idx];
+    }
     const float4 c = sf.contribs[idx];
     const float4 contrib = div4(c, c.w);
     if (sf.frame == 0) {

@@ -226,8 +226,9 @@ def main():
     r.updateCamera(camera)
     r.initSampler(W, H, 0)
     r.setScreenShard(rank, world)
-    if not args.svgf:
-        r.set_frames_in_flight(args.frames_in_flight)
+    if args.svgf:
+        args.frames_in_flight = min(args.frames_in_flight, 2)   # SVGF hands a frame over through two slots: 2 in flight is its depth
+    r.set_frames_in_flight(args.frames_in_flight)
 
     # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
     # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
@@ -336,8 +337,7 @@ def main():
     r.synchronize()
     ktimes_excl = r.kernel_times()
     r.set_path_batches(3)
-    if not args.svgf:
-        r.set_frames_in_flight(args.frames_in_flight)
+    r.set_frames_in_flight(args.frames_in_flight)      # (SVGF: the path pass of frame f + 1 overlaps the filters of frame f)
 
     frames_prof = args.steps
     kernel_count_batches = max(1, round(ktimes["gen_path"][1] / max(frames_prof * spp, 1)))
@@ -360,7 +360,7 @@ def main():
     # duration says nothing about how hard IT drives the machine; the roofline fractions use the duration of the same
     # launch with one kernel in flight at a time (the isolated pass above -- also the mode the PMC passes run in, the
     # profiler serialises dispatches), the overlapped duration is reported next to it.
-    in_flight = 1 if args.svgf else args.frames_in_flight
+    in_flight = args.frames_in_flight
     overlapped = kernel_count_batches > 1 or in_flight > 1
     iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
     roof_ms = iso_ms if overlapped else avg_launch_ms
@@ -503,7 +503,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
-                       "frames_in_flight": 1 if args.svgf else args.frames_in_flight,
+                       "frames_in_flight": args.frames_in_flight,
                        "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"]))},
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / args.steps), 2),
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},

@@ -266,3 +266,35 @@ def test_svgf_full_size_properties_1080p(gpu, orc, sponza):
         a = np.nan_to_num(a)
         return np.abs(4 * a[1:-1, 1:-1] - a[:-2, 1:-1] - a[2:, 1:-1] - a[1:-1, :-2] - a[1:-1, 2:]).mean()
     assert rough(out[..., :3]) < 0.5 * rough(raw)
+
+
+def test_svgf_frames_in_flight_equal_serial(sponza):
+    """Pipelined SVGF frames (atn_set_frames_in_flight > 1: path pass of frame f + 1 on the next bank while the filters of
+    frame f run on the filter stream, ordered by the temporal pass) give the same filtered frames and the same history."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene.camera import create_camera
+    fs, cam = sponza
+    w, h = 320, 180
+
+    def run(in_flight):
+        r = PathTracing(0)
+        try:
+            r.UpdateSceneData(fs)
+            r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+            r.initSampler(w, h, 0)
+            r.set_frames_in_flight(in_flight)
+            outs = []
+            for f in range(6):
+                img = r.svgf_render(w, h, 4, 3, frame=f, compute_motion=True, download=(f in (2, 5)))
+                if img is not None:
+                    outs.append(img.copy())
+            hist = r.svgf_buffer("prev_moment_temporalweight").copy()
+            return outs, hist
+        finally:
+            r.close()
+    want, want_hist = run(1)
+    for n in (2, 3):
+        got, hist = run(n)
+        for a, b in zip(got, want):
+            assert a.tobytes() == b.tobytes(), n
+        assert hist.tobytes() == want_hist.tobytes(), n

@@ -527,7 +527,7 @@ public:
     void launch_trace(const PathBuffers& pb, uint32_t grid, bool count, int32_t b, hipStream_t stream)
     {
         const dim3 g(grid), t(use_refill ? (uint32_t)kTraceBlock : 256u);
-        const uint32_t lds = use_refill ? scene.treelet_bytes : 0u;
+        const uint32_t lds = (use_refill && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
         if (SHADOW) {
             if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, t, lds, stream, pb, scene, b); }
             else { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, t, lds, stream, pb, scene, b); }
@@ -649,7 +649,7 @@ public:
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
                         prof_begin(prof, ATN_K_TRACE_FUSED, st);
                         const dim3 gr(use_refill ? g_fused : g_fused * (256u / simple_block)), tb(use_refill ? (uint32_t)kTraceBlock : simple_block);
-                        const uint32_t lds = use_refill ? scene.treelet_bytes : 0u;
+                        const uint32_t lds = (use_refill && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
                         if (use_refill) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
@@ -1380,7 +1380,7 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
         const bool probe_refill = r.flavour_forced ? r.use_refill : r.tree_is_deep;
         r.use_refill = probe_refill;        // trace_grid sizes the launch for it
         const dim3 g(r.trace_grid(n)), t(probe_refill ? (uint32_t)atn::kTraceBlock : 256u);
-        const uint32_t lds = probe_refill ? r.scene.treelet_bytes : 0u;
+        const uint32_t lds = (probe_refill && ATN_TREELET_LDS) ? r.scene.treelet_bytes : 0u;
         const atn_ray* rp = rays.p;
         if (stats_out) {
             if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);

@@ -274,9 +274,11 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
 {
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
-        const uint32_t n16 = sc.treelet_bytes / 16u;
-        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
-        __syncthreads();
+        if (ATN_TREELET_LDS) {
+            const uint32_t n16 = sc.treelet_bytes / 16u;
+            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
+            __syncthreads();
+        }
         trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {

@@ -146,6 +146,9 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
     w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
 }
 
+#ifndef ATN_TREELET_LDS
+#define ATN_TREELET_LDS 1       /* 0: keep the treelet REGION (hot records contiguous at the head of the image) but read it from global memory */
+#endif
 #ifndef ATN_INNER_BURST
 #define ATN_INNER_BURST 4
 #endif
@@ -428,7 +431,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        walk_iteration<COUNT, (kTreeletMaxBytes > 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
+        walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
     }
 }
 

@@ -287,6 +287,34 @@ class SceneBuilder:
         hdr, mtrl_names, nodes = read_sbvh(path)
         self.blas[obj_id] = ("imported", nodes, hdr)
 
+    def export_sbvh(self, obj_id, path, lib=None):
+        """sbvh::exportTree for one polygon object (accelerator/sbvh.cpp:1237-1338): the object's BLAS (the imported one,
+        or the SAH tree atns_build_blas builds) with object-local triangle ids, in the reference's .sbvh format."""
+        lib = lib or hostlib()
+        spec = self.blas.get(obj_id)
+        if spec is not None and spec[0] == "imported":
+            hdr = spec[2]
+            return write_sbvh(path, spec[1], hdr["boxmin"], hdr["boxmax"], hdr["maxDepth"], None, hdr["version"])
+        o = self.objects[obj_id]
+        if o["type"] != L.OBJ_POLYGONS:
+            raise ValueError("only polygon objects carry a bottom-level tree")
+        tri_ids = [t for m in o["meshes"] for t in m["tris"]]
+        pos = np.asarray(self.pos, F32).reshape(-1, 4)
+        tris = np.zeros(len(self.tris), L.TRIANGLE_PARAM)
+        tris["idx"] = np.asarray([t["idx"] for t in self.tris], np.int32)
+        ids = np.asarray(tri_ids, np.uint32)
+        out = C.c_void_p(); cnt = C.c_uint32()
+        bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
+        rc = lib.atns_build_blas(L.ptr(pos), L.ptr(tris), L.ptr(ids), len(ids), C.byref(out), C.byref(cnt), bmin, bmax)
+        if rc != 0:
+            raise RuntimeError("atns_build_blas failed: %d" % rc)
+        nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
+        lib.atns_free(out)
+        first = min(tri_ids)
+        leaf = nodes["f0"] >= 0
+        nodes["f1"][leaf] -= F32(first)         # the file holds object-local ids; import adds the offset back
+        return write_sbvh(path, nodes, list(bmin), list(bmax))
+
     # ---------------------------------------------------------------- lights
     def add_area_light(self, instance_id, color, intensity, scale=1.0):
         l = np.zeros((), L.LIGHT_PARAM)
@@ -513,3 +541,48 @@ def read_sbvh(path):
     assert off + node_num * 48 == len(buf), "trailing bytes in sbvh file"
     hdr = dict(version=ver, nodeNum=node_num, maxDepth=max_depth, boxmin=box[:3], boxmax=box[3:])
     return hdr, names, nodes
+
+
+def threaded_depth(nodes):
+    """Depth of a threaded tree, root = depth 0 as sbvh's m_maxDepth counts it: an inner node's left child is its hit link, the right child is the
+    left child's miss link (sbvh::convert / registerThreadedBvh order, accelerator/sbvh.cpp:1085-1180)."""
+    n = len(nodes)
+    if n == 0:
+        return 0
+    depth = np.zeros(n, np.int32)
+    depth[0] = 1                            # stored +1 so that 0 means 'not reached'
+    hit = nodes["hit"].astype(np.int64)
+    miss = nodes["miss"].astype(np.int64)
+    leaf = nodes["f0"] >= 0
+    for i in range(n):                      # children always follow their parent in the array
+        if leaf[i] or depth[i] == 0:
+            continue
+        l = hit[i]
+        if 0 <= l < n:
+            depth[l] = depth[i] + 1
+            r = miss[l]
+            if 0 <= r < n and r != miss[i]:
+                depth[r] = depth[i] + 1
+    return int(depth.max()) - 1
+
+
+def write_sbvh(path, nodes, boxmin, boxmax, max_depth=None, mtrl_names=None, version=0x01000000):
+    """Inverse of read_sbvh: the file sbvh::exportTree writes (accelerator/sbvh.cpp:1220-1338) -- SbvhFileHeader,
+    the voxel-material table (id, 4-byte-aligned length, zero-padded name) and ThreadedSbvhNode[].  A file read with
+    read_sbvh and written back is byte-identical; a tree built by atns_build_blas exported this way loads in the
+    reference through PolygonObject::importInternalAccelTree."""
+    nodes = np.ascontiguousarray(nodes, L.BVH_NODE)
+    if max_depth is None:
+        max_depth = threaded_depth(nodes)
+    mtrl_names = mtrl_names or {}
+    out = bytearray()
+    out += struct.pack("<4sIIII", b"SBVH", version, len(nodes), int(max_depth), len(mtrl_names))
+    out += struct.pack("<6f", *[float(x) for x in boxmin], *[float(x) for x in boxmax])
+    for mid in sorted(mtrl_names):          # std::map iteration order
+        name = mtrl_names[mid].encode()
+        aligned = (len(name) + 3) // 4 * 4
+        out += struct.pack("<ii", mid, aligned) + name + b"\0" * (aligned - len(name))
+    out += nodes.tobytes()
+    with open(path, "wb") as f:
+        f.write(out)
+    return len(out)

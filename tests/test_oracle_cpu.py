@@ -51,6 +51,45 @@ def test_sbvh_fixture_from_reference_asset():
     assert np.allclose(hdr["boxmin"], nodes["boxmin"][0]) and np.allclose(hdr["boxmax"], nodes["boxmax"][0])
 
 
+def test_sbvh_export_round_trips(tmp_path):
+    """write_sbvh is the inverse of read_sbvh: the reference-written asset comes back byte for byte
+    (sbvh::exportTree's layout, accelerator/sbvh.cpp:1237-1338), and threaded_depth reproduces the header's maxDepth."""
+    from aten_amd.scene.builder import read_sbvh, write_sbvh, threaded_depth
+    src = os.path.join(ROOT, "assets", "sponza", "sponza_lod.sbvh")
+    hdr, names, nodes = read_sbvh(src)
+    assert threaded_depth(nodes) == hdr["maxDepth"]
+    dst = str(tmp_path / "copy.sbvh")
+    write_sbvh(dst, nodes, hdr["boxmin"], hdr["boxmax"], None, names, hdr["version"])
+    assert open(src, "rb").read() == open(dst, "rb").read()
+
+
+def test_sbvh_export_of_built_tree_imports_identically(tmp_path):
+    """A tree built by atns_build_blas, exported with object-local triangle ids and imported again through
+    PolygonObject::importInternalAccelTree's path gives the same flattened scene as building it in place."""
+    from aten_amd.scene.builder import SceneBuilder, read_sbvh
+    from aten_amd import layout as L
+    sb = SceneBuilder()
+    m = sb.add_material("m", L.MTRL_DIFFUSE, (0.5, 0.5, 0.5))
+    rng = np.random.default_rng(3)
+    # a first small object so that the exported object's global triangle ids do not start at 0
+    sb.create_instance(sb.add_mesh("pad", rng.random((12, 3)).astype(np.float32), np.arange(12).reshape(4, 3), m))
+    c = rng.random((300, 1, 3)).astype(np.float32) * 4
+    p = (c + rng.random((300, 3, 3)).astype(np.float32) * 0.3).reshape(-1, 3)
+    big = sb.add_mesh("soup", p, np.arange(900).reshape(300, 3), m)
+    sb.create_instance(big)
+    built = sb.build()
+    path = str(tmp_path / "obj.sbvh")
+    sb.export_sbvh(big, path)
+    hdr, names, nodes = read_sbvh(path)
+    assert names == {} and hdr["version"] == 0x01000000
+    leaf = nodes["f0"] >= 0
+    assert nodes["f1"][leaf].min() == 0
+    sb.import_sbvh(big, path)
+    again = sb.build()
+    for a, b in zip(built.arrays["bvh_lists"], again.arrays["bvh_lists"]):
+        assert a.tobytes() == b.tobytes()
+
+
 def test_compaction_kat_data():
     """The commented self-test in src/libidaten/kernel/StreamCompaction.cu:318-400 scans
     f = {3,1,7,0,4,1,6,3,...}; the compaction contract on flags>0 is ascending indices."""

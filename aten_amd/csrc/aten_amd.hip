@@ -17,6 +17,7 @@
 #include "../../include/aten_amd.h"
 #include "device/kernels.hpp"
 #include "device/svgf.hpp"
+#include "device/lbvh.hpp"
 #include "host/scene_upload.hpp"
 #include "host/ibl_precompute.hpp"
 
@@ -85,6 +86,17 @@ public:
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
     uint32_t top_base = 0, n_host_matrices = 0;
+    std::vector<uint32_t> list_base, list_bytes, list_tri_leaves, list_inner;   // region of every list in the node image
+    uint32_t n_scene_tris = 0, n_scene_vtx = 0, n_scene_mtrls = 0;
+
+    // LBVH rebuild scratch (atn_lbvh_*), grown on demand
+    struct LbvhScratch {
+        DevBuf<uint32_t> codes[2], indices[2], counts, arrived, offs;
+        DevBuf<int32_t> left, right, parent, first;
+        DevBuf<atn_bvh_node> ref_nodes;
+        DevBuf<atn_triangle_param> tris;     // atn_lbvh_build's own inputs
+        DevBuf<float4> vtx;
+    } lb;
     uint64_t n_bottom_nodes = 0;
     atn_camera_param camera{};
 
@@ -279,6 +291,8 @@ public:
             if (orc) return orc;
         }
         list_root_link = img.list_root_link;
+        list_base = img.list_root; list_bytes = img.list_bytes; list_tri_leaves = img.list_tri_leaves; list_inner = img.list_inner;
+        n_scene_tris = s->n_triangles; n_scene_vtx = s->n_vertices; n_scene_mtrls = s->n_materials;
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
         n_bottom_nodes = img.n_nodes - s->bvh_lists[0].count;
         n_host_matrices = s->n_matrices;
@@ -391,6 +405,136 @@ public:
         scene.nodes = nodes.p; scene.objects = objects.p; scene.matrices = matrices.p;
         tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;
         if (!flavour_forced) use_refill = tree_is_deep;
+        return ATN_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // Dynamic geometry: ≙ the per-tick sequence of src/deformation_renderer/main.cpp:636-710
+    //   skinning -> LBVHBuilder::build into the renderer's node list -> Renderer::updateGeometry -> Renderer::updateBVH.
+
+    // ≙ idaten::Renderer::updateGeometry, src/libidaten/kernel/renderer.cpp:155-215: overwrite a range of the scene's
+    // vertices and triangles.  (The BVH records of lists over these triangles hold hoisted vertex data: rebuild them.)
+    int updateGeometry(const atn_vec4* pos, const atn_vec4* nml, uint32_t n_vtx, uint32_t vtx_offset,
+                       const atn_triangle_param* tr, uint32_t n_tr, uint32_t tri_offset)
+    {
+        if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+        if ((n_vtx && !pos && !nml) || (n_tr && !tr)) return fail(ATN_ERR_INVALID_ARG, "null geometry array");
+        if ((uint64_t)vtx_offset + n_vtx > n_scene_vtx) return fail(ATN_ERR_INVALID_ARG, "vertex range outside the uploaded scene");
+        if ((uint64_t)tri_offset + n_tr > n_scene_tris) return fail(ATN_ERR_INVALID_ARG, "triangle range outside the uploaded scene");
+        for (uint32_t i = 0; i < n_tr; i++) {
+            if (tr[i].mtrlid >= 0 && (uint32_t)tr[i].mtrlid >= n_scene_mtrls) return fail(ATN_ERR_UNSUPPORTED, "triangle material id out of range");
+            for (int v = 0; v < 3; v++)
+                if (tr[i].idx[v] < 0 || (uint32_t)tr[i].idx[v] >= n_scene_vtx) return fail(ATN_ERR_UNSUPPORTED, "triangle vertex index out of range");
+        }
+        ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
+        if (n_vtx && pos) ATN_HIP(hipMemcpyAsync(vtx_pos.p + vtx_offset, pos, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
+        if (n_vtx && nml) ATN_HIP(hipMemcpyAsync(vtx_nml.p + vtx_offset, nml, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
+        if (n_tr) ATN_HIP(hipMemcpyAsync(tris.p + tri_offset, tr, (size_t)n_tr * sizeof(atn_triangle_param), hipMemcpyHostToDevice, stream));
+        ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;
+    }
+
+    int lbvh_reserve(uint32_t n)
+    {
+        const uint32_t nb = (n + kSortTile - 1) / kSortTile, nn = 2 * n - 1;
+        for (int k = 0; k < 2; k++) {
+            if (lb.codes[k].n < n) ATN_HIP(lb.codes[k].resize(n));
+            if (lb.indices[k].n < n) ATN_HIP(lb.indices[k].resize(n));
+        }
+        if (lb.counts.n < 256u * nb) ATN_HIP(lb.counts.resize(256u * nb));
+        if (lb.arrived.n < n) ATN_HIP(lb.arrived.resize(n));
+        if (lb.offs.n < nn) ATN_HIP(lb.offs.resize(nn));
+        if (lb.left.n < nn) ATN_HIP(lb.left.resize(nn));
+        if (lb.right.n < nn) ATN_HIP(lb.right.resize(nn));
+        if (lb.parent.n < nn) ATN_HIP(lb.parent.resize(nn));
+        if (lb.first.n < n) ATN_HIP(lb.first.resize(n));
+        if (lb.ref_nodes.n < nn) ATN_HIP(lb.ref_nodes.resize(nn));
+        return ATN_OK;
+    }
+
+    // Morton codes -> sort -> hierarchy -> links -> boxes, all enqueued on `stream`; the tree is left in lb.ref_nodes in
+    // the reference's node order.  `tr` points at the first of the n triangles, `vtx` at the vertex array.
+    int lbvh_enqueue(const atn_triangle_param* tr, uint32_t n, int32_t tri_id_offset, const float* bmin, const float* bmax,
+                     const float4* vtx, int32_t vtx_offset)
+    {
+        { int r = lbvh_reserve(n); if (r) return r; }
+        const uint32_t nb = (n + kSortTile - 1) / kSortTile, nn = 2 * n - 1;
+        const dim3 b256(256);
+        f3 mn, mx;
+        mn.x = bmin[0]; mn.y = bmin[1]; mn.z = bmin[2]; mx.x = bmax[0]; mx.y = bmax[1]; mx.z = bmax[2];
+        hipLaunchKernelGGL(k_lbvh_morton, dim3((n + 255) / 256), b256, 0, stream, tr, vtx, vtx_offset, n, mn, mx, lb.codes[0].p, lb.indices[0].p);
+        for (uint32_t pass = 0; pass < 4; pass++) {
+            const int in = pass & 1, out = in ^ 1;
+            hipLaunchKernelGGL(k_radix_count, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, n, pass * 8u, lb.counts.p, nb);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, lb.counts.p, 256u * nb);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, (const uint32_t*)lb.indices[in].p,
+                               lb.codes[out].p, lb.indices[out].p, n, pass * 8u, (const uint32_t*)lb.counts.p, nb);
+        }
+        LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p };
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), b256, 0, stream, (const uint32_t*)lb.codes[0].p, n, t);
+        hipLaunchKernelGGL(k_lbvh_order, dim3((nn + 255) / 256), b256, 0, stream, n, tri_id_offset, t, (const uint32_t*)lb.indices[0].p, lb.ref_nodes.p);
+        ATN_HIP(hipMemsetAsync(lb.arrived.p, 0, (size_t)n * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3((n + 255) / 256), b256, 0, stream, n, t, (const uint32_t*)lb.indices[0].p, tr, vtx, vtx_offset,
+                           lb.ref_nodes.p, lb.arrived.p);
+        ATN_HIP(hipGetLastError());
+        return ATN_OK;
+    }
+
+    // ≙ idaten::LBVHBuilder::build(dst, std::vector<TriangleParameter>&, ..., threadedBvhNodes), LBVHBuilder.cu:812-833:
+    // host arrays in, the ThreadedBvhNode array out, in the reference's node order.
+    int lbvh_build(const atn_triangle_param* tr, uint32_t n, int32_t tri_id_offset, const float* bmin, const float* bmax,
+                   const atn_vec4* vtx, uint32_t n_vtx, int32_t vtx_offset, atn_bvh_node* out, uint32_t* out_codes, uint32_t* out_indices)
+    {
+        if (!tr || !vtx || !out || !bmin || !bmax) return fail(ATN_ERR_INVALID_ARG, "null argument");
+        if (n < 2) return fail(ATN_ERR_INVALID_ARG, "an LBVH needs at least two triangles");
+        if (n > kLbvhMaxTris) return fail(ATN_ERR_UNSUPPORTED, "too many triangles: node indices are stored as floats");
+        for (uint32_t i = 0; i < n; i++)
+            for (int v = 0; v < 3; v++) {
+                const int64_t j = (int64_t)tr[i].idx[v] + vtx_offset;
+                if (j < 0 || j >= (int64_t)n_vtx) return fail(ATN_ERR_INVALID_ARG, "triangle vertex index out of range");
+            }
+        ATN_HIP(hipSetDevice(device));
+        ATN_HIP(hipStreamSynchronize(stream));
+        if (lb.tris.n < n) ATN_HIP(lb.tris.resize(n));
+        if (lb.vtx.n < n_vtx) ATN_HIP(lb.vtx.resize(n_vtx));
+        ATN_HIP(hipMemcpyAsync(lb.tris.p, tr, (size_t)n * sizeof(atn_triangle_param), hipMemcpyHostToDevice, stream));
+        ATN_HIP(hipMemcpyAsync(lb.vtx.p, vtx, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
+        { int r = lbvh_enqueue(lb.tris.p, n, tri_id_offset, bmin, bmax, lb.vtx.p, vtx_offset); if (r) return r; }
+        ATN_HIP(hipMemcpyAsync(out, lb.ref_nodes.p, (size_t)(2 * n - 1) * sizeof(atn_bvh_node), hipMemcpyDeviceToHost, stream));
+        if (out_codes) ATN_HIP(hipMemcpyAsync(out_codes, lb.codes[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        if (out_indices) ATN_HIP(hipMemcpyAsync(out_indices, lb.indices[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;
+    }
+
+    // ≙ lbvh_.build(nodes[deformPos], tris, tri_offset_, sceneBbox, vtxPos, ...) of deformation_renderer/main.cpp:686-693:
+    // rebuild bottom-level list `list` as an LBVH over the scene's triangles [tri_offset, tri_offset + n) as they are on
+    // the device NOW, and write its records over the list's region of the node image.  The region keeps its size: an
+    // LBVH over n triangles is n - 1 inner records and n triangle leaves, so the list must have been uploaded with one
+    // leaf per triangle (any full binary tree over the n triangles, e.g. atns_build_blas's).
+    int lbvh_rebuild_list(uint32_t list, uint32_t tri_offset, uint32_t n, const float* bmin, const float* bmax, bool sync)
+    {
+        if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+        if (!bmin || !bmax) return fail(ATN_ERR_INVALID_ARG, "null bounding box");
+        if (list == 0 || list >= list_base.size()) return fail(ATN_ERR_INVALID_ARG, "not a bottom-level BVH list");
+        if (n < 2) return fail(ATN_ERR_INVALID_ARG, "an LBVH needs at least two triangles");
+        if (n > kLbvhMaxTris) return fail(ATN_ERR_UNSUPPORTED, "too many triangles: node indices are stored as floats");
+        if ((uint64_t)tri_offset + n > n_scene_tris) return fail(ATN_ERR_INVALID_ARG, "triangle range outside the uploaded scene");
+        if (scene.treelet_bytes) return fail(ATN_ERR_UNSUPPORTED, "the node image has a treelet region (ATN_TREELET_BYTES > 0): lists cannot be rebuilt in place");
+        if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
+            return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
+        ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
+        { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0); if (r) return r; }
+        const uint32_t nn = 2 * n - 1;
+        LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p };
+        hipLaunchKernelGGL(k_lbvh_layout, dim3((nn + 255) / 256), dim3(256), 0, stream, n, t, list_base[list], lb.offs.p);
+        hipLaunchKernelGGL(k_lbvh_emit, dim3((nn + 255) / 256), dim3(256), 0, stream, n, (const atn_bvh_node*)lb.ref_nodes.p, (const uint32_t*)lb.offs.p,
+                           (const atn_triangle_param*)tris.p, (const float4*)vtx_pos.p, nodes.p);
+        ATN_HIP(hipGetLastError());
+        // the root is node 0 = an inner record at the start of the region: the TLAS leaves' root link stays valid
+        if (sync) ATN_HIP(hipStreamSynchronize(stream));
         return ATN_OK;
     }
 
@@ -1061,6 +1205,34 @@ int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_ob
     CTX_QUIET_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); });
 }
+int atn_update_geometry(atn_ctx* ctx, const atn_vec4* vtx_pos, const atn_vec4* vtx_nml, uint32_t n_vertices, uint32_t vtx_offset,
+                        const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.updateGeometry(vtx_pos, vtx_nml, n_vertices, vtx_offset, triangles, n_triangles, tri_offset); });
+}
+int atn_lbvh_rebuild_list(atn_ctx* ctx, uint32_t list_index, uint32_t tri_offset, uint32_t n_triangles, const float* bbox_min, const float* bbox_max)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, true); });
+}
+int atn_lbvh_build(atn_ctx* ctx, const atn_triangle_param* triangles, uint32_t n_triangles, int32_t tri_id_offset,
+                   const float* bbox_min, const float* bbox_max, const atn_vec4* vtx_pos, uint32_t n_vertices, int32_t vtx_offset,
+                   atn_bvh_node* out_nodes, uint32_t* out_sorted_codes, uint32_t* out_sorted_indices)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.lbvh_build(triangles, n_triangles, tri_id_offset, bbox_min, bbox_max, vtx_pos, n_vertices, vtx_offset,
+                                                       out_nodes, out_sorted_codes, out_sorted_indices); });
+}
+int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void** triangles)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    if (!ctx->r.has_scene) return ctx->r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    if (vtx_pos) *vtx_pos = ctx->r.vtx_pos.p;
+    if (vtx_nml) *vtx_nml = ctx->r.vtx_nml.p;
+    if (triangles) *triangles = ctx->r.tris.p;
+    return ATN_OK;
+}
 int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.initSampler(w, h, seed); }); }
 int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.setRandom(seeds, n); }); }
 
@@ -1284,6 +1456,23 @@ int atn_mgpu_update_tlas(atn_mgpu* mg, const atn_object_param* objects, uint32_t
 {
     MG_OR_FAIL(mg);
     return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) { return mg->m.shard[i]->updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); }); });
+}
+int atn_mgpu_update_geometry(atn_mgpu* mg, const atn_vec4* vtx_pos, const atn_vec4* vtx_nml, uint32_t n_vertices, uint32_t vtx_offset,
+                             const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) {
+        PathTracing& r = *mg->m.shard[i];
+        if (hipSetDevice(r.device) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipSetDevice");
+        return r.updateGeometry(vtx_pos, vtx_nml, n_vertices, vtx_offset, triangles, n_triangles, tri_offset); }); });
+}
+int atn_mgpu_lbvh_rebuild_list(atn_mgpu* mg, uint32_t list_index, uint32_t tri_offset, uint32_t n_triangles, const float* bbox_min, const float* bbox_max)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) {
+        PathTracing& r = *mg->m.shard[i];
+        if (hipSetDevice(r.device) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipSetDevice");
+        return r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, true); }); });
 }
 int atn_mgpu_update_camera(atn_mgpu* mg, const atn_camera_param* camera)
 {

@@ -15,6 +15,8 @@ struct HostSceneImage {
     uint64_t n_nodes = 0;
     std::vector<uint32_t> list_root;    // byte offset of each list's first non-treelet record
     std::vector<int32_t> list_root_link; // typed link of each list's root
+    std::vector<uint32_t> list_bytes;   // bytes of each list's contiguous region starting at list_root (treelet records excluded)
+    std::vector<uint32_t> list_tri_leaves, list_inner;  // record counts of each list
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
     std::vector<atn_object_param> objects;
@@ -254,15 +256,21 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             if (lay[k].in_treelet[j]) { lay[k].offset[j] = (uint32_t)off; off += kInnerBytes; }
     const uint64_t treelet_bytes = off;
     img.list_root.assign(nl, 0);
+    img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0);
     for (uint32_t kk = 1; kk <= nl; kk++) {
         const uint32_t k = kk % nl;         // 1, 2, ..., nl-1, 0
         img.list_root[k] = (uint32_t)off;
+        for (uint32_t j = 0; j < lay[k].order.size(); j++) {
+            if (lay[k].kind[j] == KIND_TRI) img.list_tri_leaves[k]++;
+            else if (lay[k].kind[j] == KIND_INNER) img.list_inner[k]++;
+        }
         for (uint32_t j = 0; j < lay[k].order.size(); j++) {
             if (lay[k].in_treelet[j]) continue;
             if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
             lay[k].offset[j] = (uint32_t)off;
             off += record_bytes(lay[k].kind[j]);
         }
+        img.list_bytes[k] = (uint32_t)(off - img.list_root[k]);
     }
     if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
     img.nodes.assign((size_t)(off / 16), make_float4(0, 0, 0, 0));

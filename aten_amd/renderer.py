@@ -58,6 +58,41 @@ class PathTracing:
         self._check(self._l.atn_update_tlas(self._ctx, objs.ctypes.data, len(objs), mtx.ctypes.data if len(mtx) else None,
                                             len(mtx), top.ctypes.data, len(top)))
 
+    # ---- dynamic geometry (the reference's deformation renderer, src/deformation_renderer/main.cpp:636-710)
+    def updateGeometry(self, vtx_pos=None, vtx_nml=None, vtx_offset=0, triangles=None, tri_offset=0):
+        """idaten::Renderer::updateGeometry (renderer.cpp:155-215): overwrite a vertex / triangle range of the scene."""
+        from . import layout as L
+        pos = None if vtx_pos is None else np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
+        nml = None if vtx_nml is None else np.ascontiguousarray(vtx_nml, np.float32).reshape(-1, 4)
+        nv = len(pos) if pos is not None else (len(nml) if nml is not None else 0)
+        tr = None if triangles is None else np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
+        self._check(self._l.atn_update_geometry(self._ctx, pos.ctypes.data if pos is not None else None, nml.ctypes.data if nml is not None else None,
+                               nv, vtx_offset, tr.ctypes.data if tr is not None else None, len(tr) if tr is not None else 0, tri_offset))
+
+    def lbvh_rebuild_list(self, list_index, tri_offset, n_triangles, bbox_min, bbox_max):
+        """idaten::LBVHBuilder::build into the renderer's node list (LBVHBuilder.cu:700-810), on the device."""
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        self._check(self._l.atn_lbvh_rebuild_list(self._ctx, list_index, tri_offset, n_triangles, f3(bbox_min), f3(bbox_max)))
+
+    def lbvh_build(self, triangles, bbox_min, bbox_max, vtx_pos, tri_id_offset=0, vtx_offset=0, with_keys=False):
+        """LBVHBuilder::build(..., threadedBvhNodes) (LBVHBuilder.cu:812-833): ThreadedBvhNode[2 n - 1] in the reference's order."""
+        from . import layout as L
+        tr = np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
+        pos = np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
+        n = len(tr)
+        out = np.zeros(max(2 * n - 1, 1), L.BVH_NODE)
+        codes = np.zeros(max(n, 1), np.uint32); idx = np.zeros(max(n, 1), np.uint32)
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        self._check(self._l.atn_lbvh_build(self._ctx, tr.ctypes.data, n, tri_id_offset, f3(bbox_min), f3(bbox_max), pos.ctypes.data, len(pos),
+                                           vtx_offset, out.ctypes.data, codes.ctypes.data, idx.ctypes.data))
+        return (out, codes, idx) if with_keys else out
+
+    def scene_device_arrays(self):
+        """(vtx_pos, vtx_nml, triangles) device addresses of the uploaded scene."""
+        p = [C.c_void_p() for _ in range(3)]
+        self._check(self._l.atn_scene_device_arrays(self._ctx, C.byref(p[0]), C.byref(p[1]), C.byref(p[2])))
+        return tuple(x.value for x in p)
+
     def updateCamera(self, cam):
         self._check(self._l.atn_update_camera(self._ctx, cam.ctypes.data))
 
@@ -291,6 +326,22 @@ class MultiGpuPathTracing:
         objs = np.ascontiguousarray(a["objects"]); mtx = np.ascontiguousarray(a["matrices"]); top = np.ascontiguousarray(a["bvh_lists"][0])
         self._check(self._l.atn_mgpu_update_tlas(self._mg, objs.ctypes.data, len(objs), mtx.ctypes.data if len(mtx) else None,
                                                  len(mtx), top.ctypes.data, len(top)))
+
+    # ---- dynamic geometry (the reference's deformation renderer, src/deformation_renderer/main.cpp:636-710)
+    def updateGeometry(self, vtx_pos=None, vtx_nml=None, vtx_offset=0, triangles=None, tri_offset=0):
+        """idaten::Renderer::updateGeometry (renderer.cpp:155-215): overwrite a vertex / triangle range of the scene."""
+        from . import layout as L
+        pos = None if vtx_pos is None else np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
+        nml = None if vtx_nml is None else np.ascontiguousarray(vtx_nml, np.float32).reshape(-1, 4)
+        nv = len(pos) if pos is not None else (len(nml) if nml is not None else 0)
+        tr = None if triangles is None else np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
+        self._check(self._l.atn_mgpu_update_geometry(self._mg, pos.ctypes.data if pos is not None else None, nml.ctypes.data if nml is not None else None,
+                               nv, vtx_offset, tr.ctypes.data if tr is not None else None, len(tr) if tr is not None else 0, tri_offset))
+
+    def lbvh_rebuild_list(self, list_index, tri_offset, n_triangles, bbox_min, bbox_max):
+        """idaten::LBVHBuilder::build into the renderer's node list (LBVHBuilder.cu:700-810), on the device."""
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        self._check(self._l.atn_mgpu_lbvh_rebuild_list(self._mg, list_index, tri_offset, n_triangles, f3(bbox_min), f3(bbox_max)))
 
     def updateCamera(self, cam):
         self._check(self._l.atn_mgpu_update_camera(self._mg, cam.ctypes.data))

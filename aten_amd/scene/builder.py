@@ -43,6 +43,13 @@ class FlatScene:
     def ref(self):
         return C.byref(self.desc)
 
+    def replace_bvh_list(self, k, nodes):
+        """Swap node list k (e.g. for a tree built elsewhere over the same triangles)."""
+        nodes = np.ascontiguousarray(nodes, L.BVH_NODE)
+        self.arrays["bvh_lists"][k] = nodes
+        self.lists[k].nodes = nodes.ctypes.data
+        self.lists[k].count = len(nodes)
+
 
 class SceneBuilder:
     def __init__(self):
@@ -264,6 +271,23 @@ class SceneBuilder:
         self.objects[oid]["meshes"].append(mesh)
         self.blas[oid] = None
         return oid
+
+    def set_mesh_vertices(self, obj_id, positions, indices, normals=None):
+        """Move the vertices of a polygon object made by ONE add_mesh call (same index list): a deformation tick."""
+        mesh, = self.objects[obj_id]["meshes"]
+        flat = np.asarray(indices, np.int64).reshape(-1)
+        assert len(flat) == 3 * len(mesh["tris"])
+        base_v = self.tris[mesh["tris"][0]]["idx"][0]
+        P = np.asarray(positions, F32)[flat]
+        for j in range(len(flat)):
+            self.pos[base_v + j] = (float(P[j, 0]), float(P[j, 1]), float(P[j, 2]), self.pos[base_v + j][3])
+        if normals is not None:
+            Nn = np.asarray(normals, F32)[flat]
+            for j in range(len(flat)):
+                self.nml[base_v + j] = (float(Nn[j, 0]), float(Nn[j, 1]), float(Nn[j, 2]), self.nml[base_v + j][3])
+        if self.blas.get(obj_id) is not None:
+            self.blas[obj_id] = None
+        return base_v, len(flat)
 
     def add_sphere(self, center, radius, mtrl):
         """TransformableFactory::createSphere (geometry/sphere.h:16-28): a transformable of type Sphere.  The
@@ -503,6 +527,8 @@ class SceneBuilder:
         d.scene_bbox_min[:] = [float(x) for x in smin]
         d.scene_bbox_max[:] = [float(x) for x in smax]
         fs.keep = [objs, mtx, mats, lights, tris, pos, nml, bvh_lists, lists, texd, [t for _, t in self.textures]]
+        fs.lists = lists
+        fs.blas_index = dict(blas_index)      # polygon object id -> its node list
         fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lights, triangles=tris,
                          vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, textures=[t for _, t in self.textures])
         fs.names = dict(materials=[n for n, _ in self.materials], textures=[n for n, _ in self.textures])

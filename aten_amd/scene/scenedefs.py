@@ -331,3 +331,46 @@ def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
     b.add_ibl(tid, avg_illum=envmap_avg_illum(env))
     cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
     return b.build(), cam
+
+
+def blob_mesh(t, nu=48, nv=24, centre=(0.33, 1.05, 0.35), radius=0.3):
+    """A UV sphere whose radius is modulated by two travelling waves of phase t: the stand-in for the reference's
+    skinned character (asset/converted_unitychan, absent from the snapshot) in the deformation-renderer sequence.
+    Returns (positions [V,3], normals [V,3], indices [2 nu nv, 3])."""
+    f = np.float32
+    th = (np.arange(nv + 1, dtype=f) / f(nv)) * f(np.pi)
+    ph = (np.arange(nu, dtype=f) / f(nu)) * f(2 * np.pi)
+    TH, PH = np.meshgrid(th, ph, indexing="ij")
+    r = f(radius) * (f(1) + f(0.25) * np.sin(f(3) * PH + f(t)) * np.sin(f(2) * TH) + f(0.15) * np.sin(f(5) * TH - f(2 * t)))
+    d = np.stack([np.sin(TH) * np.cos(PH), np.cos(TH), np.sin(TH) * np.sin(PH)], axis=-1).astype(f)
+    pos = (np.asarray(centre, f)[None, None, :] + r[..., None] * d).reshape(-1, 3).astype(f)
+    nml = d.reshape(-1, 3)
+    idx = []
+    for i in range(nv):
+        for j in range(nu):
+            a, b = i * nu + j, i * nu + (j + 1) % nu
+            c, e = a + nu, b + nu
+            idx.append((a, c, b)); idx.append((b, c, e))
+    return pos, nml, np.asarray(idx, np.int64)
+
+
+def deformable_room(t=0.0, asset_dir=None, **blob):
+    """The Cornell box with a deforming mesh in it (the reference's deformation renderer puts a skinned model in a
+    room: src/deformation_renderer/main.cpp:262-340, scenedefs.cpp DeformScene).  Returns (builder, blob object id,
+    camera): call builder.build() for the scene at phase t, builder.set_mesh_vertices(...) + build() for the next."""
+    asset_dir = asset_dir or os.path.join(ASSETS, "cornellbox")
+    b = SceneBuilder()
+    emit = b.add_material("light", L.MTRL_EMISSIVE, (1.0, 1.0, 1.0))
+    objs = b.load_obj(os.path.join(asset_dir, "orig.obj"), create_mtrl=lambda name, mt, clr, a, n: b.add_material(name, mt, clr),
+                      separate_objs=True, normal_on_the_fly=True)
+    light = b.create_instance(objs[0])
+    b.add_area_light(light, b.materials[emit][1]["baseColor"][:3], 200.0)
+    for o in objs[1:]:
+        b.create_instance(o)
+    skin = b.add_material("skin", L.MTRL_GGX, (0.8, 0.45, 0.3), roughness=0.35, ior=1.4)
+    pos, nml, idx = blob_mesh(t, **blob)
+    oid = b.add_mesh("blob", pos, idx, skin, normals=nml)
+    b.create_instance(oid)
+    b.set_background((0.0, 0.0, 0.0))
+    cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)
+    return b, oid, cam

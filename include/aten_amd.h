@@ -70,6 +70,36 @@ int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_ob
 /* ≙ idaten::Renderer::updateCamera (renderer.cpp:202-205). */
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
 
+/* ---- dynamic geometry: the per-tick sequence of the reference's deformation renderer
+ * (src/deformation_renderer/main.cpp:636-710): skinned vertices -> LBVHBuilder::build into the renderer's node list ->
+ * Renderer::updateGeometry -> Renderer::updateBVH (= atn_update_tlas). */
+
+/* ≙ idaten::Renderer::updateGeometry (src/libidaten/kernel/renderer.cpp:155-215): overwrite vertices
+ * [vtx_offset, vtx_offset + n_vertices) and triangles [tri_offset, tri_offset + n_triangles) of the uploaded scene.  Host
+ * pointers; vtx_pos or vtx_nml may be NULL (left as they are).  Bottom-level lists over these triangles must be rebuilt
+ * (atn_lbvh_rebuild_list) before the next render: their leaf records hold vertex data. */
+int atn_update_geometry(atn_ctx* ctx, const atn_vec4* vtx_pos, const atn_vec4* vtx_nml, uint32_t n_vertices, uint32_t vtx_offset,
+                        const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset);
+/* The scene arrays in device memory (float4[n_vertices] x 2, atn_triangle_param[n_triangles]) for a caller whose own HIP
+ * skinning kernel writes them in place (≙ the interop VBO the reference's skinning writes, main.cpp:673-676).  Waits for
+ * the frames in flight; the pointers stay valid until the next atn_upload_scene. */
+int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void** triangles);
+/* ≙ lbvh_.build(nodes[deformPos], tris, tri_offset_, sceneBbox, vtxPos, ...) (main.cpp:686-693; idaten::LBVHBuilder::onBuild,
+ * src/libidaten/kernel/LBVHBuilder.cu:700-810): rebuild bottom-level list `list_index` ON THE DEVICE as an LBVH over the
+ * scene's triangles [tri_offset, tri_offset + n_triangles) as they are in device memory now; bbox_* is the box the Morton
+ * codes are normalised with (the reference passes the skinned mesh's box).  The tree is the reference's, node for node;
+ * its records replace the list's region of the node image, which must hold exactly n - 1 inner and n leaf records (a list
+ * uploaded as a binary tree with one leaf per triangle).  ATN_ERR_UNSUPPORTED otherwise. */
+int atn_lbvh_rebuild_list(atn_ctx* ctx, uint32_t list_index, uint32_t tri_offset, uint32_t n_triangles,
+                          const float bbox_min[3], const float bbox_max[3]);
+/* ≙ idaten::LBVHBuilder::build(dst, std::vector<TriangleParameter>&, triIdOffset, sceneBbox, vtxPos, vtxOffset,
+ * threadedBvhNodes) (LBVHBuilder.cu:812-833): the same builder as a function of host arrays, returning
+ * ThreadedBvhNode[2 n - 1] in the reference's node order (inner nodes 0 .. n-2, leaves n-1 .. 2n-2; leaf f0 = 1,
+ * f1 = tri_id_offset + triangle index).  out_sorted_codes / out_sorted_indices (n each) may be NULL.  Needs no scene. */
+int atn_lbvh_build(atn_ctx* ctx, const atn_triangle_param* triangles, uint32_t n_triangles, int32_t tri_id_offset,
+                   const float bbox_min[3], const float bbox_max[3], const atn_vec4* vtx_pos, uint32_t n_vertices, int32_t vtx_offset,
+                   atn_bvh_node* out_nodes, uint32_t* out_sorted_codes, uint32_t* out_sorted_indices);
+
 /* ≙ aten::initSampler(width, height, seed) (src/libaten/sampler/sampler.cpp:8-18) followed by
  * idaten::PathTracing::initSamplerParameter's upload of aten::getRandom()
  * (src/libidaten/kernel/renderer.h:113-124): one std::mt19937(seed) draw per pixel. */
@@ -175,6 +205,10 @@ int atn_mgpu_upload_scene(atn_mgpu* mg, const atn_scene_desc* scene);
 int atn_mgpu_update_tlas(atn_mgpu* mg, const atn_object_param* objects, uint32_t n_objects,
                          const atn_mat4* matrices, uint32_t n_matrices,
                          const atn_bvh_node* top_nodes, uint32_t n_top_nodes);
+int atn_mgpu_update_geometry(atn_mgpu* mg, const atn_vec4* vtx_pos, const atn_vec4* vtx_nml, uint32_t n_vertices, uint32_t vtx_offset,
+                             const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset);
+int atn_mgpu_lbvh_rebuild_list(atn_mgpu* mg, uint32_t list_index, uint32_t tri_offset, uint32_t n_triangles,
+                               const float bbox_min[3], const float bbox_max[3]);
 int atn_mgpu_update_camera(atn_mgpu* mg, const atn_camera_param* camera);
 int atn_mgpu_init_sampler(atn_mgpu* mg, int32_t width, int32_t height, int32_t seed);
 int atn_mgpu_set_random(atn_mgpu* mg, const uint32_t* seeds, uint32_t n);

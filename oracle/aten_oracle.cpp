@@ -7,6 +7,7 @@
  */
 #include "orc_pt.h"
 #include "orc_svgf.h"
+#include "orc_lbvh.h"
 #include <cstdio>
 #include <omp.h>
 
@@ -386,6 +387,23 @@ void orc_svgf_render(void* h, const atn_scene_desc* scene, const atn_camera_para
         for (size_t i = 0; i < n; i++) { cv[i].z = P.temporary_color_buffer[i].z; cv[i].y = P.temporary_color_buffer[i].y; cv[i].x = P.temporary_color_buffer[i].x; }
     }
     P.curr_aov_pos = 1 - P.curr_aov_pos;
+}
+
+// idaten::LBVHBuilder::build with threadedBvhNodes (LBVHBuilder.cu:812-833): the node array in the reference's order
+int orc_lbvh_build(const atn_triangle_param* tris, uint32_t n, int32_t tri_id_offset, const float* bmin, const float* bmax,
+                   const atn_vec4* vtx_pos, int32_t vtx_offset, atn_bvh_node* out_nodes, uint32_t* out_codes, uint32_t* out_indices)
+{
+    return orc::lbvh::build(tris, n, tri_id_offset, bmin, bmax, vtx_pos, vtx_offset, out_nodes, out_codes, out_indices) ? 0 : -1;
+}
+
+// buildTree alone on given SORTED keys (LBVHBuilder.cu:299-350): left / right / parent of the 2 n - 1 nodes
+int orc_lbvh_hierarchy(const uint32_t* sorted_keys, uint32_t n, int32_t* left, int32_t* right, int32_t* parent)
+{
+    if (n < 2) return -1;
+    std::vector<orc::lbvh::Node> nodes;
+    orc::lbvh::build_tree(sorted_keys, n, nodes);
+    for (size_t i = 0; i < nodes.size(); i++) { left[i] = nodes[i].left; right[i] = nodes[i].right; parent[i] = nodes[i].parent; }
+    return 0;
 }
 
 } // extern "C"

@@ -122,6 +122,36 @@ def sample_texture(scene, texid, uv):
     return out
 
 
+def lbvh_build(tris, bbox_min, bbox_max, vtx_pos, tri_id_offset=0, vtx_offset=0, with_keys=False):
+    """idaten::LBVHBuilder::build on the CPU oracle (oracle/orc_lbvh.h): ThreadedBvhNode[2 n - 1] in the reference's
+    own order (inner nodes 0 .. n-2, leaves n-1 .. 2n-2)."""
+    from aten_amd import layout as L
+    tris = np.ascontiguousarray(tris, L.TRIANGLE_PARAM)
+    vtx_pos = np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
+    n = len(tris)
+    out = np.zeros(2 * n - 1, L.BVH_NODE)
+    codes = np.zeros(n, np.uint32); idx = np.zeros(n, np.uint32)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    rc = lib().orc_lbvh_build(C.c_void_p(tris.ctypes.data), C.c_uint32(n), C.c_int32(tri_id_offset), f3(bbox_min), f3(bbox_max),
+                              C.c_void_p(vtx_pos.ctypes.data), C.c_int32(vtx_offset), C.c_void_p(out.ctypes.data),
+                              C.c_void_p(codes.ctypes.data), C.c_void_p(idx.ctypes.data))
+    if rc != 0:
+        raise ValueError("orc_lbvh_build: needs at least two triangles")
+    return (out, codes, idx) if with_keys else out
+
+
+def lbvh_hierarchy(sorted_keys):
+    """buildTree (LBVHBuilder.cu:299-350) on sorted keys: (left, right, parent) of the 2 n - 1 nodes."""
+    keys = np.ascontiguousarray(sorted_keys, np.uint32)
+    n = len(keys)
+    l = np.zeros(2 * n - 1, np.int32); r = np.zeros_like(l); p = np.zeros_like(l)
+    rc = lib().orc_lbvh_hierarchy(C.c_void_p(keys.ctypes.data), C.c_uint32(n), C.c_void_p(l.ctypes.data),
+                                  C.c_void_p(r.ctypes.data), C.c_void_p(p.ctypes.data))
+    if rc != 0:
+        raise ValueError("orc_lbvh_hierarchy: needs at least two keys")
+    return l, r, p
+
+
 class Svgf:
     """aten::SVGFRenderer on the CPU oracle (oracle/orc_svgf.h): frame-persistent AOV / moment buffers."""
     BUFFERS = dict(normal_depth=0, albedo_meshid=1, color_variance=2, moment_temporalweight=3,

@@ -1,0 +1,233 @@
+"""SURVEY 8(f)2, "GPU LBVH": the device builder behind atn_lbvh_build / atn_lbvh_rebuild_list against the CPU restatement of
+idaten::LBVHBuilder (oracle/orc_lbvh.h; src/libidaten/kernel/LBVHBuilder.cu, MortonCode.cuh).
+
+  * the node array -- Morton codes, the stable key / value sort, Karras' hierarchy, hit / miss links, boxes -- is
+    BYTE-equal to the oracle's for triangle soups from 2 to 300 000 triangles, with heavy key duplication, a flat
+    (zero-size) axis, non-zero triangle-id and vertex offsets;
+  * the deformation sequence of src/deformation_renderer/main.cpp:636-710 (new vertices -> LBVH into the renderer's node
+    list -> updateGeometry -> updateBVH): after an in-place device rebuild the closest-hit records are byte-equal to the
+    oracle's walk through the oracle-built LBVH and the frames agree within the frame tolerance, tick after tick, also
+    with frames in flight and on the multi-shard renderer (which equals the single device byte for byte);
+  * the error paths (list of another shape, ranges, one triangle).
+"""
+import numpy as np
+import pytest
+
+from aten_amd import layout as L
+from aten_amd.renderer import AtenAmdError
+from aten_amd.scene.camera import create_camera
+from test_gpu_parity import frame_tolerance_report
+
+pytestmark = pytest.mark.gpu
+
+
+def same_frame(got, want):
+    """Whole frames go through sin / cos / pow, which differ in the last bits between the device and libm: the frame
+    tolerance of DESIGN.md section 4 (the hit records underneath are compared byte for byte)."""
+    frac, mean_err = frame_tolerance_report(got, want)
+    return frac >= 0.995 and mean_err <= 5e-3
+
+
+def soup(n, seed, kind="random"):
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    if kind == "random":
+        c = rng.random((n, 1, 3), dtype=f) * f(10) - f(5)
+        p = c + (rng.random((n, 3, 3), dtype=f) - f(0.5)) * f(0.4)
+    elif kind == "clustered":      # few distinct centroids: long runs of equal Morton codes (ties -> input order)
+        c = rng.integers(0, 3, (n, 1, 3)).astype(f)
+        shapes = (rng.integers(-1, 2, (4, 3, 3)).astype(f)) * f(0.25)
+        p = c + shapes[rng.integers(0, 4, n)]
+    elif kind == "flat":           # every vertex has z = 1.5: size.z = 0, (c - min) / size = 0 / 0
+        c = rng.random((n, 1, 3), dtype=f) * f(4)
+        p = c + (rng.random((n, 3, 3), dtype=f) - f(0.5)) * f(0.2)
+        p[:, :, 2] = f(1.5)
+    else:
+        raise ValueError(kind)
+    pos = np.zeros((3 * n, 4), f)
+    pos[:, :3] = p.reshape(-1, 3)
+    tris = np.zeros(n, L.TRIANGLE_PARAM)
+    tris["idx"] = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    return tris, pos
+
+
+@pytest.mark.parametrize("n,kind", [(2, "random"), (3, "random"), (7, "random"), (64, "random"), (257, "random"), (4097, "random"),
+                                    (100_000, "random"), (300_000, "random"), (5000, "clustered"), (70_000, "clustered"), (3000, "flat")])
+def test_lbvh_nodes_byte_equal(gpu, orc, n, kind):
+    tris, pos = soup(n, n, kind)
+    bmin, bmax = pos[:, :3].min(0), pos[:, :3].max(0)
+    want, wc, wi = orc.lbvh_build(tris, bmin, bmax, pos, with_keys=True)
+    got, gc, gi = gpu.lbvh_build(tris, bmin, bmax, pos, with_keys=True)
+    assert np.array_equal(gc, wc)                   # Morton codes, sorted
+    assert np.array_equal(gi, wi)                   # ... with equal codes in input order (a stable sort)
+    assert got.tobytes() == want.tobytes()
+    if kind == "clustered":
+        assert len(np.unique(wc)) < n // 20
+    if kind == "flat":
+        assert ((wc & 0x09249249) == 0).all()       # the z bits: NaN quantised to 0 like CUDA's fmaxf
+
+
+def test_lbvh_offsets_and_scene_box(gpu, orc):
+    """triIdOffset / vtxOffset as the reference's deformation renderer passes them (main.cpp:678-693: triangle ids are
+    offset into the scene's list, vertex indices are shifted back by the VBO offset) and a normalisation box that is not
+    the mesh's own (codes clamp at the box faces)."""
+    tris, pos = soup(2000, 5)
+    shift = 321
+    tris["idx"] += shift
+    bmin, bmax = np.float32([-2, -2, -2]), np.float32([2, 3, 2])      # smaller than the soup's extent
+    want = orc.lbvh_build(tris, bmin, bmax, pos, tri_id_offset=4500, vtx_offset=-shift)
+    got = gpu.lbvh_build(tris, bmin, bmax, pos, tri_id_offset=4500, vtx_offset=-shift)
+    assert got.tobytes() == want.tobytes()
+    leaf = got["f0"] >= 0
+    assert got["f1"][leaf].min() == 4500 and got["f1"][leaf].max() == 6499
+
+
+def test_lbvh_build_rejects_bad_input(gpu):
+    tris, pos = soup(4, 1)
+    with pytest.raises(AtenAmdError, match="at least two"):
+        gpu.lbvh_build(tris[:1], pos[:, :3].min(0), pos[:, :3].max(0), pos)
+    bad = tris.copy(); bad["idx"][2, 1] = 12
+    with pytest.raises(AtenAmdError, match="vertex index"):
+        gpu.lbvh_build(bad, pos[:, :3].min(0), pos[:, :3].max(0), pos)
+    with pytest.raises(AtenAmdError, match="vertex index"):
+        gpu.lbvh_build(tris, pos[:, :3].min(0), pos[:, :3].max(0), pos, vtx_offset=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+W, H = 160, 120
+
+
+def tick_data(b, oid, t):
+    """The scene at phase t as the host sees it (vertices, triangle areas, object boxes, top layer)."""
+    from aten_amd.scene import scenedefs
+    pos, nml, idx = scenedefs.blob_mesh(t)
+    b.set_mesh_vertices(oid, pos, idx, nml)
+    fs = b.build()
+    o = fs.arrays["objects"][oid]
+    t0, n = int(o["triangle_id"]), int(o["triangle_num"])
+    tris = fs.arrays["triangles"][t0:t0 + n]
+    v0, v1 = int(tris["idx"].min()), int(tris["idx"].max()) + 1
+    used = fs.arrays["vtx_pos"][v0:v1, :3]
+    return fs, dict(list=fs.blas_index[oid], t0=t0, n=n, v0=v0, v1=v1, bmin=used.min(0), bmax=used.max(0))
+
+
+def oracle_scene_with_lbvh(orc, fs, d):
+    tris = fs.arrays["triangles"][d["t0"]:d["t0"] + d["n"]]
+    nodes = orc.lbvh_build(tris, d["bmin"], d["bmax"], fs.arrays["vtx_pos"], tri_id_offset=d["t0"])
+    fs.replace_bvh_list(d["list"], nodes)
+    return fs
+
+
+def push_tick(r, fs, d):
+    """One tick on the product: the reference's order is build -> updateGeometry -> updateBVH with the builder reading the
+    skinning output directly; here the new vertices go in first because the builder reads the scene arrays."""
+    a = fs.arrays
+    r.updateGeometry(vtx_pos=a["vtx_pos"][d["v0"]:d["v1"]], vtx_nml=a["vtx_nml"][d["v0"]:d["v1"]], vtx_offset=d["v0"],
+                     triangles=a["triangles"][d["t0"]:d["t0"] + d["n"]], tri_offset=d["t0"])
+    r.lbvh_rebuild_list(d["list"], d["t0"], d["n"], d["bmin"], d["bmax"])
+    r.updateBVH(fs)
+
+
+@pytest.fixture(scope="module")
+def room():
+    from aten_amd.scene import scenedefs
+    b, oid, cam = scenedefs.deformable_room(0.0)
+    return b, oid, cam
+
+
+def test_deformation_ticks_render_like_oracle(orc, room):
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    assert len(fs0.arrays["bvh_lists"][d0["list"]]) == 2 * d0["n"] - 1      # uploaded as one triangle per leaf
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    seeds = orc.init_sampler(W, H, 0)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs0)
+        r.updateCamera(c)
+        r.initSampler(W, H, 0)
+        # tick 0 rebuilds over unchanged vertices: the SAH tree and the LBVH find the same hits
+        before = r.render(W, H, frame=0)
+        r.reset()
+        r.lbvh_rebuild_list(d0["list"], d0["t0"], d0["n"], d0["bmin"], d0["bmax"])
+        assert r.render(W, H, frame=0).tobytes() == before.tobytes()
+        hit_blob = 0
+        for tick, t in enumerate([0.9, 2.1, 3.3]):
+            fs, d = tick_data(b, oid, t)
+            push_tick(r, fs, d)
+            r.reset()
+            got = r.render(W, H, frame=tick)
+            ofs = oracle_scene_with_lbvh(orc, fs, d)
+            want = orc.render(ofs, c, seeds, W, H, frame=tick)
+            assert same_frame(got, want), "tick %d" % tick
+            rays = orc.generate_paths(c, seeds, W, H, 0, tick)
+            gi = r.trace_closest(rays); wi, _ = orc.trace_closest(ofs, rays)
+            assert gi.tobytes() == wi.tobytes()
+            hit_blob += int((wi["objid"] == len(fs.arrays["objects"]) - 1).sum())
+        assert hit_blob > 1500                                           # the deforming mesh is what is being looked at
+        # the frames differ from tick to tick (the geometry really moved)
+        assert got.tobytes() != before.tobytes()
+    finally:
+        r.close()
+
+
+def test_deformation_with_frames_in_flight_and_shards(orc, room):
+    """The rebuild waits for the frames in flight; every shard of the multi-GPU renderer rebuilds its own replica."""
+    from aten_amd.renderer import MultiGpuPathTracing, PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    seeds = orc.init_sampler(W, H, 0)
+    r = PathTracing(0)
+    mg = MultiGpuPathTracing([0, 0, 0])
+    try:
+        for x in (r, mg):
+            x.UpdateSceneData(fs0); x.updateCamera(c); x.initSampler(W, H, 0)
+        r.set_frames_in_flight(3)
+        for f in range(4):
+            r.render(W, H, frame=f, download=False)                      # frames of the old geometry still in flight
+        fs, d = tick_data(b, oid, 1.7)
+        push_tick(r, fs, d)
+        push_tick(mg, fs, d)
+        r.reset(); mg.reset()
+        want = orc.render(oracle_scene_with_lbvh(orc, fs, d), c, seeds, W, H, frame=9)
+        got = r.render(W, H, frame=9)
+        assert same_frame(got, want)
+        assert mg.render(W, H, frame=9).tobytes() == got.tobytes()          # shards == one device, byte for byte
+    finally:
+        r.close(); mg.close()
+
+
+def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    r = PathTracing(0)
+    try:
+        with pytest.raises(AtenAmdError, match="atn_upload_scene"):
+            r.lbvh_rebuild_list(1, 0, 10, d0["bmin"], d0["bmax"])
+        r.UpdateSceneData(fs0)
+        with pytest.raises(AtenAmdError, match="bottom-level"):
+            r.lbvh_rebuild_list(0, d0["t0"], d0["n"], d0["bmin"], d0["bmax"])
+        with pytest.raises(AtenAmdError, match="bottom-level"):
+            r.lbvh_rebuild_list(len(fs0.arrays["bvh_lists"]), d0["t0"], d0["n"], d0["bmin"], d0["bmax"])
+        with pytest.raises(AtenAmdError, match="one leaf per triangle"):
+            r.lbvh_rebuild_list(d0["list"], d0["t0"], d0["n"] - 1, d0["bmin"], d0["bmax"])
+        with pytest.raises(AtenAmdError, match="outside the uploaded scene"):
+            r.lbvh_rebuild_list(d0["list"], len(fs0.arrays["triangles"]) - 5, d0["n"], d0["bmin"], d0["bmax"])
+        with pytest.raises(AtenAmdError, match="at least two"):
+            r.lbvh_rebuild_list(d0["list"], d0["t0"], 1, d0["bmin"], d0["bmax"])
+        with pytest.raises(AtenAmdError, match="outside the uploaded scene"):
+            r.updateGeometry(vtx_pos=np.zeros((8, 4), np.float32), vtx_offset=len(fs0.arrays["vtx_pos"]) - 4)
+        bad = fs0.arrays["triangles"][:2].copy(); bad["idx"][1, 2] = len(fs0.arrays["vtx_pos"])
+        with pytest.raises(AtenAmdError, match="vertex index"):
+            r.updateGeometry(triangles=bad, tri_offset=0)
+        # the reference-built sponza_lod.sbvh duplicates references (19 000 leaves over 12 852 triangles): not rebuildable in place
+        sfs, _ = sponza
+        r.UpdateSceneData(sfs)
+        o = [x for x in sfs.arrays["objects"] if x["type"] == L.OBJ_POLYGONS][0]
+        with pytest.raises(AtenAmdError, match="one leaf per triangle"):
+            r.lbvh_rebuild_list(1, int(o["triangle_id"]), int(o["triangle_num"]), [0, 0, 0], [1, 1, 1])
+    finally:
+        r.close()

@@ -90,6 +90,62 @@ def test_sbvh_export_of_built_tree_imports_identically(tmp_path):
         assert a.tobytes() == b.tobytes()
 
 
+def test_lbvh_hierarchy_matches_karras_figure(orc):
+    """The keys of the reference's disabled builder self-test (src/libidaten/kernel/LBVHBuilder.cu:877-880),
+    {1, 19, 24, 25, 30, 2, 4, 5}, are -- sorted -- the 5-bit keys of Figure 3 of Karras 2012 (the paper the file cites,
+    :11-12): 00001 00010 00100 00101 10011 11000 11001 11110.  The figure's tree: node 0 = [0,7] splits after 3 into
+    nodes 3 and 4; 3 = [0,3] -> nodes 1 and 2; 1 -> leaves 0, 1; 2 -> leaves 2, 3; 4 = [4,7] -> leaf 4 and node 5;
+    5 = [5,7] -> node 6 and leaf 7; 6 -> leaves 5, 6.  Leaves are numbered n - 1 + i = 7 + i here."""
+    keys = sorted([1, 19, 24, 25, 30, 2, 4, 5])
+    left, right, parent = orc.lbvh_hierarchy(keys)
+    assert left[:7].tolist() == [3, 7, 9, 1, 11, 6, 12]
+    assert right[:7].tolist() == [4, 8, 10, 2, 5, 14, 13]
+    assert parent.tolist() == [-1, 3, 3, 0, 0, 4, 5, 1, 1, 2, 2, 4, 6, 6, 5]
+    assert (left[7:] == -1).all() and (right[7:] == -1).all()
+
+
+def test_lbvh_oracle_tree_is_a_threaded_bvh_over_the_same_triangles(orc):
+    """Structure of LBVHBuilder's output (LBVHBuilder.cu:353-489, 533-680): following hit links from node 0 visits all
+    2 n - 1 nodes once (inner node -> left child, leaf -> the next subtree), every triangle sits in exactly one leaf, a
+    parent's box is the union of its children's, equal Morton codes keep their input order, and rays find the same
+    hits through this tree as through the SAH tree of the same mesh."""
+    from aten_amd.scene import scenedefs
+    b, oid, cam = scenedefs.deformable_room(0.7)
+    fs = b.build()
+    k = fs.blas_index[oid]
+    o = fs.arrays["objects"][oid]
+    t0, n = int(o["triangle_id"]), int(o["triangle_num"])
+    tris = fs.arrays["triangles"][t0:t0 + n]
+    vp = fs.arrays["vtx_pos"]
+    used = vp[tris["idx"].min():tris["idx"].max() + 1, :3]
+    nodes, codes, idx = orc.lbvh_build(tris, used.min(0), used.max(0), vp, tri_id_offset=t0, with_keys=True)
+    assert len(nodes) == 2 * n - 1
+    assert (np.diff(codes.astype(np.int64)) >= 0).all()
+    same = np.flatnonzero(np.diff(codes.astype(np.int64)) == 0)
+    assert len(same) > 0 and (idx[same + 1] > idx[same]).all()          # the pole triangles share codes: stable
+    assert sorted(idx.tolist()) == list(range(n))
+    leaf = nodes["f0"] >= 0
+    assert leaf[n - 1:].all() and not leaf[:n - 1].any()
+    assert np.array_equal(np.sort(nodes["f1"][leaf].astype(np.int64)), np.arange(t0, t0 + n))
+    assert (nodes["hit"][leaf] == nodes["miss"][leaf]).all()
+    seen, cur = [], 0
+    while cur >= 0:
+        seen.append(cur)
+        cur = int(nodes["hit"][cur])
+    assert sorted(seen) == list(range(2 * n - 1))
+    for i in range(n - 1):                  # inner node i: left child = hit link, right child = the left child's miss link
+        l = int(nodes["hit"][i]); r = int(nodes["miss"][l])
+        assert np.array_equal(nodes["boxmin"][i], np.minimum(nodes["boxmin"][l], nodes["boxmin"][r]))
+        assert np.array_equal(nodes["boxmax"][i], np.maximum(nodes["boxmax"][l], nodes["boxmax"][r]))
+    c = make_camera(orc, cam, 96, 96)
+    rays = orc.generate_paths(c, orc.init_sampler(96, 96, 0), 96, 96, 0, 0)
+    a, _ = orc.trace_closest(fs, rays)
+    fs.replace_bvh_list(k, nodes)
+    bb, _ = orc.trace_closest(fs, rays)
+    assert (a["objid"] == len(fs.arrays["objects"]) - 1).sum() > 300    # the blob is in view
+    assert a.tobytes() == bb.tobytes()
+
+
 def test_compaction_kat_data():
     """The commented self-test in src/libidaten/kernel/StreamCompaction.cu:318-400 scans
     f = {3,1,7,0,4,1,6,3,...}; the compaction contract on flags>0 is ascending indices."""

@@ -91,9 +91,10 @@ public:
 
     // LBVH rebuild scratch (atn_lbvh_*), grown on demand
     struct LbvhScratch {
-        DevBuf<uint32_t> codes[2], indices[2], counts, arrived, offs;
-        DevBuf<int32_t> left, right, parent, first;
+        DevBuf<uint32_t> codes[2], indices[2], counts, totals, arrived, offs;
+        DevBuf<int32_t> left, right, parent, first, last;
         DevBuf<atn_bvh_node> ref_nodes;
+        DevBuf<LbvhBox> pre, suf, sup;
         DevBuf<atn_triangle_param> tris;     // atn_lbvh_build's own inputs
         DevBuf<float4> vtx;
     } lb;
@@ -437,46 +438,57 @@ public:
 
     int lbvh_reserve(uint32_t n)
     {
-        const uint32_t nb = (n + kSortTile - 1) / kSortTile, nn = 2 * n - 1;
+        const uint32_t rounds = radix_rounds(n), tile = kSortThreads * rounds, nb = (n + tile - 1) / tile, nn = 2 * n - 1;
         for (int k = 0; k < 2; k++) {
             if (lb.codes[k].n < n) ATN_HIP(lb.codes[k].resize(n));
             if (lb.indices[k].n < n) ATN_HIP(lb.indices[k].resize(n));
         }
         if (lb.counts.n < 256u * nb) ATN_HIP(lb.counts.resize(256u * nb));
+        if (lb.totals.n < 256u) ATN_HIP(lb.totals.resize(256u));
         if (lb.arrived.n < n) ATN_HIP(lb.arrived.resize(n));
         if (lb.offs.n < nn) ATN_HIP(lb.offs.resize(nn));
         if (lb.left.n < nn) ATN_HIP(lb.left.resize(nn));
         if (lb.right.n < nn) ATN_HIP(lb.right.resize(nn));
         if (lb.parent.n < nn) ATN_HIP(lb.parent.resize(nn));
         if (lb.first.n < n) ATN_HIP(lb.first.resize(n));
+        if (lb.last.n < n) ATN_HIP(lb.last.resize(n));
         if (lb.ref_nodes.n < nn) ATN_HIP(lb.ref_nodes.resize(nn));
+        if (lb.pre.n < n) ATN_HIP(lb.pre.resize(n));
+        if (lb.suf.n < n) ATN_HIP(lb.suf.resize(n));
+        { const uint32_t ns = (n + kBoundsBlock * kBoundsSuper - 1) / (kBoundsBlock * kBoundsSuper); if (lb.sup.n < ns) ATN_HIP(lb.sup.resize(ns)); }
         return ATN_OK;
     }
 
     // Morton codes -> sort -> hierarchy -> links -> boxes, all enqueued on `stream`; the tree is left in lb.ref_nodes in
     // the reference's node order.  `tr` points at the first of the n triangles, `vtx` at the vertex array.
     int lbvh_enqueue(const atn_triangle_param* tr, uint32_t n, int32_t tri_id_offset, const float* bmin, const float* bmax,
-                     const float4* vtx, int32_t vtx_offset)
+                     const float4* vtx, int32_t vtx_offset, uint32_t image_base = 0)
     {
         { int r = lbvh_reserve(n); if (r) return r; }
-        const uint32_t nb = (n + kSortTile - 1) / kSortTile, nn = 2 * n - 1;
+        const uint32_t rounds = radix_rounds(n), tile = kSortThreads * rounds, nb = (n + tile - 1) / tile, nn = 2 * n - 1;
         const dim3 b256(256);
         f3 mn, mx;
         mn.x = bmin[0]; mn.y = bmin[1]; mn.z = bmin[2]; mx.x = bmax[0]; mx.y = bmax[1]; mx.z = bmax[2];
         hipLaunchKernelGGL(k_lbvh_morton, dim3((n + 255) / 256), b256, 0, stream, tr, vtx, vtx_offset, n, mn, mx, lb.codes[0].p, lb.indices[0].p);
         for (uint32_t pass = 0; pass < 4; pass++) {
             const int in = pass & 1, out = in ^ 1;
-            hipLaunchKernelGGL(k_radix_count, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, n, pass * 8u, lb.counts.p, nb);
-            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, lb.counts.p, 256u * nb);
+            hipLaunchKernelGGL(k_radix_count, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, n, pass * 8u, lb.counts.p, nb, rounds);
+            hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(64), 0, stream, lb.counts.p, nb, lb.totals.p);
             hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, (const uint32_t*)lb.indices[in].p,
-                               lb.codes[out].p, lb.indices[out].p, n, pass * 8u, (const uint32_t*)lb.counts.p, nb);
+                               lb.codes[out].p, lb.indices[out].p, n, pass * 8u, (const uint32_t*)lb.counts.p, nb, (const uint32_t*)lb.totals.p, rounds);
         }
-        LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p };
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), b256, 0, stream, (const uint32_t*)lb.codes[0].p, n, t);
-        hipLaunchKernelGGL(k_lbvh_order, dim3((nn + 255) / 256), b256, 0, stream, n, tri_id_offset, t, (const uint32_t*)lb.indices[0].p, lb.ref_nodes.p);
-        ATN_HIP(hipMemsetAsync(lb.arrived.p, 0, (size_t)n * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(k_lbvh_bounds, dim3((n + 255) / 256), b256, 0, stream, n, t, (const uint32_t*)lb.indices[0].p, tr, vtx, vtx_offset,
-                           lb.ref_nodes.p, lb.arrived.p);
+        LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p, lb.last.p };
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), b256, 0, stream, (const uint32_t*)lb.codes[0].p, n, t, lb.arrived.p);
+        hipLaunchKernelGGL(k_lbvh_links, dim3((nn + 255) / 256), b256, 0, stream, n, tri_id_offset, t, (const uint32_t*)lb.indices[0].p, lb.ref_nodes.p,
+                           image_base, lb.offs.p);
+        {
+            const uint32_t nblk = (n + kBoundsBlock - 1) / kBoundsBlock, nsup = (nblk + kBoundsSuper - 1) / kBoundsSuper;
+            hipLaunchKernelGGL(k_lbvh_bounds_block, dim3(nblk), dim3(kBoundsBlock), 0, stream, n, t, (const uint32_t*)lb.indices[0].p, tr, vtx, vtx_offset,
+                               lb.ref_nodes.p, lb.arrived.p, lb.pre.p, lb.suf.p);
+            hipLaunchKernelGGL(k_lbvh_bounds_super, dim3(nsup), dim3(64), 0, stream, n, (const LbvhBox*)lb.pre.p, lb.sup.p);
+            hipLaunchKernelGGL(k_lbvh_bounds_cross, dim3((n + 255) / 256), b256, 0, stream, n, t, (const LbvhBox*)lb.pre.p, (const LbvhBox*)lb.suf.p,
+                               (const LbvhBox*)lb.sup.p, lb.ref_nodes.p);
+        }
         ATN_HIP(hipGetLastError());
         return ATN_OK;
     }
@@ -526,10 +538,8 @@ public:
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
         { int q = quiesce(); if (q) return q; }
-        { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0); if (r) return r; }
+        { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list]); if (r) return r; }
         const uint32_t nn = 2 * n - 1;
-        LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p };
-        hipLaunchKernelGGL(k_lbvh_layout, dim3((nn + 255) / 256), dim3(256), 0, stream, n, t, list_base[list], lb.offs.p);
         hipLaunchKernelGGL(k_lbvh_emit, dim3((nn + 255) / 256), dim3(256), 0, stream, n, (const atn_bvh_node*)lb.ref_nodes.p, (const uint32_t*)lb.offs.p,
                            (const atn_triangle_param*)tris.p, (const float4*)vtx_pos.p, nodes.p);
         ATN_HIP(hipGetLastError());

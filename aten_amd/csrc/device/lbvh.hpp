@@ -11,12 +11,12 @@
 //                      waves -- the in-block rank of a key is popcount(lanes below me with my digit), found with 8
 //                      ballots, no LDS atomics in the scatter             (the reference calls thrust::sort_by_key)
 //   k_lbvh_hierarchy   one thread per inner node: findSpan / findSplit           (LBVHBuilder.cu:193-350)
-//   k_lbvh_order       one thread per node: hit / miss links, leaf payload       (LBVHBuilder.cu:353-489)
-//   k_lbvh_bounds      one thread per leaf walking up; the second child to arrive at a node merges (an atomic counter
-//                      per inner node; min / max are exact, so arrival order cannot change a bit) (LBVHBuilder.cu:533-680)
-//   k_lbvh_layout      byte offset of every node's record in walk (pre-)order: a node whose range starts at sorted leaf
-//                      `a`, with L left-turns on the way down from the root, is preceded by `a` leaves and a + L inner
-//                      nodes -> offset = base + 32 (a + L) + 48 a.  No scan, no sort.
+//   k_lbvh_links       one thread per node walking to the root: hit / miss links, leaf payload (LBVHBuilder.cu:353-489)
+//                      and, from the left turns it counts on the way, the byte offset of the node's record in walk
+//                      (pre-)order: a node whose range starts at sorted leaf `a`, L left turns below the root, is
+//                      preceded by `a` leaves and a + L inner nodes -> offset = base + 32 (a + L) + 48 a.  No scan.
+//   k_lbvh_bounds_*    boxes = unions over ranges of sorted leaves, evaluated block-locally plus a range query for
+//                      the nodes that cross block boundaries -- no device-wide hand-over (see there) (LBVHBuilder.cu:533-680)
 //   k_lbvh_emit        writes the records of device/scene_dev.hpp (32-byte inner, 48-byte triangle leaf with v0 / e1 / e2
 //                      hoisted) straight into the scene's node image: the rebuilt tree never visits the host.
 //
@@ -28,8 +28,14 @@
 namespace atn {
 
 constexpr uint32_t kSortThreads = 256;
-constexpr uint32_t kSortRounds = 16;
-constexpr uint32_t kSortTile = kSortThreads * kSortRounds;      // keys per block and pass
+constexpr uint32_t kSortMaxRounds = 16;                         // a block sorts up to 256 x 16 keys per pass ...
+// ... and fewer when that would leave the chip idle: small meshes (the usual deformable is 10^4 .. 10^5 triangles) get
+// at least ~256 blocks, down to one round of 256 keys per block (measured at 12 852 triangles: 15 -> 3 us per scatter)
+inline uint32_t radix_rounds(uint32_t n)
+{
+    const uint32_t r = n / (256u * kSortThreads);
+    return r < 1u ? 1u : (r > kSortMaxRounds ? kSortMaxRounds : r);
+}
 constexpr uint32_t kLbvhMaxTris = 1u << 23;                     // node indices are stored as floats (ThreadedBvhNode::hit)
 
 struct LbvhTopo {
@@ -37,6 +43,7 @@ struct LbvhTopo {
     int32_t* right;
     int32_t* parent;    // [2n-1]  -1 on the root
     int32_t* first;     // [n-1]   first sorted leaf of an inner node's range
+    int32_t* last;      // [n-1]   last
 };
 
 __device__ __forceinline__ uint32_t lbvh_expand_bits(uint32_t v)
@@ -78,13 +85,13 @@ __global__ __launch_bounds__(256) void k_lbvh_morton(const atn_triangle_param* _
 // ---------------------------------------------------------------------------------------------------------------------
 // stable LSD radix sort, 8 bits per pass.  counts[digit * n_blocks + block].
 __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                              uint32_t* __restrict__ counts, uint32_t n_blocks)
+                                                              uint32_t* __restrict__ counts, uint32_t n_blocks, uint32_t rounds)
 {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kSortTile;
-    for (uint32_t r = 0; r < kSortRounds; r++) {
+    const uint32_t base = blockIdx.x * kSortThreads * rounds;
+    for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t g = base + r * kSortThreads + threadIdx.x;
         if (g < n) atomicAdd(&hist[(keys[g] >> shift) & 255u], 1u);
     }
@@ -92,40 +99,53 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint32_t* __
     counts[threadIdx.x * n_blocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan of `total` counters in place, one block of 1024 threads (total = 256 * n_blocks: 64 K entries for a
-// million keys)
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ counts, uint32_t total)
+// Row d of counts[256][n_blocks] -> its exclusive scan over the blocks, and totals[d] = keys with digit d.  One wave per
+// digit (grid 256): coalesced 64-entry reads, a shuffle prefix sum.  The scatter adds the digits' own prefix itself.
+__global__ __launch_bounds__(64) void k_radix_scan(uint32_t* __restrict__ counts, uint32_t n_blocks, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, total);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += counts[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    const uint32_t lane = threadIdx.x, row = blockIdx.x;
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n_blocks ? counts[row * n_blocks + i] : 0u;
+        uint32_t incl = v;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (i < n_blocks) counts[row * n_blocks + i] = run + incl - v;
+        run += __shfl(incl, 63);
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
+    if (lane == 0) totals[row] = run;
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                uint32_t n, uint32_t shift, const uint32_t* __restrict__ offsets, uint32_t n_blocks)
+                                                                uint32_t n, uint32_t shift, const uint32_t* __restrict__ offsets, uint32_t n_blocks,
+                                                                const uint32_t* __restrict__ totals, uint32_t rounds)
 {
     constexpr uint32_t kWaves = kSortThreads / 64;
     __shared__ uint32_t run[256];               // where this block's next key with digit d goes
     __shared__ uint32_t wcount[kWaves][256];    // keys with digit d in wave w of the current round
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    run[tid] = offsets[tid * n_blocks + blockIdx.x];
+    {   // keys with a smaller digit come first: exclusive scan of the 256 digit totals (4 waves x 64 lanes)
+        const uint32_t v = totals[tid];
+        uint32_t incl = v;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wcount[0][wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; w++) base += wcount[0][w];
+        run[tid] = base + incl - v + offsets[tid * n_blocks + blockIdx.x];
+        __syncthreads();
+    }
     for (uint32_t w = 0; w < kWaves; w++) wcount[w][tid] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kSortTile;
-    for (uint32_t r = 0; r < kSortRounds; r++) {
+    const uint32_t base = blockIdx.x * kSortThreads * rounds;
+    for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t g = base + r * kSortThreads + tid;
         const bool valid = g < n;
         const uint32_t key = valid ? keys_in[g] : 0u, val = valid ? vals_in[g] : 0u;
@@ -165,10 +185,11 @@ __device__ __forceinline__ int32_t lbvh_lcp(const uint32_t* __restrict__ keys, i
     return a != b ? lbvh_clz(a ^ b) : 32 + lbvh_clz((uint32_t)(l ^ r));
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, LbvhTopo t)
+__global__ __launch_bounds__(256) void k_lbvh_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, LbvhTopo t, uint32_t* __restrict__ arrived)
 {
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
     if (idx >= num - 1) return;
+    arrived[idx] = 0;       // k_lbvh_bounds_block's hand-over counters
     // findSpan, LBVHBuilder.cu:218-263
     const int32_t d = (lbvh_lcp(keys, num, idx, idx + 1) - lbvh_lcp(keys, num, idx, idx - 1)) < 0 ? -1 : 1;
     const int32_t min_lcp = lbvh_lcp(keys, num, idx, idx - d);
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256) void k_lbvh_hierarchy(const uint32_t* __restri
     const int32_t cl = split == lo ? split + num - 1 : split;
     const int32_t cr = split + 1 == hi ? split + 1 + num - 1 : split + 1;
     if (idx == 0) t.parent[0] = -1;
-    t.left[idx] = cl; t.right[idx] = cr; t.first[idx] = lo;
+    t.left[idx] = cl; t.right[idx] = cr; t.first[idx] = lo; t.last[idx] = hi;
     t.parent[cl] = idx; t.parent[cr] = idx;
     if (cl >= num - 1) { t.left[cl] = -1; t.right[cl] = -1; }
     if (cr >= num - 1) { t.left[cr] = -1; t.right[cr] = -1; }
@@ -202,17 +223,21 @@ __global__ __launch_bounds__(256) void k_lbvh_hierarchy(const uint32_t* __restri
 // onApplyTraverseOrder, LBVHBuilder.cu:353-470.  An inner node's hit link is its left child; a node's miss link is the
 // right sibling of the nearest ancestor-or-self that is a left child (-1 when there is none); a leaf's hit link equals
 // its miss link.  Leaves carry isleaf = 1 (GPGPU_TRAVERSE_SBVH) and the triangle id as a float.
-__global__ __launch_bounds__(256) void k_lbvh_order(uint32_t n, int32_t tri_id_offset, LbvhTopo t, const uint32_t* __restrict__ sorted_indices,
-                                                    atn_bvh_node* __restrict__ out)
+// The same walk to the root counts the left turns, which gives the byte offset of the node's device record in walk
+// (pre-)order from `base`: a node whose range starts at sorted leaf `a` is preceded by `a` leaves and a + lefts inner
+// nodes.  No scan, no sort.
+__global__ __launch_bounds__(256) void k_lbvh_links(uint32_t n, int32_t tri_id_offset, LbvhTopo t, const uint32_t* __restrict__ sorted_indices,
+                                                    atn_bvh_node* __restrict__ out, uint32_t base, uint32_t* __restrict__ offs)
 {
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
     if (idx >= 2 * num - 1) return;
     const bool leaf = idx >= num - 1;
-    int32_t cur = idx, miss = -1;
-    for (;;) {
+    int32_t miss = -1;
+    uint32_t lefts = 0;
+    for (int32_t cur = idx;;) {
         const int32_t p = t.parent[cur];
         if (p < 0) break;
-        if (t.left[p] == cur) { miss = t.right[p]; break; }
+        if (t.left[p] == cur) { if (lefts == 0) miss = t.right[p]; lefts++; }
         cur = p;
     }
     atn_bvh_node& g = out[idx];
@@ -221,54 +246,121 @@ __global__ __launch_bounds__(256) void k_lbvh_order(uint32_t n, int32_t tri_id_o
     g.f0 = leaf ? 1.0F : -1.0F;
     g.f1 = leaf ? (float)(tri_id_offset + (int32_t)sorted_indices[idx - (num - 1)]) : -1.0F;
     g.f2 = -1.0F; g.f3 = -1.0F;
+    const uint32_t a = leaf ? (uint32_t)(idx - (num - 1)) : (uint32_t)t.first[idx];
+    offs[idx] = base + kInnerBytes * (a + lefts) + kTriLeafBytes * a;
 }
 
-__device__ __forceinline__ float lbvh_ld_coherent(const float* p)
+// computeBoudingBox, LBVHBuilder.cu:533-680, without a single device-wide hand-over.  The reference lets one thread per
+// leaf climb and the second child to arrive at a node merge, synchronised by an atomic per node; on this chip every such
+// hand-over between workgroups costs an agent-scope release, i.e. a write-back of an XCD's L2 (measured: 6.7 ms of a
+// 7.4 ms rebuild of 10^6 triangles).  A node's box is the union of the leaf boxes of its RANGE of sorted leaves, and
+// min / max are exact, so any other evaluation order gives the same bits:
+//
+//   k_lbvh_bounds_block  a block owns 256 consecutive sorted leaves.  Nodes whose range lies inside them are only ever
+//                        touched by this block: the climb of the reference, with workgroup-scope hand-overs (one CU, one
+//                        L1).  It also leaves, per leaf i, the union of the block's leaves up to i (`pre`) and from i on
+//                        (`suf`) -- two 8-step scans in LDS.
+//   k_lbvh_bounds_super  union of every 64 blocks (a wave per super-block).
+//   k_lbvh_bounds_cross  a thread per inner node whose range [a, b] crosses block boundaries (a few per cent of them):
+//                        suf[a] U whole blocks U whole super-blocks U whole blocks U pre[b].
+constexpr uint32_t kBoundsBlock = 256;
+constexpr uint32_t kBoundsSuper = 64;       // blocks per super-block
+
+struct LbvhBox { float mn[3], mx[3]; };
+
+__device__ __forceinline__ void lbvh_merge(f3& mn, f3& mx, const f3& omn, const f3& omx)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mn = mk3(fminf(mn.x, omn.x), fminf(mn.y, omn.y), fminf(mn.z, omn.z));
+    mx = mk3(fmaxf(mx.x, omx.x), fmaxf(mx.y, omx.y), fmaxf(mx.z, omx.z));
+}
+__device__ __forceinline__ void lbvh_merge(f3& mn, f3& mx, const LbvhBox& b)
+{
+    lbvh_merge(mn, mx, mk3(b.mn[0], b.mn[1], b.mn[2]), mk3(b.mx[0], b.mx[1], b.mx[2]));
+}
+__device__ __forceinline__ void lbvh_store(LbvhBox& b, const f3& mn, const f3& mx)
+{
+    b.mn[0] = mn.x; b.mn[1] = mn.y; b.mn[2] = mn.z; b.mx[0] = mx.x; b.mx[1] = mx.y; b.mx[2] = mx.z;
 }
 
-// computeBoudingBox, LBVHBuilder.cu:533-680.  `arrived` [n-1] is zero on entry.
-__global__ __launch_bounds__(256) void k_lbvh_bounds(uint32_t n, LbvhTopo t, const uint32_t* __restrict__ sorted_indices,
-                                                     const atn_triangle_param* __restrict__ tris, const float4* __restrict__ vtx, int32_t vtx_offset,
-                                                     atn_bvh_node* out, uint32_t* arrived)
+__global__ __launch_bounds__(kBoundsBlock) void k_lbvh_bounds_block(uint32_t n, LbvhTopo t, const uint32_t* __restrict__ sorted_indices,
+                                                                    const atn_triangle_param* __restrict__ tris, const float4* __restrict__ vtx,
+                                                                    int32_t vtx_offset, atn_bvh_node* out, uint32_t* arrived,
+                                                                    LbvhBox* __restrict__ pre, LbvhBox* __restrict__ suf)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
-    if (i >= num) return;
-    f3 mn, mx;
-    lbvh_triangle_box(tris, vtx, vtx_offset, sorted_indices[i], mn, mx);
+    __shared__ float sc[2][6][kBoundsBlock];     // [prefix | suffix][component][leaf]
+    const int32_t tid = threadIdx.x, i = blockIdx.x * kBoundsBlock + tid, num = (int32_t)n;
+    const int32_t blk_lo = blockIdx.x * kBoundsBlock, blk_hi = blk_lo + (int32_t)kBoundsBlock - 1;
+    const bool valid = i < num;
+    f3 mn = mk3(INFINITY), mx = mk3(-INFINITY);
+    if (valid) lbvh_triangle_box(tris, vtx, vtx_offset, sorted_indices[i], mn, mx);
+    for (int s = 0; s < 2; s++) {
+        sc[s][0][tid] = mn.x; sc[s][1][tid] = mn.y; sc[s][2][tid] = mn.z;
+        sc[s][3][tid] = mx.x; sc[s][4][tid] = mx.y; sc[s][5][tid] = mx.z;
+    }
+    __syncthreads();
+    for (int32_t d = 1; d < (int32_t)kBoundsBlock; d <<= 1) {
+        float v[2][6];
+        const bool lo_ok = tid >= d, hi_ok = tid + d < (int32_t)kBoundsBlock;
+        for (int c = 0; c < 6; c++) {
+            v[0][c] = lo_ok ? sc[0][c][tid - d] : sc[0][c][tid];
+            v[1][c] = hi_ok ? sc[1][c][tid + d] : sc[1][c][tid];
+        }
+        __syncthreads();
+        for (int c = 0; c < 3; c++) {
+            sc[0][c][tid] = fminf(sc[0][c][tid], v[0][c]); sc[0][c + 3][tid] = fmaxf(sc[0][c + 3][tid], v[0][c + 3]);
+            sc[1][c][tid] = fminf(sc[1][c][tid], v[1][c]); sc[1][c + 3][tid] = fmaxf(sc[1][c + 3][tid], v[1][c + 3]);
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    lbvh_store(pre[i], mk3(sc[0][0][tid], sc[0][1][tid], sc[0][2][tid]), mk3(sc[0][3][tid], sc[0][4][tid], sc[0][5][tid]));
+    lbvh_store(suf[i], mk3(sc[1][0][tid], sc[1][1][tid], sc[1][2][tid]), mk3(sc[1][3][tid], sc[1][4][tid], sc[1][5][tid]));
+    // the reference's climb, inside the block
     int32_t cur = i + num - 1;
     for (;;) {
         atn_bvh_node& g = out[cur];
         g.boxmin[0] = mn.x; g.boxmin[1] = mn.y; g.boxmin[2] = mn.z;
         g.boxmax[0] = mx.x; g.boxmax[1] = mx.y; g.boxmax[2] = mx.z;
         const int32_t p = t.parent[cur];
-        if (p < 0) return;
-        __threadfence();                                    // my box before my arrival
-        if (atomicAdd(&arrived[p], 1u) == 0u) return;       // the sibling subtree is not finished: its thread goes on
-        __threadfence();
-        const int32_t other = t.left[p] == cur ? t.right[p] : t.left[p];
-        const atn_bvh_node& o = out[other];
-        mn = mk3(fminf(mn.x, lbvh_ld_coherent(&o.boxmin[0])), fminf(mn.y, lbvh_ld_coherent(&o.boxmin[1])), fminf(mn.z, lbvh_ld_coherent(&o.boxmin[2])));
-        mx = mk3(fmaxf(mx.x, lbvh_ld_coherent(&o.boxmax[0])), fmaxf(mx.y, lbvh_ld_coherent(&o.boxmax[1])), fmaxf(mx.z, lbvh_ld_coherent(&o.boxmax[2])));
+        if (p < 0 || t.first[p] < blk_lo || t.last[p] > blk_hi) return;        // the root, or a node of k_lbvh_bounds_cross
+        if (__hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) return;
+        const atn_bvh_node& o = out[t.left[p] == cur ? t.right[p] : t.left[p]];
+        lbvh_merge(mn, mx, mk3(o.boxmin[0], o.boxmin[1], o.boxmin[2]), mk3(o.boxmax[0], o.boxmax[1], o.boxmax[2]));
         cur = p;
     }
 }
 
-// Byte offset of every node's device record, walk (pre-)order from `base`.
-__global__ __launch_bounds__(256) void k_lbvh_layout(uint32_t n, LbvhTopo t, uint32_t base, uint32_t* __restrict__ offs)
+// sup[s] = union of blocks [64 s, 64 s + 63]; a block's union is the `pre` of its last leaf
+__global__ __launch_bounds__(64) void k_lbvh_bounds_super(uint32_t n, const LbvhBox* __restrict__ pre, LbvhBox* __restrict__ sup)
 {
-    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
-    if (idx >= 2 * num - 1) return;
-    const uint32_t a = idx >= num - 1 ? (uint32_t)(idx - (num - 1)) : (uint32_t)t.first[idx];
-    uint32_t lefts = 0;
-    for (int32_t cur = idx;;) {
-        const int32_t p = t.parent[cur];
-        if (p < 0) break;
-        lefts += t.left[p] == cur ? 1u : 0u;
-        cur = p;
-    }
-    offs[idx] = base + kInnerBytes * (a + lefts) + kTriLeafBytes * a;
+    const uint32_t n_blocks = (n + kBoundsBlock - 1) / kBoundsBlock;
+    const uint32_t blk = blockIdx.x * kBoundsSuper + threadIdx.x;
+    f3 mn = mk3(INFINITY), mx = mk3(-INFINITY);
+    if (blk < n_blocks) lbvh_merge(mn, mx, pre[min(blk * kBoundsBlock + kBoundsBlock - 1, n - 1)]);
+    for (int d = 32; d > 0; d >>= 1)
+        lbvh_merge(mn, mx, mk3(__shfl_xor(mn.x, d), __shfl_xor(mn.y, d), __shfl_xor(mn.z, d)), mk3(__shfl_xor(mx.x, d), __shfl_xor(mx.y, d), __shfl_xor(mx.z, d)));
+    if (threadIdx.x == 0) lbvh_store(sup[blockIdx.x], mn, mx);
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_bounds_cross(uint32_t n, LbvhTopo t, const LbvhBox* __restrict__ pre, const LbvhBox* __restrict__ suf,
+                                                           const LbvhBox* __restrict__ sup, atn_bvh_node* __restrict__ out)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx + 1 >= n) return;
+    const uint32_t a = (uint32_t)t.first[idx], b = (uint32_t)t.last[idx];
+    const uint32_t A = a / kBoundsBlock, B = b / kBoundsBlock;
+    if (A == B) return;
+    f3 mn = mk3(INFINITY), mx = mk3(-INFINITY);
+    lbvh_merge(mn, mx, suf[a]);
+    lbvh_merge(mn, mx, pre[b]);
+    uint32_t x = A + 1;                                        // whole blocks x .. B - 1
+    auto block_box = [&](uint32_t blk) -> const LbvhBox& { return pre[min(blk * kBoundsBlock + kBoundsBlock - 1, n - 1)]; };
+    for (; x < B && (x % kBoundsSuper) != 0; x++) lbvh_merge(mn, mx, block_box(x));
+    for (; x + kBoundsSuper <= B; x += kBoundsSuper) lbvh_merge(mn, mx, sup[x / kBoundsSuper]);
+    for (; x < B; x++) lbvh_merge(mn, mx, block_box(x));
+    atn_bvh_node& g = out[idx];
+    g.boxmin[0] = mn.x; g.boxmin[1] = mn.y; g.boxmin[2] = mn.z;
+    g.boxmax[0] = mx.x; g.boxmax[1] = mx.y; g.boxmax[2] = mx.z;
 }
 
 __global__ __launch_bounds__(256) void k_lbvh_emit(uint32_t n, const atn_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ offs,

@@ -2,7 +2,7 @@
 idaten::LBVHBuilder (oracle/orc_lbvh.h; src/libidaten/kernel/LBVHBuilder.cu, MortonCode.cuh).
 
   * the node array -- Morton codes, the stable key / value sort, Karras' hierarchy, hit / miss links, boxes -- is
-    BYTE-equal to the oracle's for triangle soups from 2 to 300 000 triangles, with heavy key duplication, a flat
+    BYTE-equal to the oracle's for triangle soups from 2 to 1 200 000 triangles, with heavy key duplication, a flat
     (zero-size) axis, non-zero triangle-id and vertex offsets;
   * the deformation sequence of src/deformation_renderer/main.cpp:636-710 (new vertices -> LBVH into the renderer's node
     list -> updateGeometry -> updateBVH): after an in-place device rebuild the closest-hit records are byte-equal to the
@@ -52,7 +52,7 @@ def soup(n, seed, kind="random"):
 
 
 @pytest.mark.parametrize("n,kind", [(2, "random"), (3, "random"), (7, "random"), (64, "random"), (257, "random"), (4097, "random"),
-                                    (100_000, "random"), (300_000, "random"), (5000, "clustered"), (70_000, "clustered"), (3000, "flat")])
+                                    (100_000, "random"), (300_000, "random"), (1_200_000, "random"), (5000, "clustered"), (70_000, "clustered"), (3000, "flat")])
 def test_lbvh_nodes_byte_equal(gpu, orc, n, kind):
     tris, pos = soup(n, n, kind)
     bmin, bmax = pos[:, :3].min(0), pos[:, :3].max(0)

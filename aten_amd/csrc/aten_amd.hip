@@ -75,7 +75,7 @@ public:
     int env_shade_items = 0, env_flavour = -1;
 
     // scene (HBM-resident after UpdateSceneData)
-    DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint;
+    DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint, shade_tris;
     DevBuf<atn_triangle_param> tris;
     DevBuf<atn_object_param> objects;
     DevBuf<DevMaterial> materials;
@@ -272,9 +272,14 @@ public:
         ATN_HIP(texels.upload(img.texels, stream));
         ATN_HIP(texels8.upload(img.texels8, stream));
         ATN_HIP(textures.upload(img.textures, stream));
+        ATN_HIP(shade_tris.resize((size_t)kShadeTriQuads * (img.tris.size() ? img.tris.size() : 1)));
+        if (!img.tris.empty())
+            hipLaunchKernelGGL(k_pack_shade_tris, dim3(((uint32_t)img.tris.size() + 255) / 256), dim3(256), 0, stream, (const atn_triangle_param*)tris.p,
+                               (const float4*)vtx_pos.p, (const float4*)vtx_nml.p, 0u, (uint32_t)img.tris.size(), shade_tris.p);
+        ATN_HIP(hipGetLastError());
         ATN_HIP(hipStreamSynchronize(stream));      // `img` is pageable host memory
         scene = img.params;
-        scene.nodes = nodes.p; scene.tris = tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
+        scene.nodes = nodes.p; scene.tris = tris.p; scene.shade_tris = shade_tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         has_scene = true;
@@ -432,7 +437,18 @@ public:
         if (n_vtx && pos) ATN_HIP(hipMemcpyAsync(vtx_pos.p + vtx_offset, pos, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
         if (n_vtx && nml) ATN_HIP(hipMemcpyAsync(vtx_nml.p + vtx_offset, nml, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
         if (n_tr) ATN_HIP(hipMemcpyAsync(tris.p + tri_offset, tr, (size_t)n_tr * sizeof(atn_triangle_param), hipMemcpyHostToDevice, stream));
+        // which triangles use the new vertices is not known here: repack every shading record (a copy of the scene arrays)
+        { int r = repack_shade_tris(0, n_scene_tris); if (r) return r; }
         ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;
+    }
+
+    int repack_shade_tris(uint32_t first, uint32_t count)
+    {
+        if (!count) return ATN_OK;
+        hipLaunchKernelGGL(k_pack_shade_tris, dim3((count + 255) / 256), dim3(256), 0, stream, (const atn_triangle_param*)tris.p,
+                           (const float4*)vtx_pos.p, (const float4*)vtx_nml.p, first, count, shade_tris.p);
+        ATN_HIP(hipGetLastError());
         return ATN_OK;
     }
 
@@ -538,6 +554,8 @@ public:
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
         { int q = quiesce(); if (q) return q; }
+        // a caller may have written the scene arrays in place (atn_scene_device_arrays): refresh this mesh's shading records
+        { int r = repack_shade_tris(tri_offset, n); if (r) return r; }
         { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list]); if (r) return r; }
         const uint32_t nn = 2 * n - 1;
         hipLaunchKernelGGL(k_lbvh_emit, dim3((nn + 255) / 256), dim3(256), 0, stream, n, (const atn_bvh_node*)lb.ref_nodes.p, (const uint32_t*)lb.offs.p,

@@ -429,7 +429,7 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
                 const int32_t tri_id = __float_as_int(is4.w);
                 HitRec rec;
                 evaluate_hit(rec, sc, hit_objid, tri_id, is4.y, is4.z);
-                const int32_t mtrlid = sc.tris[tri_id].mtrlid;
+                const int32_t mtrlid = triangle_mtrlid(sc, tri_id);
 
                 const bool isBackfacing = dot(rec.normal, -ray_dir) < 0.0F;
                 f3 orienting_normal = rec.normal;
@@ -648,7 +648,7 @@ struct ShadowJob {
             // anyway: only then is the material worth a look.  (A walk that stopped early -- fetch -- is never
             // `visible` and has a budget of one, so `h` is the exact closest hit whenever it matters.)
             if (visible || max_lookups > 1u) {
-                const int32_t mid = sc.tris[h.tri].mtrlid;
+                const int32_t mid = triangle_mtrlid(sc, h.tri);
                 const uint32_t mattr = mid >= 0 ? sc.materials[mid].attrib : 0u;
                 bool ignore = need_stencil && (mattr & kAttrStencilStencil);
                 f3 hit_p = mk3(0.0F), hit_n = mk3(0.0F, 1.0F, 0.0F);
@@ -938,4 +938,23 @@ __global__ void __launch_bounds__(256) k_compact_append(const int32_t* __restric
     }
 }
 
+} // namespace atn
+
+namespace atn {
+// scene_dev.hpp's packed per-triangle shading record, (re)built on the device from the scene arrays
+__global__ __launch_bounds__(256) void k_pack_shade_tris(const atn_triangle_param* __restrict__ tris, const float4* __restrict__ vtx_pos,
+                                                         const float4* __restrict__ vtx_nml, uint32_t first, uint32_t count, float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t t = first + i;
+    const float4* tp = reinterpret_cast<const float4*>(&tris[t]);
+    const float4 h0 = tp[0], h1 = tp[1];
+    const int32_t i0 = __float_as_int(h0.x), i1 = __float_as_int(h0.y), i2 = __float_as_int(h0.z);
+    float4* q = out + (size_t)kShadeTriQuads * t;
+    q[0] = vtx_pos[i0]; q[1] = vtx_pos[i1]; q[2] = vtx_pos[i2];
+    q[3] = vtx_nml[i0]; q[4] = vtx_nml[i1]; q[5] = vtx_nml[i2];
+    q[6] = h1;
+    q[7] = make_float4(h0.x, h0.y, h0.z, 0.0F);
+}
 } // namespace atn

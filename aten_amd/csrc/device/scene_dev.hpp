@@ -31,6 +31,7 @@ constexpr int32_t kLinkTypeMask = 3;
 constexpr uint32_t kLinkOffsetMask = ~15u;
 constexpr uint32_t kInnerBytes = 32;
 constexpr uint32_t kTriLeafBytes = 48;
+constexpr uint32_t kShadeTriQuads = 8;
 #ifndef ATN_TREELET_BYTES
 #define ATN_TREELET_BYTES 0      /* measured on MI355X: the LDS copy loses to the L1; > 0 re-enables it */
 #endif
@@ -70,6 +71,10 @@ struct DevTexture {
 struct DevScene {
     const float4* nodes;                // byte image of the BVH records (see above)
     const atn_triangle_param* tris;     // 32 B each (ids / needNormal / mtrlid / mesh_id)
+    const float4* shade_tris;           // kShadeTriQuads float4 per triangle: everything a HIT needs in one 128-byte line
+                                        //   {p0,u0} {p1,u1} {p2,u2} {n0,v0} {n1,v1} {n2,v2} {area, needNormal, mtrlid, mesh_id} {idx0..2, 0}
+                                        // (k_pack_shade_tris): one aligned line instead of the dependent gathers
+                                        // TriangleParameter -> 3 x position -> 3 x normal, seven lines in the worst case
     const float4* vtx_pos;              // (pos.xyz, u)
     const float4* vtx_nml;              // (nml.xyz, v)
     const atn_object_param* objects;

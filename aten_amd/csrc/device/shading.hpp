@@ -19,6 +19,11 @@ ATN_DEV m4 load_m4(const DevScene& sc, int32_t elem) // element index of a mat4
     return m;
 }
 
+ATN_DEV int32_t triangle_mtrlid(const DevScene& sc, int32_t tri_id)
+{
+    return __float_as_int(sc.shade_tris[(size_t)kShadeTriQuads * (uint32_t)tri_id + 6].z);
+}
+
 // evaluate_hit_result (geometry/EvaluateHitResult.h:10-72) -> PolygonObject::evaluate_hit_result
 // (geometry/PolygonObject.h:37-72) -> triangle::EvaluateHitResult (geometry/triangle.h:69-120)
 ATN_DEV void evaluate_hit(HitRec& rec, const DevScene& sc, int32_t objid, int32_t tri_id, float a, float b)
@@ -30,12 +35,11 @@ ATN_DEV void evaluate_hit(HitRec& rec, const DevScene& sc, int32_t objid, int32_
     m4 L2W = m4_identity();
     if (mtx_id >= 0) L2W = load_m4(sc, mtx_id);
 
-    // TriangleParameter = two 16-byte halves {idx[3], pad}{area, needNormal, mtrlid, mesh_id}: only the
-    // first half and needNormal are needed here
-    const int4 tidx = *reinterpret_cast<const int4*>(&sc.tris[tri_id]);
-    const int32_t need_normal = sc.tris[tri_id].needNormal;
-    const float4 p0 = sc.vtx_pos[tidx.x], p1 = sc.vtx_pos[tidx.y], p2 = sc.vtx_pos[tidx.z];
-    const float4 n0 = sc.vtx_nml[tidx.x], n1 = sc.vtx_nml[tidx.y], n2 = sc.vtx_nml[tidx.z];
+    // the triangle's packed record (scene_dev.hpp): the vertices' own float4s, copied
+    const float4* st = sc.shade_tris + (size_t)kShadeTriQuads * (uint32_t)tri_id;
+    const float4 p0 = st[0], p1 = st[1], p2 = st[2];
+    const float4 n0 = st[3], n1 = st[4], n2 = st[5];
+    const int32_t need_normal = __float_as_int(st[6].y);
     const float c = 1 - a - b;
 
     float4 P = add4(add4(mul4(c, p0), mul4(a, p1)), mul4(b, p2));

@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experiment", default="", help="traffic experiments on the sponza scene, not a benchmark configuration: "
+                    "'notex' (no textures), 'noibl' (white background instead of the environment map), 'notex,noibl'")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="consecutive frames enqueued on rotating banks of path state and streams (atn_set_frames_in_flight): "
@@ -207,8 +209,11 @@ def main():
 
     W, H, spp, depth, rr = args.width, args.height, args.spp, args.depth, 3
     if args.scene == "sponza":
-        fs, cam = scenedefs.sponza_lod()
+        ex = set(x for x in args.experiment.split(",") if x)
+        fs, cam = scenedefs.sponza_lod(textures="notex" not in ex, ibl="noibl" not in ex)
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh (stand-in for missing sponza.obj)" % (W, H, spp, depth)
+        if ex:
+            workload += " EXPERIMENT " + "+".join(sorted(ex))
     elif args.scene == "atrium":
         fs, cam = scenedefs.atrium()
         workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; stand-in for the missing "

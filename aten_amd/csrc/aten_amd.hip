@@ -81,6 +81,9 @@ public:
     DevBuf<DevMaterial> materials;
     DevBuf<atn_light_param> lights;
     DevBuf<DevTexture> textures;
+    DevBuf<atn_toon_param> toon;
+    DevBuf<atn_light_param> npr_lights;
+    DevBuf<float> screen_shadow;
     DevBuf<uint32_t> texels8;
     DevScene scene{};
     bool has_scene = false, has_camera = false;
@@ -268,6 +271,9 @@ public:
         ATN_HIP(matrices.upload(img.matrices, stream));
         ATN_HIP(materials.upload(img.materials, stream));
         ATN_HIP(carpaint.upload(img.carpaint, stream));
+        ATN_HIP(toon.upload(img.toon, stream));
+        ATN_HIP(npr_lights.upload(img.npr_lights, stream));
+        ATN_HIP(screen_shadow.upload(img.screen_shadow, stream));
         ATN_HIP(lights.upload(img.lights, stream));
         ATN_HIP(texels.upload(img.texels, stream));
         ATN_HIP(texels8.upload(img.texels8, stream));
@@ -281,6 +287,7 @@ public:
         scene = img.params;
         scene.nodes = nodes.p; scene.tris = tris.p; scene.shade_tris = shade_tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
+        scene.toon = toon.p; scene.npr_lights = npr_lights.p; scene.screen_shadow = img.screen_shadow.empty() ? nullptr : screen_shadow.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         has_scene = true;
         env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;
@@ -717,7 +724,8 @@ public:
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
         case 0: hipLaunchKernelGGL((k_shade<SVGF, 0>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         case 1: hipLaunchKernelGGL((k_shade<SVGF, 1>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-        default: hipLaunchKernelGGL((k_shade<SVGF, 2>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        case 2: hipLaunchKernelGGL((k_shade<SVGF, 2>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        default: hipLaunchKernelGGL((k_shade<SVGF, 3>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         }
     }
 

@@ -12,6 +12,7 @@
 // 269-366 and pathtracing_impl.h) -- NOT of the CUDA backend, which re-seeds CMJ per bounce.
 #pragma once
 #include "shading.hpp"
+#include "toon.hpp"
 
 namespace atn {
 
@@ -436,7 +437,20 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
 
                 // FillMaterial (material_impl.h:232-262): a negative id selects the white-diffuse fallback, which
                 // the upload appends after the last real material
-                const DevMaterial& m = sc.materials[mtrlid >= 0 ? mtrlid : sc.n_materials];
+                const DevMaterial* mp = &sc.materials[mtrlid >= 0 ? mtrlid : sc.n_materials];
+                DevMaterial toon_base;      // material set 3: a toon surface deeper in the path is its base material
+                bool toon_first_hit = false;
+                if (MS >= 3 && (mp->type == ATN_MTRL_TOON || mp->type == ATN_MTRL_STYLIZED_BRDF)) {
+                    // PathTracing::shade, pathtracing.cpp:160-184.  toon_type is Diffuse or Specular, so the reference's
+                    // `is_singular = (toon_type == ToonSpecular)` is always false: an ideal mirror that NEE treats as non-singular
+                    toon_first_hit = bounce == 0;
+                    toon_base = *mp;
+                    const int32_t tt = sc.toon[mtrlid >= 0 ? mtrlid : sc.n_materials].toon_type;
+                    toon_base.type = tt == ATN_MTRL_DIFFUSE ? ATN_MTRL_DIFFUSE : ATN_MTRL_SPECULAR;
+                    toon_base.attrib = (toon_base.attrib & ~(uint32_t)ATN_MTRL_ATTR_SINGULAR) | (tt == ATN_MTRL_TOON_SPECULAR ? ATN_MTRL_ATTR_SINGULAR : 0u);
+                    if (!toon_first_hit) mp = &toon_base;
+                }
+                const DevMaterial& m = *mp;
                 float4 albedo4;
                 if (SVGF) {
                     int32_t albedo_map = m.albedoMap;
@@ -458,6 +472,17 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
                 const f3 albedo = mk3(albedo4);
 
                 bool shaded_out = false;
+                if (MS >= 3 && toon_first_hit) {
+                    // HitTeminatedMaterial, pathtracing_impl.h:482-503: "treat toon as a light" -- the stylised colour is the
+                    // path's contribution and the path ends (what PathTracing::shade still computes after it --
+                    // pathtracing.cpp:174-184 -- is never observed: HitShadowRay and the next bounce skip terminated paths)
+                    int32_t px = 0, py = 0;
+                    slot_to_pixel(fp, slot, px, py);
+                    const f3 toon = toon_bsdf(sc, m, mtrlid >= 0 ? mtrlid : sc.n_materials, smp, rec.p, rec.normal, ray_dir, rec.u, rec.v, px, py);
+                    contrib_add = (throughput * toon) * albedo; contrib_changed = true;
+                    flags |= F_TERMINATED;
+                    shaded_out = true;
+                }
                 // HitTeminatedMaterial -> HitImplicitLight, pathtracing_impl.h:395-509
                 if (m.type == ATN_MTRL_EMISSIVE && (m.attrib & ATN_MTRL_ATTR_EMISSIVE) && !isBackfacing) {
                     // an emissive surface that is not registered as a light (light_id < 0) has no LightParameter to

@@ -80,6 +80,11 @@ struct DevScene {
     const atn_object_param* objects;
     const float4* matrices;             // 4 rows per mat4
     const DevMaterial* materials;
+    const atn_toon_param* toon;         // one per material (+ the fallback): ToonParameter (material.h:124-161), material set 3
+    const atn_light_param* npr_lights;  // context::GetNprTargetLight
+    const float* screen_shadow;         // context::screen_space_texture, x channel, [ss_h][ss_w]; null = 1.0
+    int32_t n_npr_lights, ss_w, ss_h;
+    int32_t enable_shadowray_base_stylized_shadow;
     const float4* carpaint;             // 4 per material: CarPaintMaterialParameter (the union member of MaterialParameter, material.h:163-176)
     const atn_light_param* lights;
     const float4* texels;
@@ -97,7 +102,7 @@ struct DevScene {
     int32_t enable_env_map;
     int32_t any_alpha;          // some material carries kAttrMaybeAlpha or kAttrStencilStencil: a shadow-ray hit may be "ignored"
     int32_t enable_alpha_blending;      // scene_rendering_config.enable_alpha_blending
-    int32_t material_set;               // 0 = BASELINE BSDFs only, 1 = + the other analytic ones, 2 = + CarPaint: which k_shade is launched
+    int32_t material_set;               // 0 = BASELINE BSDFs only, 1 = + the other analytic ones, 2 = + CarPaint, 3 = + Toon / StylizedBrdf: which k_shade is launched
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS

@@ -230,10 +230,8 @@ ATN_DEV f3 ggx_dir(float r1, float r2, float roughness, const f3& wi, const f3& 
 {
     return reflect_vector(wi, ggx_sample_m(roughness, n, r1, r2));
 }
-ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo)
+ATN_DEV f3 ggx_brdf_h(float roughness, float ior, const f3& N, const f3& V, const f3& L, const f3& H)     // ComputeBRDFWithHalfVector
 {
-    const f3 V = -wi, L = wo;
-    const f3 H = normalize(L + V);
     const float NL = fabsf(dot(N, L));
     const float NV = fabsf(dot(N, V));
     const float D = ggx_D(H, N, roughness);
@@ -242,6 +240,32 @@ ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const
     const float denom = (4 * NL) * NV;
     const float bsdf = denom > kEps ? ((F * G) * D) / denom : 0.0f;
     return mk3(bsdf);
+}
+ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo)
+{
+    const f3 V = -wi, L = wo;
+    return ggx_brdf_h(roughness, ior, N, V, L, normalize(L + V));
+}
+
+// ToonSpecular (material/toon.cpp:288-367): GGX with the "stylized highlight" half vector; a material type that only
+// Toon::ComputeBRDF creates.  Material set 3.
+ATN_DEV float sign_of(float f) { return f == 0.0F ? 0.0F : (f > 0.0F ? 1.0F : -1.0F); }      // aten::sign, math/math.h:62-73
+ATN_DEV f3 toon_specular_half(const atn_toon_param& tp, const f3& N, const f3& V, const f3& L)
+{
+    f3 H = normalize(L + V);
+    f3 t, b;
+    tangent_coordinate(N, t, b);
+    H = (H + tp.highlight.translation_dt * t) + tp.highlight.translation_db * b;
+    H = normalize(H);
+    H = (H - (tp.highlight.scale_t * dot(H, t)) * t) - (tp.highlight.scale_b * dot(H, b)) * b;
+    H = normalize(H);
+    H = (H - (tp.highlight.split_t * sign_of(dot(H, t))) * t) - (tp.highlight.split_b * sign_of(dot(H, b))) * b;
+    H = normalize(H);
+    const float sqrnorm_t = sinf(powf(acosf(dot(H, t)), tp.highlight.square_sharp));
+    const float sqrnorm_b = sinf(powf(acosf(dot(H, b)), tp.highlight.square_sharp));
+    H = H - tp.highlight.square_magnitude * (((sqrnorm_t * dot(H, t)) * t) + ((sqrnorm_b * dot(H, b)) * b));
+    H = normalize(H);
+    return H;
 }
 ATN_DEV float ggx_roughness(const DevScene& sc, const DevMaterial& m, float u, float v)
 {
@@ -1139,6 +1163,10 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
                            int32_t mtrl_id = 0)
 {
     if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) return carpaint_pdf(carpaint_params(sc, mtrl_id), normal, wi, wo);
+    if (MS >= 3 && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputePDF, toon.cpp:288-301
+        const f3 V = -wi;
+        return ggx_pdf_h(m.roughness, normal, toon_specular_half(sc.toon[mtrl_id], normal, V, wo), wo);
+    }
     if (MS >= 1) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: return 1.0F;
@@ -1163,6 +1191,11 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
 {
     MtrlSample r; r.pdf = 0.0F; r.dir = wo; r.bsdf = mk3(0.0F);
     if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) { r.bsdf = carpaint_bsdf(sc, m, carpaint_params(sc, mtrl_id), normal, wi, wo, u, v, pre_r); return r; }
+    if (MS >= 3 && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputeBRDF, toon.cpp:303-322
+        const f3 V = -wi;
+        r.bsdf = ggx_brdf_h(m.roughness, m.ior, normal, V, wo, toon_specular_half(sc.toon[mtrl_id], normal, V, wo));
+        return r;
+    }
     if (MS >= 1) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); return r;
@@ -1428,8 +1461,10 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
 template <int MS = 2>
 ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
-                          float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F)
+                          float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F,
+                          float* weight_ptr = nullptr)
 {
+    if (weight_ptr) *weight_ptr = 0.0F;
     const float cosShadow = dot(nml, ls.dir);
     float path_pdf = material_pdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id);
     const MtrlSample ev = material_bsdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id, pre_r);
@@ -1445,6 +1480,7 @@ ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& n
         const float misW = is_singular ? 1.0f : f / (f + path_pdf);
         const float G = isInfinite ? cosShadow * cosLight : (cosShadow * cosLight) / dist2;
         out = ((((misW * ev.bsdf) * ls.color) * G) / ls.pdf) / light_select_prob;
+        if (weight_ptr) *weight_ptr = (misW / ls.pdf) / light_select_prob;      // pathtracing_nee_impl.h:87-89
         return true;
     }
     return false;

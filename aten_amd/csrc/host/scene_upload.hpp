@@ -23,6 +23,9 @@ struct HostSceneImage {
     std::vector<float4> matrices;
     std::vector<DevMaterial> materials;
     std::vector<float4> carpaint;
+    std::vector<atn_toon_param> toon;           // per material + the fallback slot
+    std::vector<atn_light_param> npr_lights;
+    std::vector<float> screen_shadow;
     std::vector<atn_light_param> lights;
     std::vector<float4> texels;
     std::vector<uint32_t> texels8;
@@ -391,11 +394,36 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     p.any_alpha = 0;
     for (const DevMaterial& dm : img.materials) if (dm.attrib & (kAttrMaybeAlpha | kAttrStencilStencil)) p.any_alpha = 1;
     p.enable_alpha_blending = s->config.enable_alpha_blending ? 1 : 0;
+    // NPR: ToonParameter per material, the target lights, the screen-space shadow texture (x channel)
+    img.toon.assign((size_t)s->n_materials + 1, atn_toon_param{});
+    for (uint32_t i = 0; i < s->n_materials; i++) {
+        img.toon[i] = s->materials[i].toon;
+        const int32_t t = s->materials[i].type;
+        if (t == ATN_MTRL_TOON || t == ATN_MTRL_STYLIZED_BRDF) {
+            const atn_toon_param& tp = img.toon[i];
+            if (tp.target_light_idx >= 0 && (uint32_t)tp.target_light_idx >= s->n_npr_target_lights) { err = "toon material's target light index out of range"; return false; }
+            if (tp.target_light_idx >= 0 && !s->npr_target_lights) { err = "null NPR target light array"; return false; }
+        }
+    }
+    if (s->n_npr_target_lights && s->npr_target_lights) {
+        img.npr_lights.assign(s->npr_target_lights, s->npr_target_lights + s->n_npr_target_lights);
+        for (const atn_light_param& l : img.npr_lights)
+            if (l.arealight_objid >= 0 && (uint32_t)l.arealight_objid >= s->n_objects) { err = "NPR target light refers to an object id out of range"; return false; }
+    }
+    p.n_npr_lights = (int32_t)img.npr_lights.size();
+    p.enable_shadowray_base_stylized_shadow = s->enable_shadowray_base_stylized_shadow ? 1 : 0;
+    p.ss_w = p.ss_h = 0;
+    if (s->screen_space_texture.texels && s->screen_space_texture.width > 0 && s->screen_space_texture.height > 0) {
+        p.ss_w = s->screen_space_texture.width; p.ss_h = s->screen_space_texture.height;
+        const size_t n = (size_t)p.ss_w * p.ss_h;
+        img.screen_shadow.resize(n);
+        for (size_t i = 0; i < n; i++) img.screen_shadow[i] = s->screen_space_texture.texels[i].x;
+    }
     p.material_set = 0;
     for (const DevMaterial& dm : img.materials) {
         const int32_t t = dm.type;
         const bool core = t == ATN_MTRL_EMISSIVE || t == ATN_MTRL_DIFFUSE || t == ATN_MTRL_SPECULAR || t == ATN_MTRL_GGX || t == ATN_MTRL_DISNEY;
-        const int32_t need = t == ATN_MTRL_CARPAINT ? 2 : (core ? 0 : 1);
+        const int32_t need = (t == ATN_MTRL_TOON || t == ATN_MTRL_STYLIZED_BRDF) ? 3 : (t == ATN_MTRL_CARPAINT ? 2 : (core ? 0 : 1));
         if (need > p.material_set) p.material_set = need;
     }
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /

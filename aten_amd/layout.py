@@ -34,12 +34,24 @@ TRIANGLE_PARAM = np.dtype([
 STANDARD_FIELDS = ["ior", "roughness", "shininess", "subsurface", "metallic", "specular",
                    "specularTint", "anisotropic", "sheen", "sheenTint", "clearcoat", "clearcoatGloss"]
 
+# aten::ToonParameter, 100 B (material.h:124-161)
+TOON_PARAM = np.dtype([
+    ("target_light_idx", i4), ("remap_texture", i4), ("stylized_y_min", f4), ("stylized_y_max", f4),
+    ("toon_type", i4), ("will_receive_shadow", np.uint8), ("_pad0", np.uint8, 3),
+    ("translation_dt", f4), ("translation_db", f4), ("scale_t", f4), ("scale_b", f4),
+    ("split_t", f4), ("split_b", f4), ("square_sharp", f4), ("square_magnitude", f4),
+    ("rim_width", f4), ("rim_softness", f4), ("rim_enable", np.uint8), ("_pad1", np.uint8, 3),
+    ("rim_color", f4, 3), ("rim_spread", f4),
+    ("shadow_threshold", f4), ("shadow_offset", f4), ("shadow_scale", f4), ("shadow_enable", np.uint8), ("_pad2", np.uint8, 3),
+])
+assert TOON_PARAM.itemsize == 100
+
 MATERIAL_PARAM = np.dtype([
     ("baseColor", f4, 4), ("type", i4), ("attrib", u4),
     ("id", np.uint16), ("isIdealRefraction", np.uint8), ("is_medium", np.uint8),
     ("albedoMap", i4), ("normalMap", i4), ("roughnessMap", i4), ("stencil_type", i4),
     ("standard", f4, 12), ("_union_tail", f4, 4),
-    ("medium", f4, 8), ("toon", np.uint8, 100), ("feature_line", np.uint8, 8),
+    ("medium", f4, 8), ("toon", TOON_PARAM), ("feature_line", np.uint8, 8),
 ])
 
 LIGHT_PARAM = np.dtype([
@@ -76,6 +88,7 @@ OBJ_POLYGONS, OBJ_INSTANCE, OBJ_SPHERE = 0, 1, 2
 (MTRL_EMISSIVE, MTRL_DIFFUSE, MTRL_OREN_NAYAR, MTRL_SPECULAR, MTRL_REFRACTION, MTRL_GGX,
  MTRL_BECKMAN, MTRL_VELVET, MTRL_MICROFACET_REFRACTION, MTRL_RETROREFLECTIVE, MTRL_CARPAINT,
  MTRL_DISNEY, MTRL_TOON, MTRL_STYLIZED) = range(14)
+MTRL_TOON_SPECULAR = 16
 ATTR_EMISSIVE, ATTR_SINGULAR, ATTR_TRANSLUCENT, ATTR_GLOSSY = 1, 2, 4, 8
 # aten::MaterialAttribute* constants, src/libaten/material/material.h:34-39
 MTRL_ATTRIB = {
@@ -127,6 +140,8 @@ class SceneDesc(C.Structure):
         ("textures", C.c_void_p), ("n_textures", C.c_uint32), ("_p7", C.c_uint32),
         ("config", SceneRenderingConfig),
         ("scene_bbox_min", C.c_float * 3), ("scene_bbox_max", C.c_float * 3),
+        ("npr_target_lights", C.c_void_p), ("n_npr_target_lights", C.c_uint32),
+        ("enable_shadowray_base_stylized_shadow", C.c_int32), ("screen_space_texture", TextureDesc),
     ]
 
 

@@ -61,6 +61,9 @@ class SceneBuilder:
         self.objects = []       # dict: type, ...
         self.matrices = []      # 4x4 f32
         self.lights = []
+        self.npr_lights = []
+        self.screen_space_texture = None    # float32 [h, w, 4]: context::screen_space_texture
+        self.enable_shadowray_base_stylized_shadow = True
         self.blas = {}          # polygon object id -> node array (or None = build)
         self.mesh_counter = 0
         self.config = L.SceneRenderingConfig()
@@ -105,6 +108,30 @@ class SceneBuilder:
         m["standard"] = v[:12]
         m["_union_tail"] = v[12:]
         return mid
+
+    def add_toon_material(self, name, base_color, stylized=False, toon_type=None, target_light_idx=-1, remap_texture=-1,
+                          albedo_map=-1, normal_map=-1, **p):
+        """aten::Toon / aten::StylizedBrdf (material/toon.h:20-34,80-90): ToonParameter with the defaults of material.h:124-161,
+        attrib = Diffuse's or Microfacet's by toon_type.  `p`: roughness / ior (standard part) and any TOON_PARAM field."""
+        toon_type = L.MTRL_DIFFUSE if toon_type is None else toon_type
+        std = {k: p.pop(k) for k in list(p) if k in L.STANDARD_FIELDS}
+        mid = self.add_material(name, L.MTRL_STYLIZED if stylized else L.MTRL_TOON, base_color, albedo_map=albedo_map,
+                                normal_map=normal_map, **std)
+        m = self.materials[mid][1]
+        m["attrib"] = 0 if toon_type == L.MTRL_DIFFUSE else L.ATTR_GLOSSY
+        t = m["toon"]
+        t["target_light_idx"], t["remap_texture"] = target_light_idx, remap_texture
+        t["stylized_y_min"], t["stylized_y_max"] = 0.0, 1.0
+        t["toon_type"], t["will_receive_shadow"] = toon_type, 1
+        t["shadow_threshold"], t["shadow_offset"], t["shadow_scale"] = 0.5, 0.05, 10.0
+        for k, v in p.items():
+            t[k] = v
+        return mid
+
+    def add_npr_target_light(self, light):
+        """context::AddNprTargetLight: a LightParameter toon materials aim at (ToonParameter::target_light_idx)."""
+        self.npr_lights.append(np.array(light, L.LIGHT_PARAM))
+        return len(self.npr_lights) - 1
 
     def find_material(self, name):
         for i, (n, _) in enumerate(self.materials):
@@ -526,7 +553,15 @@ class SceneBuilder:
         d.config = self.config
         d.scene_bbox_min[:] = [float(x) for x in smin]
         d.scene_bbox_max[:] = [float(x) for x in smax]
-        fs.keep = [objs, mtx, mats, lights, tris, pos, nml, bvh_lists, lists, texd, [t for _, t in self.textures]]
+        npr = (np.stack(self.npr_lights) if self.npr_lights else np.zeros(0, L.LIGHT_PARAM)).astype(L.LIGHT_PARAM)
+        d.npr_target_lights, d.n_npr_target_lights = L.ptr(npr), len(npr)
+        d.enable_shadowray_base_stylized_shadow = 1 if self.enable_shadowray_base_stylized_shadow else 0
+        sst = None
+        if self.screen_space_texture is not None:
+            sst = np.ascontiguousarray(self.screen_space_texture, F32)
+            d.screen_space_texture.texels = sst.ctypes.data
+            d.screen_space_texture.height, d.screen_space_texture.width = sst.shape[0], sst.shape[1]
+        fs.keep = [objs, mtx, mats, lights, tris, pos, nml, bvh_lists, lists, texd, [t for _, t in self.textures], npr, sst]
         fs.lists = lists
         fs.blas_index = dict(blas_index)      # polygon object id -> its node list
         fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lights, triangles=tris,

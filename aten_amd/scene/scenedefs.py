@@ -374,3 +374,68 @@ def deformable_room(t=0.0, asset_dir=None, **blob):
     b.set_background((0.0, 0.0, 0.0))
     cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)
     return b, oid, cam
+
+
+def toon_ramp(steps=(0.15, 0.45, 0.8, 1.0), width=64, tint=(1.0, 1.0, 1.0)):
+    """A 1-D remap texture (ToonParameter::remap_texture): `width` texels in `len(steps)` flat bands."""
+    t = np.ones((1, width, 4), np.float32)
+    for x in range(width):
+        b = steps[min(x * len(steps) // width, len(steps) - 1)]
+        t[0, x, :3] = [b * c for c in tint]
+    return t
+
+
+def toon_room(asset_dir=None, target="point", screen_shadow=None, alpha_blocker=False):
+    """The Cornell box with NPR materials (material/toon.cpp): the tall box is a Toon material of diffuse type, the short
+    box a StylizedBrdf of specular type with a stylised highlight and a rim light, the floor a Toon material of specular type;
+    all aim at ONE NPR target light (context::AddNprTargetLight) -- a point light, or the room's area light -- and the
+    area light still lights the rest of the room.  `screen_shadow` [h, w]: the screen-space shadow texture of the
+    stylized-shadow feature (enabled on the tall box when given)."""
+    asset_dir = asset_dir or os.path.join(ASSETS, "cornellbox")
+    b = SceneBuilder()
+    emit = b.add_material("light", L.MTRL_EMISSIVE, (1.0, 1.0, 1.0))
+    ramp = b.add_texture("ramp4", toon_ramp())
+    ramp_warm = b.add_texture("ramp3warm", toon_ramp((0.2, 0.6, 1.0), tint=(1.0, 0.85, 0.6)))
+
+    def create_mtrl(name, mtype, clr, albedo, nml):
+        if name == "tallBox":
+            extra = dict(shadow_enable=1, shadow_threshold=0.9, shadow_offset=0.05, shadow_scale=1.0) if screen_shadow is not None else {}
+            return b.add_toon_material(name, (0.9, 0.5, 0.4), target_light_idx=0, remap_texture=ramp, **extra)
+        if name == "shortBox":
+            return b.add_toon_material(name, (0.4, 0.6, 0.9), stylized=True, toon_type=L.MTRL_SPECULAR, target_light_idx=0,
+                                       remap_texture=ramp_warm, roughness=0.3, ior=1.5, stylized_y_min=0.05, stylized_y_max=0.6,
+                                       translation_dt=0.1, translation_db=-0.05, scale_t=0.2, scale_b=0.1, split_t=0.05, split_b=0.02,
+                                       square_sharp=0.7, square_magnitude=0.3,
+                                       rim_enable=1, rim_width=0.4, rim_softness=0.3, rim_color=(0.3, 0.5, 1.0), rim_spread=1.0)
+        if name == "floor":
+            return b.add_toon_material(name, (0.7, 0.7, 0.6), toon_type=L.MTRL_SPECULAR, target_light_idx=0, remap_texture=-1,
+                                       roughness=0.4, ior=1.4, will_receive_shadow=1)
+        return b.add_material(name, mtype, clr)
+
+    objs = b.load_obj(os.path.join(asset_dir, "orig.obj"), create_mtrl=create_mtrl, separate_objs=True, normal_on_the_fly=True)
+    light = b.create_instance(objs[0])
+    lid = b.add_area_light(light, b.materials[emit][1]["baseColor"][:3], 200.0)
+    for o in objs[1:]:
+        b.create_instance(o)
+    if alpha_blocker:
+        glass = b.add_material("pane", L.MTRL_DIFFUSE, (0.9, 0.9, 0.9, 0.5))
+        b.config.enable_alpha_blending = 1
+        q = np.array([[-0.6, 1.5, -0.4], [0.6, 1.5, -0.4], [0.6, 1.5, 0.6], [-0.6, 1.5, 0.6]], np.float32)
+        b.create_instance(b.add_mesh("pane", q, [[0, 1, 2], [0, 2, 3]], glass))
+    if target == "point":
+        l = np.zeros((), L.LIGHT_PARAM)
+        l["type"] = L.LIGHT_POINT; l["attrib"] = L.LATTR_SINGULAR
+        l["pos"] = [0.3, 1.7, 1.2, 1.0]; l["light_color"] = (1.0, 1.0, 1.0)
+        l["innerAngle"] = l["outerAngle"] = np.pi
+        l["scale"], l["intensity"] = 1.0, 4.0
+        l["arealight_objid"] = -1; l["envmapidx"] = -1
+        b.add_npr_target_light(l)
+    else:
+        b.add_npr_target_light(b.lights[lid])
+    if screen_shadow is not None:
+        sst = np.zeros(screen_shadow.shape + (4,), np.float32)
+        sst[..., 0] = screen_shadow
+        b.screen_space_texture = sst
+    b.set_background((0.0, 0.0, 0.0))
+    cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)
+    return b.build(), cam

@@ -79,7 +79,8 @@ enum {
     ATN_MTRL_EMISSIVE = 0, ATN_MTRL_DIFFUSE = 1, ATN_MTRL_OREN_NAYAR = 2, ATN_MTRL_SPECULAR = 3,
     ATN_MTRL_REFRACTION = 4, ATN_MTRL_GGX = 5, ATN_MTRL_BECKMAN = 6, ATN_MTRL_VELVET = 7,
     ATN_MTRL_MICROFACET_REFRACTION = 8, ATN_MTRL_RETROREFLECTIVE = 9, ATN_MTRL_CARPAINT = 10,
-    ATN_MTRL_DISNEY = 11, ATN_MTRL_TOON = 12, ATN_MTRL_STYLIZED_BRDF = 13, ATN_MTRL_TYPE_MAX = 14
+    ATN_MTRL_DISNEY = 11, ATN_MTRL_TOON = 12, ATN_MTRL_STYLIZED_BRDF = 13, ATN_MTRL_TYPE_MAX = 14,
+    ATN_MTRL_VOLUME = 15, ATN_MTRL_TOON_SPECULAR = 16   /* "specialized" types after MaterialTypeMax (material.h:59-63) */
 };
 /* MaterialAttribute bit-field (material.h:27-32), LSB first. */
 #define ATN_MTRL_ATTR_EMISSIVE    0x1u
@@ -91,6 +92,30 @@ typedef struct atn_standard_mtrl {   /* StandardMaterialParameter, 48 B (materia
     float ior, roughness, shininess, subsurface, metallic, specular;
     float specularTint, anisotropic, sheen, sheenTint, clearcoat, clearcoatGloss;
 } atn_standard_mtrl;
+
+/* aten::ToonParameter, 100 B (material.h:124-161); bools are one byte followed by padding */
+typedef struct atn_toon_param {
+    int32_t target_light_idx;      /*   0: index into the scene's NPR target lights (context::GetNprTargetLight), -1 = none */
+    int32_t remap_texture;         /*   4 */
+    float stylized_y_min;          /*   8 */
+    float stylized_y_max;          /*  12 */
+    int32_t toon_type;             /*  16: ATN_MTRL_DIFFUSE or ATN_MTRL_SPECULAR */
+    uint8_t will_receive_shadow;   /*  20 */
+    uint8_t _pad0[3];
+    struct {                       /*  24: Hightlight */
+        float translation_dt, translation_db, scale_t, scale_b, split_t, split_b, square_sharp, square_magnitude;
+    } highlight;
+    struct {                       /*  56: RimLight */
+        float width, softness;
+        uint8_t enable; uint8_t _pad[3];
+        float color[3];
+        float spread;
+    } rim_light;
+    struct {                       /*  84: StylizedShadow */
+        float threshold, offset, scale;
+        uint8_t enable; uint8_t _pad[3];
+    } stylized_shadow;
+} atn_toon_param;
 
 typedef struct atn_material_param {
     atn_vec4 baseColor;            /*   0 */
@@ -108,7 +133,7 @@ typedef struct atn_material_param {
         float carpaint[16];
     } u;
     float medium[8];               /* 108, MediumParameter 32 B */
-    uint8_t toon[100];             /* 140, ToonParameter 100 B (not on this path) */
+    atn_toon_param toon;           /* 140, ToonParameter 100 B */
     uint8_t feature_line[8];       /* 240 */
 } atn_material_param;
 
@@ -222,6 +247,11 @@ typedef struct atn_scene_desc {
     atn_scene_rendering_config config;
     float scene_bbox_min[3];   /* ctxt.GetSceneBoundingBox() (host_scene_context.h:586-590) */
     float scene_bbox_max[3];
+    /* ---- NPR (Toon / StylizedBrdf materials, material/toon.cpp); all may be left zero */
+    const atn_light_param* npr_target_lights;   /* context::GetNprTargetLightParameters (host_scene_context.cpp:76-86) */
+    uint32_t n_npr_target_lights;
+    int32_t enable_shadowray_base_stylized_shadow;   /* context member, host_scene_context.h:50 (default true there) */
+    atn_texture_desc screen_space_texture;      /* context::GetScreenSpaceTextureAt reads .x of texel (x, y); texels NULL = 1.0 */
 } atn_scene_desc;
 
 #ifdef __cplusplus
@@ -244,6 +274,8 @@ static_assert(offsetof(atn_material_param, stencil_type) == 40, "MaterialParamet
 static_assert(offsetof(atn_material_param, u) == 44, "MaterialParameter.standard");
 static_assert(offsetof(atn_material_param, medium) == 108, "MaterialParameter.medium");
 static_assert(offsetof(atn_material_param, toon) == 140, "MaterialParameter.toon");
+static_assert(sizeof(atn_toon_param) == 100, "ToonParameter");
+static_assert(offsetof(atn_toon_param, highlight) == 24 && offsetof(atn_toon_param, rim_light) == 56 && offsetof(atn_toon_param, stylized_shadow) == 84, "ToonParameter members");
 static_assert(offsetof(atn_material_param, feature_line) == 240, "MaterialParameter.feature_line");
 static_assert(sizeof(atn_light_param) == 80, "LightParameter");
 static_assert(offsetof(atn_light_param, type) == 32, "LightParameter.type");

@@ -104,6 +104,15 @@ struct Scene {
     v4 GetNormalAsVec4(uint32_t i) const { const auto& p = d->vtx_nml[i]; return v4(p.x, p.y, p.z, p.w); }
     const atn_bvh_node* GetBvhNodes(uint32_t list) const { return d->bvh_lists[list].nodes; }
     const atn_scene_rendering_config& cfg() const { return d->config; }
+    // context::GetNprTargetLight (scene/host_scene_context.cpp:70-74)
+    const atn_light_param& GetNprTargetLight(uint32_t i) const { return d->npr_target_lights[i]; }
+    // context::GetScreenSpaceTextureAt (host_scene_context.h:611-617) -> texture::AtByXY(x, y).x (image/texture.cpp:36-60)
+    float GetScreenSpaceTextureAt(int32_t x, int32_t y) const
+    {
+        const atn_texture_desc& t = d->screen_space_texture;
+        if (t.texels && t.width > 0 && t.height > 0) return t.texels[(uint32_t)(y * t.width + x)].x;
+        return 1.0F;
+    }
 };
 
 // ---------------------------------------------------------------------------------------

@@ -1116,6 +1116,42 @@ inline void sample(MaterialSampling& result, const Scene& ctxt, const atn_materi
 
 // ---- dispatch: material/material_impl.h:24-206 (types outside the BASELINE configs fall
 //      to the reference's own default branch: Diffuse) --------------------------------------
+// ToonSpecular (material/toon.cpp:288-367, toon_specular.h): GGX evaluated with a "stylized highlight" half vector
+// (Anjyo & Hiramitsu); a material TYPE that only Toon::ComputeBRDF creates, for pdf / bsdf evaluation.
+namespace ToonSpecular {
+inline float sign(float f) { return f == 0.0F ? 0.0F : (f > 0.0F ? 1.0F : -1.0F); }     // math/math.h:62-73
+inline v3 ComputeHalfVector(const atn_material_param& param, const v3& N, const v3& V, const v3& L)
+{
+    const auto& h = param.toon.highlight;
+    v3 H = normalize(L + V);
+    v3 t, b;
+    GetTangentCoordinate(N, t, b);
+    H = H + h.translation_dt * t + h.translation_db * b;
+    H = normalize(H);
+    H = H - h.scale_t * dot(H, t) * t - h.scale_b * dot(H, b) * b;
+    H = normalize(H);
+    H = H - h.split_t * sign(dot(H, t)) * t - h.split_b * sign(dot(H, b)) * b;
+    H = normalize(H);
+    const float sqrnorm_t = std::sin(std::pow(std::acos(dot(H, t)), h.square_sharp));
+    const float sqrnorm_b = std::sin(std::pow(std::acos(dot(H, b)), h.square_sharp));
+    H = H - h.square_magnitude * (sqrnorm_t * dot(H, t) * t + sqrnorm_b * dot(H, b) * b);
+    H = normalize(H);
+    return H;
+}
+inline float ComputePDF(const atn_material_param& param, const v3& normal, const v3& wi, const v3& wo)
+{
+    const v3 V = -wi, L = wo, N = normal;
+    const v3 H = ComputeHalfVector(param, N, V, L);
+    return GGX::ComputePDFWithHalfVector(param.u.standard.roughness, N, H, L);
+}
+inline v3 ComputeBRDF(const atn_material_param& param, const v3& normal, const v3& wi, const v3& wo)
+{
+    const v3 V = -wi, L = wo, N = normal;
+    const v3 H = ComputeHalfVector(param, N, V, L);
+    return GGX::ComputeBRDFWithHalfVector(param.u.standard.roughness, param.u.standard.ior, N, V, L, H);
+}
+} // namespace ToonSpecular
+
 inline void sampleMaterial(MaterialSampling* result, const Scene& ctxt, const atn_material_param* mtrl,
     const v3& normal, const v3& wi, CMJ* sampler, float u, float v, float pre_sampled_r = 0.0F)
 {
@@ -1152,6 +1188,7 @@ inline float samplePDF(const Scene& ctxt, const atn_material_param* mtrl, const 
     case ATN_MTRL_DISNEY: return Disney::pdf(*mtrl, normal, wi, wo);
     case ATN_MTRL_RETROREFLECTIVE: return Retroreflective::pdf(*mtrl, normal, wi, wo);
     case ATN_MTRL_CARPAINT: return CarPaint::pdf(*mtrl, normal, wi, wo);
+    case ATN_MTRL_TOON_SPECULAR: return ToonSpecular::ComputePDF(*mtrl, normal, wi, wo);       // material_impl.h:135-137
     default: return Diffuse::ComputePDF(normal, wo);
     }
 }
@@ -1170,6 +1207,7 @@ inline MaterialSampling sampleBSDF(const Scene& ctxt, const atn_material_param* 
     case ATN_MTRL_DISNEY: r = Disney::bsdf(*mtrl, normal, wi, wo); break;
     case ATN_MTRL_RETROREFLECTIVE: r = Retroreflective::bsdf(*mtrl, normal, wi, wo); break;
     case ATN_MTRL_CARPAINT: r.bsdf = CarPaint::bsdf(ctxt, *mtrl, normal, wi, wo, u, v, pre_sampled_r); break;
+    case ATN_MTRL_TOON_SPECULAR: r.bsdf = ToonSpecular::ComputeBRDF(*mtrl, normal, wi, wo); break;     // material_impl.h:196-198
     default: r.bsdf = Diffuse::ComputeBRDF(); break;
     }
     return r;
@@ -1500,6 +1538,7 @@ struct PathState {
     v3 contrib{ 0.0F }; float samples{ 0 };
     bool isHit{ false }, is_terminated{ false }, is_singular{ false };
     int32_t last_hit_mtrl_idx{ -1 };
+    int32_t screen_space_x{ 0 }, screen_space_y{ 0 };       // PathAttribute, pt_params.h:69-70
     CMJ sampler;
 };
 struct ShadowRay {
@@ -1528,14 +1567,16 @@ inline void GeneratePath(Ray& generated_ray, int32_t ix, int32_t iy, int32_t sam
     path.pdfb = 1.0f;
     path.isHit = false; path.is_terminated = false; path.is_singular = false;
     path.last_hit_mtrl_idx = -1;
+    path.screen_space_x = ix; path.screen_space_y = iy;     // pathtracing_impl.h:106-107
     path.samples += 1;
 }
 
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
 inline bool ComputeRadianceNEE(v3& out, const Scene& ctxt, const v3& wi, const v3& surface_nml,
     const atn_material_param& surface_mtrl, float hit_u, float hit_v, float light_select_prob,
-    const LightSampleResult& ls, float pre_sampled_random = 0.0F)
+    const LightSampleResult& ls, float pre_sampled_random = 0.0F, float* weight_ptr = nullptr)
 {
+    if (weight_ptr) *weight_ptr = 0.0F;
     float cosShadow = dot(surface_nml, ls.dir);
     float path_pdf = samplePDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v);
     MaterialSampling ev = sampleBSDF(ctxt, &surface_mtrl, surface_nml, wi, ls.dir, hit_u, hit_v, pre_sampled_random);
@@ -1553,6 +1594,7 @@ inline bool ComputeRadianceNEE(v3& out, const Scene& ctxt, const v3& wi, const v
         float misW = is_singular ? 1.0f : (ls.pdf * light_select_prob) / ((ls.pdf * light_select_prob) + path_pdf);
         const float G = isInfinite ? cosShadow * cosLight : cosShadow * cosLight / dist2;
         out = (misW * bsdf * emit * G / ls.pdf) / light_select_prob;
+        if (weight_ptr) *weight_ptr = misW / ls.pdf / light_select_prob;     // pathtracing_nee_impl.h:87-89
         return true;
     }
     return false;
@@ -1595,15 +1637,10 @@ inline void FillShadowRay(ShadowRay& shadow_ray, const Scene& ctxt, PathState& p
 // surface_stencil_type: stencil_type of the material at the SHADED point (pathtracing.cpp:59-66 passes
 // ctxt.GetMaterial(isect.mtrlid)); ALWAYS raises the lookup budget to 10 and makes STENCIL surfaces transparent to
 // the shadow ray; scene_rendering_config.enable_alpha_blending raises it to 10 as well.
-inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& shadow_ray, int32_t surface_stencil_type,
-    PathCounters* cnt)
+// HitTestToTargetLight, pathtracing_impl.h:266-365
+inline bool HitTestToTargetLight(const Scene& ctxt, const Ray& original_ray, const atn_light_param& light, float distToLight,
+    int32_t surface_stencil_type, PathCounters* cnt)
 {
-    if (path.is_terminated) return false;
-    if (!shadow_ray.isActive) return false;
-    const auto& light = ctxt.GetLight(shadow_ray.targetLightId);
-    const float distToLight = shadow_ray.distToLight;
-    const Ray original_ray(shadow_ray.rayorg, shadow_ray.raydir);
-
     const bool valid_obj = (light.type == ATN_LIGHT_AREA) && light.arealight_objid >= 0;
     const int32_t lightobj = valid_obj ? light.arealight_objid : -1;
     int32_t hitobj = lightobj;      // kept across lookups, like the reference's pointer (:291)
@@ -1648,10 +1685,135 @@ inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& sh
         else is_hit_to_light = false;
         break;
     }
+    return is_hit_to_light;
+}
 
+inline bool HitShadowRay(const Scene& ctxt, PathState& path, const ShadowRay& shadow_ray, int32_t surface_stencil_type,
+    PathCounters* cnt)
+{
+    if (path.is_terminated) return false;
+    if (!shadow_ray.isActive) return false;
+    const auto& light = ctxt.GetLight(shadow_ray.targetLightId);
+    const Ray original_ray(shadow_ray.rayorg, shadow_ray.raydir);
+    const bool is_hit_to_light = HitTestToTargetLight(ctxt, original_ray, light, shadow_ray.distToLight, surface_stencil_type, cnt);
     if (is_hit_to_light) path.contrib += shadow_ray.lightcontrib;
     return is_hit_to_light;
 }
+
+// ---------------------------------------------------------------------------------------
+// Toon / StylizedBrdf, material/toon.cpp:88-286,371-445.  "Terminated" materials (material.h:583-588): at bounce 0 the
+// path tracer treats them as a light (HitTeminatedMaterial, pathtracing_impl.h:482-503) whose colour is Toon::bsdf --
+// a one-sample NEE towards ONE designated target light (with its own visibility test), quantised through a 1-D remap
+// texture, times a screen-space shadow texture, plus a rim light.
+// ---------------------------------------------------------------------------------------
+namespace Toon {
+inline float bezier_smoothstep(float edge0, float edge1, float mid, float t, float s)   // toon.cpp:222-239
+{
+    if (t <= edge0) return 0;
+    else if (t >= edge1) return 1;
+    t = (t - edge0) / (edge1 - edge0);
+    t *= s;
+    float B0 = 0.0F, B1 = mid, B2 = 1.0F;
+    float P = (B0 - 2 * B1 + B2) * t * t + (-2 * B0 + 2 * B1) * t + B0;
+    return P;
+}
+inline v3 ComputeRimLight(const atn_material_param& param, const v3& normal, const v3& wi)     // toon.cpp:243-286
+{
+    v3 c(0.0F);
+    const v3 V = -wi, N = normal;
+    if (param.toon.rim_light.enable) {
+        const float NdotV = dot(V, N);
+        if (NdotV > 0) {
+            const float rim = bezier_smoothstep(1.0F - param.toon.rim_light.width, 1.0F, (1 - param.toon.rim_light.softness) * 0.5F,
+                1 - NdotV, param.toon.rim_light.spread);
+            c += rim * v3(param.toon.rim_light.color[0], param.toon.rim_light.color[1], param.toon.rim_light.color[2]);
+        }
+    }
+    return c;
+}
+inline atn_material_param base_material(const atn_material_param& param)        // toon.cpp:184-190,390-396
+{
+    atn_material_param base_mtrl = param;
+    base_mtrl.type = param.toon.toon_type == ATN_MTRL_DIFFUSE ? ATN_MTRL_DIFFUSE : ATN_MTRL_TOON_SPECULAR;
+    return base_mtrl;
+}
+// Toon::ComputeBRDF, toon.cpp:163-218
+inline void ComputeBRDF(v3& toon_term, float& remap_v, const Scene& ctxt, const atn_material_param& param,
+    const LightSampleResult* sampled_light, const v3& normal, const v3& wi, float u, float v)
+{
+    v3 radiance(0.0F);
+    if (sampled_light) {
+        const atn_material_param base_mtrl = base_material(param);
+        v3 res;
+        if (ComputeRadianceNEE(res, ctxt, wi, normal, base_mtrl, u, v, 1.0F, *sampled_light, 0.0F)) radiance = res;
+    }
+    float lum_y = clamp_(luminance(radiance), 0.0F, 1.0F);
+    lum_y = clamp_(std::pow(lum_y, 1.0F / 2.2F), 0.0F, 1.0F);
+    const v4 remap = sampleTexture(ctxt, param.toon.remap_texture, lum_y, 0.5F, v4(1.0F));
+    toon_term = remap.xyz();
+    remap_v = lum_y;
+}
+// StylizedBrdf::ComputeBRDF, toon.cpp:373-445
+inline void Stylized_ComputeBRDF(v3& toon_term, float& remap_v, const Scene& ctxt, const atn_material_param& param,
+    const LightSampleResult* sampled_light, const v3& normal, const v3& wi, float u, float v)
+{
+    v3 radiance(0.0F);
+    float pdf = 1.0F;
+    if (sampled_light) {
+        const atn_material_param base_mtrl = base_material(param);
+        float nee_weight = 0.0F;
+        v3 res;
+        if (ComputeRadianceNEE(res, ctxt, wi, normal, base_mtrl, u, v, 1.0F, *sampled_light, 0.0F, &nee_weight)) {
+            radiance = res;
+            pdf = 1.0F / nee_weight;
+        }
+    }
+    constexpr float W_MIN = 0.01F;
+    // color::sRGBtoXYZ (misc/color.h:75-88): only Y is used
+    const float y = dot(v3(0.212639F, 0.71517F, 0.0721926F), radiance);
+    const float weight = fmax_(y, W_MIN);
+    const float y_min = fmax_(0.0F, fmin_(param.toon.stylized_y_min, param.toon.stylized_y_max));
+    const float y_max = fmax_(param.toon.stylized_y_min, param.toon.stylized_y_max);
+    float rv = 0.0F;
+    if (y_max <= y) rv = 1.0F;
+    else if (y <= y_min) rv = 0.0F;
+    else rv = (y - y_min) / (y_max - y_min);
+    const v4 remap = sampleTexture(ctxt, param.toon.remap_texture, rv, 0.5F, v4(radiance.x, radiance.y, radiance.z, 0.0F));
+    toon_term = weight * remap.xyz() * pdf;
+    remap_v = rv;
+}
+// Toon::bsdf, toon.cpp:88-161
+inline v3 bsdf(const Scene& ctxt, const atn_material_param& param, PathState& path, const v3& hit_pos, const v3& normal,
+    const v3& wi, float u, float v, PathCounters* cnt)
+{
+    const atn_light_param* target_light = (param.toon.target_light_idx >= 0 && (uint32_t)param.toon.target_light_idx < ctxt.d->n_npr_target_lights)
+        ? &ctxt.GetNprTargetLight((uint32_t)param.toon.target_light_idx) : nullptr;     // (the reference asserts the range)
+    v3 toon_term(0.0F);
+    float remap_v = 1.0F;
+    if (target_light) {
+        LightSampleResult light_sample;
+        Light_sample(light_sample, *target_light, ctxt, hit_pos, normal, &path.sampler);
+        const Ray r(hit_pos, light_sample.dir, normal);
+        bool is_hit_to_target_light = true;
+        if (param.toon.will_receive_shadow)
+            is_hit_to_target_light = HitTestToTargetLight(ctxt, r, *target_light, light_sample.dist_to_light, param.stencil_type, cnt);
+        if (param.type == ATN_MTRL_TOON)
+            ComputeBRDF(toon_term, remap_v, ctxt, param, is_hit_to_target_light ? &light_sample : nullptr, normal, wi, u, v);
+        else if (param.type == ATN_MTRL_STYLIZED_BRDF)
+            Stylized_ComputeBRDF(toon_term, remap_v, ctxt, param, is_hit_to_target_light ? &light_sample : nullptr, normal, wi, u, v);
+    }
+    if (param.toon.stylized_shadow.enable) {
+        float shadow = ctxt.GetScreenSpaceTextureAt(path.screen_space_x, path.screen_space_y);
+        if (remap_v >= param.toon.stylized_shadow.threshold) shadow = 1.0F;
+        else {
+            const float offset = param.toon.stylized_shadow.offset, scale = param.toon.stylized_shadow.scale;
+            shadow = fmin_(fmax_(shadow * (remap_v + offset) * scale, shadow), 1.0F);
+        }
+        toon_term = toon_term * shadow;
+    }
+    return toon_term + ComputeRimLight(param, normal, wi);
+}
+} // namespace Toon
 
 // HitImplicitLight, pathtracing_impl.h:395-451
 inline bool HitImplicitLight(const Scene& ctxt, int32_t hit_obj_id, bool is_back_facing, int32_t bounce,
@@ -1742,9 +1904,31 @@ inline void shade(PathState& path, const Scene& ctxt, Ray& ray, ShadowRay& shado
     // alpha_blend.transmission == 1, alpha_blend.throughput == 0 on this path (:145)
     albedo = 1.0F * albedo + v4(v3(0.0F));
 
-    // HitTeminatedMaterial, pathtracing_impl.h:453-509 (Toon/Stylized out of scope)
+    // HitTeminatedMaterial, pathtracing_impl.h:453-509, and what PathTracing::shade does with its answer
+    // (pathtracing.cpp:160-184)
+    const bool is_toon_mtrl = mtrl.type == ATN_MTRL_TOON || mtrl.type == ATN_MTRL_STYLIZED_BRDF;
+    bool is_hit_implicit_light = false;
     if (mtrl.type == ATN_MTRL_EMISSIVE) {
-        if (HitImplicitLight(ctxt, isect.objid, isBackfacing, bounce, path, ray_in, rec, mtrl)) return;
+        is_hit_implicit_light = HitImplicitLight(ctxt, isect.objid, isBackfacing, bounce, path, ray_in, rec, mtrl);
+    }
+    else if (is_toon_mtrl) {
+        if (bounce == 0) {
+            // "treat toon as a light": the stylised colour is the path's contribution and the path ends
+            const v3 toon_bsdf = Toon::bsdf(ctxt, mtrl, path, rec.p, rec.normal, ray_in.dir, rec.u, rec.v, cnt);
+            path.contrib += path.throughput * toon_bsdf * albedo.xyz();
+            path.is_terminated = true;
+        }
+        is_hit_implicit_light = true;
+    }
+    if (is_hit_implicit_light) {
+        if (is_toon_mtrl && (bounce > 0 || ctxt.d->enable_shadowray_base_stylized_shadow)) {
+            // deeper in the path a toon surface is its plain base material.  toon_type is Diffuse or Specular, so the
+            // comparison with ToonSpecular below is always false: an ideal mirror that NEE treats as non-singular
+            mtrl.type = mtrl.toon.toon_type == ATN_MTRL_DIFFUSE ? ATN_MTRL_DIFFUSE : ATN_MTRL_SPECULAR;
+            const bool sing = mtrl.toon.toon_type == ATN_MTRL_TOON_SPECULAR;
+            mtrl.attrib = (mtrl.attrib & ~(uint32_t)ATN_MTRL_ATTR_SINGULAR) | (sing ? ATN_MTRL_ATTR_SINGULAR : 0u);
+        }
+        else return;
     }
 
     if (!attr_translucent(mtrl) && isBackfacing) orienting_normal = -orienting_normal;

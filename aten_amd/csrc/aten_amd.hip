@@ -1721,6 +1721,6 @@ int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* ou
 
 uint32_t atn_sizeof_scene_desc(void) { return (uint32_t)sizeof(atn_scene_desc); }
 uint32_t atn_sizeof_destination(void) { return (uint32_t)sizeof(atn_destination); }
-uint32_t atn_abi_version(void) { return 1; }
+uint32_t atn_abi_version(void) { return 2; }     // 2: atn_scene_desc grew the NPR fields (r02); atn_toon_param spelled out
 
 } // extern "C"

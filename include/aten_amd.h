@@ -296,7 +296,7 @@ int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags
 /* ABI self-description for binding checks. */
 uint32_t atn_sizeof_scene_desc(void);
 uint32_t atn_sizeof_destination(void);
-uint32_t atn_abi_version(void);
+uint32_t atn_abi_version(void);         /* 2 since atn_scene_desc carries the NPR fields (zero = none); check with atn_sizeof_scene_desc */
 
 #ifdef __cplusplus
 }

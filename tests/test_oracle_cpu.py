@@ -305,6 +305,18 @@ def test_layout_sizes_match_c_header():
     assert l.atn_sizeof_destination() == C.sizeof(Destination)
 
 
+def test_headers_compile_as_c99_and_cxx17(tmp_path):
+    """include/*.h is the drop-in boundary: plain C (a cgo / ctypes / C caller) and C++ (the aten application) both
+    compile it, warnings as errors, and the static layout checks hold."""
+    import subprocess
+    src = ('#include "aten_amd.h"\n#include "aten_amd_scene.h"\n'
+           'int main(void) { atn_scene_desc d; atn_destination t; (void)d; (void)t; return (int)sizeof(atn_toon_param) - 100; }\n')
+    for name, cmd in (("h.c", ["gcc", "-std=c99", "-pedantic"]), ("h.cpp", ["g++", "-std=c++17"])):
+        f = tmp_path / name
+        f.write_text(src)
+        subprocess.check_call(cmd + ["-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(f), "-o", str(f) + ".o"])
+
+
 def test_c_abi_exports_every_declared_symbol():
     """Every function declared in include/aten_amd.h / aten_amd_scene.h is exported (no compute calls)."""
     import re

@@ -43,6 +43,46 @@ class FlatScene:
     def ref(self):
         return C.byref(self.desc)
 
+    @staticmethod
+    def from_arrays(objects, matrices, materials, lights, triangles, vtx_pos, vtx_nml, bvh_lists, config=None,
+                    scene_bbox=None, textures=()):
+        """Wrap flat arrays somebody else produced (e.g. a C++ application's dump) in an atn_scene_desc."""
+        fs = FlatScene()
+        objs = np.ascontiguousarray(objects, L.OBJECT_PARAM); mats = np.ascontiguousarray(materials, L.MATERIAL_PARAM)
+        lts = np.ascontiguousarray(lights, L.LIGHT_PARAM); tris = np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
+        mtx = np.ascontiguousarray(matrices, F32).reshape(-1, 4, 4)
+        pos = np.ascontiguousarray(vtx_pos, F32).reshape(-1, 4); nml = np.ascontiguousarray(vtx_nml, F32).reshape(-1, 4)
+        nodes = [np.ascontiguousarray(n, L.BVH_NODE) for n in bvh_lists]
+        lists = (L.BvhList * len(nodes))()
+        for i, n in enumerate(nodes):
+            lists[i].nodes = n.ctypes.data
+            lists[i].count = len(n)
+        tex = [np.ascontiguousarray(t, F32) for t in textures]
+        texd = (L.TextureDesc * max(1, len(tex)))()
+        for i, t in enumerate(tex):
+            texd[i].texels = t.ctypes.data
+            texd[i].height, texd[i].width = t.shape[0], t.shape[1]
+        d = fs.desc
+        d.objects, d.n_objects = L.ptr(objs), len(objs)
+        d.matrices, d.n_matrices = L.ptr(mtx), len(mtx)
+        d.materials, d.n_materials = L.ptr(mats), len(mats)
+        d.lights, d.n_lights = L.ptr(lts), len(lts)
+        d.triangles, d.n_triangles = L.ptr(tris), len(tris)
+        d.vtx_pos, d.vtx_nml, d.n_vertices = L.ptr(pos), L.ptr(nml), len(pos)
+        d.bvh_lists, d.n_bvh_lists = C.addressof(lists), len(nodes)
+        d.textures, d.n_textures = C.addressof(texd), len(tex)
+        if config is not None:
+            d.config = config
+        if scene_bbox is not None:
+            d.scene_bbox_min[:] = [float(x) for x in scene_bbox[0]]
+            d.scene_bbox_max[:] = [float(x) for x in scene_bbox[1]]
+        d.enable_shadowray_base_stylized_shadow = 1
+        fs.keep = [objs, mtx, mats, lts, tris, pos, nml, nodes, lists, texd, tex]
+        fs.lists = lists
+        fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lts, triangles=tris, vtx_pos=pos, vtx_nml=nml,
+                         bvh_lists=nodes, textures=tex)
+        return fs
+
     def replace_bvh_list(self, k, nodes):
         """Swap node list k (e.g. for a tree built elsewhere over the same triangles)."""
         nodes = np.ascontiguousarray(nodes, L.BVH_NODE)

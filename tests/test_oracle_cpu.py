@@ -317,6 +317,23 @@ def test_headers_compile_as_c99_and_cxx17(tmp_path):
         subprocess.check_call(cmd + ["-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(f), "-o", str(f) + ".o"])
 
 
+def test_cxx_application_builds_and_fails_loudly_without_gpu(tmp_path):
+    """tests/cxx/aten_app.cpp (a C++ program on the C-ABI only) compiles warning-free against include/ and the in-tree
+    libraries; without a GPU atn_create must return an error code and a message -- there is no CPU fallback to fall to."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "aten_app")
+    lib = os.path.join(ROOT, "aten_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "aten_app.cpp"), "-L", lib, "-laten_amd", "-laten_amd_scene",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_cxx_app.py runs it")
+    res = subprocess.run([exe, str(tmp_path), "32", "32", "1"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 1
+    assert "atn_create" in res.stderr and "-2" in res.stderr          # ATN_ERR_NO_DEVICE
+
+
 def test_c_abi_exports_every_declared_symbol():
     """Every function declared in include/aten_amd.h / aten_amd_scene.h is exported (no compute calls)."""
     import re

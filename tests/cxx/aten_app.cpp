@@ -200,6 +200,85 @@ int main(int argc, char** argv)
     CHECK(atn_synchronize(ctx));
     // an error must come back as a code and a message, not as a crash
     if (atn_update_camera(ctx, nullptr) == ATN_OK || std::strlen(atn_last_error(ctx)) == 0) { std::fprintf(stderr, "null camera accepted\n"); return 1; }
+
+    // ---- the whole-node renderer (atn_mgpu_*): three shards sharing device 0 must give the same film, byte for byte
+    {
+        atn_mgpu* mg = nullptr;
+        const int32_t devs[3] = { 0, 0, 0 };
+        int rc = atn_mgpu_create(&mg, devs, 3);
+        if (rc != ATN_OK) { std::fprintf(stderr, "atn_mgpu_create -> %d\n", rc); return 1; }
+#define MCHECK(call) do { int rc_ = (call); if (rc_ != ATN_OK) { std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, atn_mgpu_last_error(mg)); return 1; } } while (0)
+        MCHECK(atn_mgpu_upload_scene(mg, &d));
+        MCHECK(atn_mgpu_update_camera(mg, &cam));
+        MCHECK(atn_mgpu_init_sampler(mg, W, H, 0));
+        MCHECK(atn_mgpu_set_frames_in_flight(mg, 2));
+        std::vector<atn_vec4> mfilm((size_t)W * H);
+        for (int32_t f = 0; f < frames; f++) {
+            atn_destination dst;
+            std::memset(&dst, 0, sizeof(dst));
+            dst.width = W; dst.height = H; dst.maxDepth = 5; dst.russianRouletteDepth = 3; dst.sample = 1; dst.frame = (uint32_t)f;
+            dst.progressive = 1; dst.break_on_terminate = 1;
+            MCHECK(atn_mgpu_render(mg, &dst, f + 1 == frames ? mfilm.data() : nullptr));
+        }
+        MCHECK(atn_mgpu_synchronize(mg));
+        if (atn_mgpu_shard_count(mg) != 3 || std::memcmp(mfilm.data(), film.data(), film.size() * sizeof(atn_vec4)) != 0) {
+            std::fprintf(stderr, "3-shard film differs from the single-context film\n"); return 1;
+        }
+        atn_mgpu_destroy(mg);
+    }
+    // ---- SVGF on the same context: two frames, finite output
+    {
+        std::vector<atn_vec4> den((size_t)W * H);
+        CHECK(atn_reset(ctx));
+        for (int32_t f = 0; f < 2; f++) {
+            atn_destination dst;
+            std::memset(&dst, 0, sizeof(dst));
+            dst.width = W; dst.height = H; dst.maxDepth = 5; dst.russianRouletteDepth = 3; dst.sample = 1; dst.frame = (uint32_t)f;
+            dst.break_on_terminate = 1;
+            CHECK(atn_svgf_render(ctx, &dst, /*compute_motion*/ 1, den.data(), nullptr));
+        }
+        double s = 0;
+        for (const auto& p : den) { if (!(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) { std::fprintf(stderr, "SVGF output has NaN\n"); return 1; } s += p.x + p.y + p.z; }
+        if (!(s > 0)) { std::fprintf(stderr, "SVGF output is black\n"); return 1; }
+    }
+    // ---- a deformation tick: the glossy panel (list 3: one quad = two triangles, three nodes) is moved, its list is
+    // rebuilt on the device (atn_lbvh_rebuild_list), the top layer re-sent; the hit records must see the new geometry
+    {
+        const uint32_t t0 = 10, n = 2, v0 = 30;          // the panel: triangles 10..11, vertices 30..35
+        for (uint32_t v = v0; v < v0 + 6; v++) { a.pos[v].x += 0.25F; a.pos[v].y += 0.1F; }
+        float mn[3] = { 1e30F, 1e30F, 1e30F }, mx[3] = { -1e30F, -1e30F, -1e30F };
+        for (uint32_t v = v0; v < v0 + 6; v++) {
+            const float q[3] = { a.pos[v].x, a.pos[v].y, a.pos[v].z };
+            for (int c = 0; c < 3; c++) { mn[c] = q[c] < mn[c] ? q[c] : mn[c]; mx[c] = q[c] > mx[c] ? q[c] : mx[c]; }
+        }
+        CHECK(atn_update_geometry(ctx, &a.pos[v0], &a.nml[v0], 6, v0, &a.tris[t0], n, t0));
+        CHECK(atn_lbvh_rebuild_list(ctx, 3, t0, n, mn, mx));
+        // the same builder as a function: 2 n - 1 nodes, leaves carry the scene's triangle ids
+        atn_bvh_node ln[3];
+        CHECK(atn_lbvh_build(ctx, &a.tris[t0], n, (int32_t)t0, mn, mx, a.pos.data(), (uint32_t)a.pos.size(), 0, ln, nullptr, nullptr));
+        if (!(ln[0].f0 < 0) || ln[1].f1 + ln[2].f1 != (float)(2 * t0 + 1)) { std::fprintf(stderr, "atn_lbvh_build: unexpected nodes\n"); return 1; }
+        // new top layer (the panel's box moved)
+        std::vector<float> boxes; std::vector<int32_t> oids, exids, mesh;
+        for (auto& it : a.insts) {
+            if (it.list == 3) { std::memcpy(it.mn, mn, sizeof(mn)); std::memcpy(it.mx, mx, sizeof(mx)); }
+            boxes.insert(boxes.end(), it.mn, it.mn + 3); boxes.insert(boxes.end(), it.mx, it.mx + 3);
+            oids.push_back(it.obj); exids.push_back(it.list); mesh.push_back(-1);
+        }
+        atn_bvh_node* nodes = nullptr; uint32_t cnt = 0;
+        if (atns_build_tlas(boxes.data(), oids.data(), exids.data(), mesh.data(), (uint32_t)a.insts.size(), &nodes, &cnt) != 0) return 2;
+        CHECK(atn_update_tlas(ctx, a.objs.data(), (uint32_t)a.objs.size(), a.mtxs.data(), (uint32_t)a.mtxs.size(), nodes, cnt));
+        atns_free(nodes);
+        // a ray straight at the panel's new centre
+        atn_ray r;
+        const float c3[3] = { 0.5F * (mn[0] + mx[0]), 0.5F * (mn[1] + mx[1]), 0.5F * (mn[2] + mx[2]) };
+        r.org[0] = c3[0]; r.org[1] = c3[1]; r.org[2] = 3.0F; r.dir[0] = 0; r.dir[1] = 0; r.dir[2] = -1;
+        atn_intersection is;
+        CHECK(atn_trace_closest(ctx, &r, 1, 1e-9F, 3.402823466e+38F, &is, nullptr));
+        if (is.objid != a.insts[2].obj || (is.tri_id != (int32_t)t0 && is.tri_id != (int32_t)t0 + 1)) {
+            std::fprintf(stderr, "after the tick the ray hits object %d triangle %d\n", is.objid, is.tri_id); return 1;
+        }
+        for (uint32_t v = v0; v < v0 + 6; v++) { a.pos[v].x -= 0.25F; a.pos[v].y -= 0.1F; }       // the dump below is the scene as rendered
+    }
     atn_destroy(ctx);
 
     dump(out, "objects.bin", a.objs.data(), a.objs.size() * sizeof(atn_object_param));

@@ -1,7 +1,9 @@
 """The drop-in boundary is C: tests/cxx/aten_app.cpp is a C++17 program that includes only include/*.h, links only
 libaten_amd.so / libaten_amd_scene.so, builds a scene with the host library, renders through atn_create / atn_upload_scene /
 atn_update_camera / atn_init_sampler / atn_render (the call sequence of INTEGRATION.md's adapter) and dumps what it built.
-The same arrays go to the CPU oracle; the films must agree."""
+The same arrays go to the CPU oracle; the films must agree.  The program then checks by itself: three atn_mgpu shards on one
+device give the same film byte for byte, atn_svgf_render gives a finite non-black image, and after a deformation tick
+(atn_update_geometry + atn_lbvh_rebuild_list + atn_update_tlas) a ray finds the moved panel."""
 import ctypes as C
 import glob
 import os

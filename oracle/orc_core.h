@@ -68,10 +68,15 @@ struct CMJ {
     // cmj.h:103-114 (both components; nextSample only uses .x)
     static void cmj(int32_t s, int32_t n, int32_t p, float& ox, float& oy)
     {
-        int32_t sx = permute(s % n, n, p * 0xa511e9b3);
-        int32_t sy = permute(s / n, n, p * 0x63d83595);
-        float jx = randfloat(s, p * 0xa399d265);
-        float jy = randfloat(s, p * 0x711ad6a5);
+        // The reference multiplies the int32_t `p` by literals: 0xa511e9b3 / 0xa399d265 do not fit an int, so those
+        // products are unsigned; 0x63d83595 / 0x711ad6a5 DO fit, so those two are int x int and overflow -- undefined
+        // behaviour that every compiler of the reference resolves as two's-complement wrap.  Spelled out here as the
+        // unsigned product (same bits, no UB; found by running this file under UBSan).
+        const uint32_t up = (uint32_t)p;
+        int32_t sx = permute(s % n, n, up * 0xa511e9b3u);
+        int32_t sy = permute(s / n, n, up * 0x63d83595u);
+        float jx = randfloat(s, up * 0xa399d265u);
+        float jy = randfloat(s, up * 0x711ad6a5u);
         ox = (s % n + (sy + jx) / n) / n;
         oy = (s / n + (sx + jy) / n) / n;
     }

@@ -498,7 +498,7 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
                 const DevMaterial* mp = &sc.materials[mtrlid >= 0 ? mtrlid : sc.n_materials];
                 DevMaterial toon_base;      // material set 3: a toon surface deeper in the path is its base material
                 bool toon_first_hit = false;
-                if (MS >= 3 && (mp->type == ATN_MTRL_TOON || mp->type == ATN_MTRL_STYLIZED_BRDF)) {
+                if (MS >= kMsToon && (mp->type == ATN_MTRL_TOON || mp->type == ATN_MTRL_STYLIZED_BRDF)) {
                     // PathTracing::shade, pathtracing.cpp:160-184.  toon_type is Diffuse or Specular, so the reference's
                     // `is_singular = (toon_type == ToonSpecular)` is always false: an ideal mirror that NEE treats as non-singular
                     toon_first_hit = bounce == 0;
@@ -530,7 +530,7 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
                 const f3 albedo = mk3(albedo4);
 
                 bool shaded_out = false;
-                if (MS >= 3 && toon_first_hit) {
+                if (MS >= kMsToon && toon_first_hit) {
                     // HitTeminatedMaterial, pathtracing_impl.h:482-503: "treat toon as a light" -- the stylised colour is the
                     // path's contribution and the path ends (what PathTracing::shade still computes after it --
                     // pathtracing.cpp:174-184 -- is never observed: HitShadowRay and the next bounce skip terminated paths)
@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
     f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
     const f3 WI = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
     // CarPaint: material::applyNormal runs first, as in shade (it draws the shared random number and may swap the normal)
-    const float pre_r = m.type == ATN_MTRL_CARPAINT ? apply_normal<2>(sc, m, mtrl_id, N, uv[2 * i], uv[2 * i + 1], WI, s) : 0.0F;
+    const float pre_r = m.type == ATN_MTRL_CARPAINT ? apply_normal<kMsCarPaint>(sc, m, mtrl_id, N, uv[2 * i], uv[2 * i + 1], WI, s) : 0.0F;
     MtrlSample ms;
     sample_material(ms, sc, m, N, WI, s, uv[2 * i], uv[2 * i + 1], mtrl_id, pre_r);
     float* o = out_sample + 7 * i;

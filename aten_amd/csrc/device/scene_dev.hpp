@@ -32,6 +32,14 @@ constexpr uint32_t kLinkOffsetMask = ~15u;
 constexpr uint32_t kInnerBytes = 32;
 constexpr uint32_t kTriLeafBytes = 48;
 constexpr uint32_t kShadeTriQuads = 8;
+// Material sets: which BSDFs a k_shade instantiation contains (DevScene::material_set picks the smallest that covers
+// the uploaded materials).  Every BSDF in the type switch costs registers in a kernel that runs at 3 waves per SIMD:
+// without Disney compiled in, the GGX-only headline scene and the Cornell box gain 2 %.
+constexpr int kMsCore = 0;        // Emissive, Diffuse, Specular, GGX
+constexpr int kMsDisney = 1;      // + Disney
+constexpr int kMsAnalytic = 2;    // + Refraction, Beckman, Oren-Nayar, Velvet, MicrofacetRefraction, Retroreflective
+constexpr int kMsCarPaint = 3;    // + CarPaint (flake normals, shared random number)
+constexpr int kMsToon = 4;        // + Toon / StylizedBrdf (inline visibility walk)
 #ifndef ATN_TREELET_BYTES
 #define ATN_TREELET_BYTES 0      /* measured on MI355X: the LDS copy loses to the L1; > 0 re-enables it */
 #endif
@@ -102,7 +110,7 @@ struct DevScene {
     int32_t enable_env_map;
     int32_t any_alpha;          // some material carries kAttrMaybeAlpha or kAttrStencilStencil: a shadow-ray hit may be "ignored"
     int32_t enable_alpha_blending;      // scene_rendering_config.enable_alpha_blending
-    int32_t material_set;               // 0 = BASELINE BSDFs only, 1 = + the other analytic ones, 2 = + CarPaint, 3 = + Toon / StylizedBrdf: which k_shade is launched
+    int32_t material_set;               // kMsCore .. kMsToon: which k_shade is launched
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS

@@ -993,11 +993,11 @@ ATN_DEV float4 flakes_normal_gen(float u, float v, float flake_scale, float flak
 }
 // material::applyNormal (material_impl.h:208-230): CarPaint::applyNormalMap (car_paint.cpp:195-236) draws the shared
 // random number and may replace the normal by a flake's; every other material takes its normal map and returns -1.
-// MS < 2 compiles CarPaint out (see the material sets at sample_material).
+// MS < kMsCarPaint compiles CarPaint out (see the material sets at sample_material).
 template <int MS>
 ATN_DEV float apply_normal(const DevScene& sc, const DevMaterial& m, int32_t mtrl_id, f3& nml, float u, float v, const f3& wi, Cmj& smp)
 {
-    if (MS < 2 || m.type != ATN_MTRL_CARPAINT) {
+    if (MS < kMsCarPaint || m.type != ATN_MTRL_CARPAINT) {
         nml = apply_normal_map(sc, m.normalMap, nml, u, v);
         return -1.0F;
     }
@@ -1077,24 +1077,22 @@ ATN_DEV f3 carpaint_bsdf(const DevScene& sc, const DevMaterial& m, const CarPain
 }
 
 // material::sampleMaterial / samplePDF / sampleBSDF, material/material_impl.h:24-206
-// Material set MS of a k_shade instantiation (chosen by the host from the uploaded materials, DevScene::material_set):
-//   0 = the BASELINE set: Emissive, Diffuse, Specular, GGX, Disney          (the other BSDFs are compiled out: every one
-//   1 = + Refraction, Beckman, OrenNayar, Velvet, MicrofacetRefraction,       of them costs registers in a kernel that
-//         Retroreflective                                                     runs at 3 waves per SIMD; measured: shade
-//   2 = + CarPaint (flake noise, its own parameter block)                      1.32 -> 1.35 -> 1.65 ms per frame)
+// Material set MS of a k_shade instantiation: kMsCore .. kMsToon (scene_dev.hpp), chosen by the host from the uploaded
+// materials (DevScene::material_set); BSDFs outside the set are compiled out (shade per frame on sponza_lod, measured:
+// core + Disney 1.32 ms, + the analytic ones 1.35, + CarPaint 1.65; core without Disney: frame -2 %).
 // mtrl_id / pre_r: only CarPaint reads them (its parameter block and the random number material::applyNormal drew).
-template <int MS = 2>
+template <int MS = kMsCarPaint>
 ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
                              const f3& wi, Cmj& smp, float u, float v, int32_t mtrl_id = 0, float pre_r = 0.0F)
 {
-    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) {       // CarPaint::sample, car_paint.cpp:178-193
+    if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) {       // CarPaint::sample, car_paint.cpp:178-193
         const CarPaintP p = carpaint_params(sc, mtrl_id);
         r.dir = carpaint_dir(p, normal, wi, smp, pre_r);
         r.pdf = carpaint_pdf(p, normal, wi, r.dir);
         r.bsdf = carpaint_bsdf(sc, m, p, normal, wi, r.dir, u, v, pre_r);
         return;
     }
-    if (MS >= 1) {
+    if (MS >= kMsAnalytic) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION:
             refraction_sample(r, m, normal, wi, smp);
@@ -1147,8 +1145,8 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
         break;
     }
     case ATN_MTRL_DISNEY:
-        disney_sample(r, m, normal, wi, smp);
-        break;
+        if (MS >= kMsDisney) { disney_sample(r, m, normal, wi, smp); break; }
+        [[fallthrough]];
     default: {  // Diffuse, Emissive (emissive.h:70-83) and the reference's fallback
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
         r.dir = diffuse_dir(normal, r1, r2);
@@ -1158,16 +1156,16 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
     }
     }
 }
-template <int MS = 2>
+template <int MS = kMsCarPaint>
 ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
                            int32_t mtrl_id = 0)
 {
-    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) return carpaint_pdf(carpaint_params(sc, mtrl_id), normal, wi, wo);
-    if (MS >= 3 && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputePDF, toon.cpp:288-301
+    if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) return carpaint_pdf(carpaint_params(sc, mtrl_id), normal, wi, wo);
+    if (MS >= kMsToon && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputePDF, toon.cpp:288-301
         const f3 V = -wi;
         return ggx_pdf_h(m.roughness, normal, toon_specular_half(sc.toon[mtrl_id], normal, V, wo), wo);
     }
-    if (MS >= 1) {
+    if (MS >= kMsAnalytic) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: return 1.0F;
         case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
@@ -1181,22 +1179,22 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
     switch (m.type) {
     case ATN_MTRL_SPECULAR: return 1.0F;
     case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
-    case ATN_MTRL_DISNEY: return disney_pdf(m, normal, wi, wo);
+    case ATN_MTRL_DISNEY: if (MS >= kMsDisney) return disney_pdf(m, normal, wi, wo); [[fallthrough]];
     default: return diffuse_pdf(normal, wo);
     }
 }
-template <int MS = 2>
+template <int MS = kMsCarPaint>
 ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
                                  int32_t mtrl_id = 0, float pre_r = 0.0F)
 {
     MtrlSample r; r.pdf = 0.0F; r.dir = wo; r.bsdf = mk3(0.0F);
-    if (MS >= 2 && m.type == ATN_MTRL_CARPAINT) { r.bsdf = carpaint_bsdf(sc, m, carpaint_params(sc, mtrl_id), normal, wi, wo, u, v, pre_r); return r; }
-    if (MS >= 3 && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputeBRDF, toon.cpp:303-322
+    if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) { r.bsdf = carpaint_bsdf(sc, m, carpaint_params(sc, mtrl_id), normal, wi, wo, u, v, pre_r); return r; }
+    if (MS >= kMsToon && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputeBRDF, toon.cpp:303-322
         const f3 V = -wi;
         r.bsdf = ggx_brdf_h(m.roughness, m.ior, normal, V, wo, toon_specular_half(sc.toon[mtrl_id], normal, V, wo));
         return r;
     }
-    if (MS >= 1) {
+    if (MS >= kMsAnalytic) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); return r;
         case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); return r;
@@ -1210,7 +1208,7 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     switch (m.type) {
     case ATN_MTRL_SPECULAR: { const float c = dot(normal, wo); r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c); break; }
     case ATN_MTRL_GGX: r.bsdf = ggx_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
-    case ATN_MTRL_DISNEY: r = disney_bsdf(m, normal, wi, wo); break;
+    case ATN_MTRL_DISNEY: if (MS >= kMsDisney) { r = disney_bsdf(m, normal, wi, wo); break; } [[fallthrough]];
     default: r.bsdf = diffuse_brdf(); break;
     }
     return r;
@@ -1459,7 +1457,7 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
 }
 
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
-template <int MS = 2>
+template <int MS = kMsCarPaint>
 ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
                           float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F,
                           float* weight_ptr = nullptr)

@@ -1,4 +1,4 @@
-// Toon / StylizedBrdf materials (material set 3): material/toon.cpp:88-286,371-445 of the reference.
+// Toon / StylizedBrdf materials (material set kMsToon): material/toon.cpp:88-286,371-445 of the reference.
 //
 // "Terminated" materials (material.h:583-588): at bounce 0 the path tracer treats such a surface as a light
 // (HitTeminatedMaterial, pathtracing_impl.h:482-503) whose colour is Toon::bsdf -- a one-sample NEE towards ONE
@@ -92,7 +92,7 @@ ATN_DEV f3 toon_bsdf(const DevScene& sc, const DevMaterial& m, int32_t mtrl_id, 
             base.type = tp.toon_type == ATN_MTRL_DIFFUSE ? ATN_MTRL_DIFFUSE : ATN_MTRL_TOON_SPECULAR;
             float nee_weight = 0.0F;
             f3 res;
-            if (radiance_nee<3>(res, sc, wi, normal, base, u, v, 1.0F, ls, mtrl_id, 0.0F, &nee_weight)) {
+            if (radiance_nee<kMsToon>(res, sc, wi, normal, base, u, v, 1.0F, ls, mtrl_id, 0.0F, &nee_weight)) {
                 radiance = res;
                 pdf = 1.0F / nee_weight;
             }

@@ -419,11 +419,12 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         img.screen_shadow.resize(n);
         for (size_t i = 0; i < n; i++) img.screen_shadow[i] = s->screen_space_texture.texels[i].x;
     }
-    p.material_set = 0;
+    p.material_set = kMsCore;
     for (const DevMaterial& dm : img.materials) {
         const int32_t t = dm.type;
-        const bool core = t == ATN_MTRL_EMISSIVE || t == ATN_MTRL_DIFFUSE || t == ATN_MTRL_SPECULAR || t == ATN_MTRL_GGX || t == ATN_MTRL_DISNEY;
-        const int32_t need = (t == ATN_MTRL_TOON || t == ATN_MTRL_STYLIZED_BRDF) ? 3 : (t == ATN_MTRL_CARPAINT ? 2 : (core ? 0 : 1));
+        const bool core = t == ATN_MTRL_EMISSIVE || t == ATN_MTRL_DIFFUSE || t == ATN_MTRL_SPECULAR || t == ATN_MTRL_GGX;
+        const int32_t need = (t == ATN_MTRL_TOON || t == ATN_MTRL_STYLIZED_BRDF) ? kMsToon
+                           : t == ATN_MTRL_CARPAINT ? kMsCarPaint : t == ATN_MTRL_DISNEY ? kMsDisney : core ? kMsCore : kMsAnalytic;
         if (need > p.material_set) p.material_set = need;
     }
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /

@@ -350,7 +350,7 @@ struct SvgfShade {
 struct ShadePartShared { uint32_t perm[kChunk]; uint32_t wcount[kChunkItems][4][2]; };
 
 template <bool SVGF, int MS>
-__global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FrameParams& fp, const atn_camera_param& cam, int32_t bounce, const SvgfShade& sv)
 {
     __shared__ BlockAppendShared sh;
     __shared__ BlockBinShared shb;
@@ -666,6 +666,20 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
           block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, entry_of);
     }
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
+}
+
+template <bool SVGF, int MS>
+__global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+{
+    shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
+}
+// The two smallest material sets need 141 / 148 VGPRs (3 waves per SIMD); held to 128 they run 4 waves per SIMD with a
+// few spilled registers and come out ahead (sponza_lod 4.37 -> 4.30 ms, atrium 6.30 -> 6.26 ms per 1080p frame).  The
+// larger sets (160 .. 226 VGPRs) would spill too much: they keep the compiler's own allocation.
+template <bool SVGF, int MS>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) k_shade_w4(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+{
+    shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }
 
 // HitShadowRay -> HitTestToTargetLight -> scene::hitLight

@@ -676,8 +676,11 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
 // The two smallest material sets need 141 / 148 VGPRs (3 waves per SIMD); held to 128 they run 4 waves per SIMD with a
 // few spilled registers and come out ahead (sponza_lod 4.37 -> 4.30 ms, atrium 6.30 -> 6.26 ms per 1080p frame).  The
 // larger sets (160 .. 226 VGPRs) would spill too much: they keep the compiler's own allocation.
+#ifndef ATN_SHADE_SMALL_WAVES
+#define ATN_SHADE_SMALL_WAVES 4
+#endif
 template <bool SVGF, int MS>
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) k_shade_w4(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+__global__ void __attribute__((amdgpu_waves_per_eu(ATN_SHADE_SMALL_WAVES, ATN_SHADE_SMALL_WAVES))) __launch_bounds__(256) k_shade_w4(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }

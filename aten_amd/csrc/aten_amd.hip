@@ -136,6 +136,8 @@ public:
         DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
+        uint64_t bank_epoch = 0;
+        int scene_set = 0;
         hipStream_t stream = nullptr, bstream[kMaxBatches] = {};
         hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {}, ev_gather = nullptr;
     };
@@ -151,7 +153,7 @@ public:
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
         counters.swap(b.counters);
-        std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth);
+        std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
         for (int k = 0; k < kMaxBatches; k++) { std::swap(bstream[k], b.bstream[k]); std::swap(ev_join[k], b.ev_join[k]); }
     }
@@ -182,8 +184,160 @@ public:
         ATN_HIP(hipStreamSynchronize(stream));
         for (int i = 0; i < n_spare_ready; i++) ATN_HIP(hipStreamSynchronize(spare[i].stream));
         if (sv_stream) ATN_HIP(hipStreamSynchronize(sv_stream));
+        if (scene_stream) ATN_HIP(hipStreamSynchronize(scene_stream));
         last_gather = nullptr;
         sv_prepare_recorded[0] = sv_prepare_recorded[1] = false;
+        return ATN_OK;
+    }
+
+    // Scene updates between frames (atn_update_geometry / atn_lbvh_rebuild_list / atn_update_tlas) do not stop the host:
+    // they are enqueued on the current bank's stream behind the frames in flight (every bank's "film updated" event is
+    // its last read of the scene), their host inputs travel through a pinned staging arena, and the next render on every
+    // bank waits for `ev_scene`.  The host only ever waits for the staging arena of the PREVIOUS update to drain.
+    // With frames in flight the MUTABLE part of the scene (node image, vertices, triangles, shading records, objects,
+    // matrices) exists twice: an update is written into the set no recent frame reads, after copying over what the
+    // previous update changed in the other one (its dirty ranges, device to device), and only frames enqueued afterwards
+    // read it -- so the frames in flight keep running while the next tick's geometry, LBVH and top layer are built.
+    // The members below ARE the set being written / read by new frames; `alt` is the other one (allocated at the first
+    // update of a scene).  In place, behind all frames, when there is one frame in flight or the caller writes the arrays
+    // itself (atn_scene_device_arrays).
+    enum SceneBufId { SB_NODES, SB_VTX_POS, SB_VTX_NML, SB_SHADE, SB_MATRICES, SB_TRIS, SB_OBJECTS, SB_COUNT };
+    struct SceneRange { int buf; size_t off, bytes; };
+    struct SceneSet {
+        DevBuf<float4> nodes, vtx_pos, vtx_nml, shade_tris, matrices;
+        DevBuf<atn_triangle_param> tris;
+        DevBuf<atn_object_param> objects;
+    } alt;
+    bool alt_ready = false, frame_since_update = true, scene_in_place = false;
+    int cur_set = 0, bank_scene_set = 0;            // bank_scene_set: the set this bank's last frame read (travels with the bank)
+    std::vector<SceneRange> log_now;                // what the updates since the last flip wrote into the current set
+
+    char* set_ptr(int b)
+    {
+        switch (b) {
+        case SB_NODES: return (char*)nodes.p; case SB_VTX_POS: return (char*)vtx_pos.p; case SB_VTX_NML: return (char*)vtx_nml.p;
+        case SB_SHADE: return (char*)shade_tris.p; case SB_MATRICES: return (char*)matrices.p; case SB_TRIS: return (char*)tris.p;
+        default: return (char*)objects.p;
+        }
+    }
+    char* alt_ptr(int b)
+    {
+        switch (b) {
+        case SB_NODES: return (char*)alt.nodes.p; case SB_VTX_POS: return (char*)alt.vtx_pos.p; case SB_VTX_NML: return (char*)alt.vtx_nml.p;
+        case SB_SHADE: return (char*)alt.shade_tris.p; case SB_MATRICES: return (char*)alt.matrices.p; case SB_TRIS: return (char*)alt.tris.p;
+        default: return (char*)alt.objects.p;
+        }
+    }
+    size_t set_bytes(int b)
+    {
+        switch (b) {
+        case SB_NODES: return nodes.n * sizeof(float4); case SB_VTX_POS: return vtx_pos.n * sizeof(float4); case SB_VTX_NML: return vtx_nml.n * sizeof(float4);
+        case SB_SHADE: return shade_tris.n * sizeof(float4); case SB_MATRICES: return matrices.n * sizeof(float4);
+        case SB_TRIS: return tris.n * sizeof(atn_triangle_param); default: return objects.n * sizeof(atn_object_param);
+        }
+    }
+    void log_range(int b, size_t off, size_t bytes) { if (bytes) log_now.push_back(SceneRange{ b, off, bytes }); }
+    void drop_alt_set()
+    {
+        alt.nodes.release(); alt.vtx_pos.release(); alt.vtx_nml.release(); alt.shade_tris.release(); alt.matrices.release();
+        alt.tris.release(); alt.objects.release();
+        alt_ready = false; log_now.clear();
+    }
+    void point_scene_at_current_set()
+    {
+        scene.nodes = nodes.p; scene.tris = tris.p; scene.shade_tris = shade_tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
+        scene.objects = objects.p; scene.matrices = matrices.p;
+    }
+    // switch to the other set (see above); everything is enqueued on `stream`
+    int flip_scene_set()
+    {
+        if (!alt_ready) {
+            ATN_HIP(alt.nodes.resize(nodes.n)); ATN_HIP(alt.vtx_pos.resize(vtx_pos.n)); ATN_HIP(alt.vtx_nml.resize(vtx_nml.n));
+            ATN_HIP(alt.shade_tris.resize(shade_tris.n)); ATN_HIP(alt.matrices.resize(matrices.n));
+            ATN_HIP(alt.tris.resize(tris.n)); ATN_HIP(alt.objects.resize(objects.n));
+            for (int b = 0; b < SB_COUNT; b++)
+                if (set_bytes(b)) ATN_HIP(hipMemcpyAsync(alt_ptr(b), set_ptr(b), set_bytes(b), hipMemcpyDeviceToDevice, upd));
+            alt_ready = true;
+            log_now.clear();
+        }
+        const int target = 1 - cur_set;
+        // the frames that still read the target set (two flips ago): its writers go behind them
+        for (int i = 0; i < n_spare_ready; i++)
+            if (spare[i].scene_set == target && spare[i].ev_gather) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_gather, 0));
+        if (bank_scene_set == target && ev_gather) ATN_HIP(hipStreamWaitEvent(upd, ev_gather, 0));
+        nodes.swap(alt.nodes); vtx_pos.swap(alt.vtx_pos); vtx_nml.swap(alt.vtx_nml); shade_tris.swap(alt.shade_tris);
+        matrices.swap(alt.matrices); tris.swap(alt.tris); objects.swap(alt.objects);
+        cur_set = target;
+        // what the previous update wrote into the other set (now `alt`) is missing here
+        for (const SceneRange& r : log_now)
+            ATN_HIP(hipMemcpyAsync(set_ptr(r.buf) + r.off, alt_ptr(r.buf) + r.off, r.bytes, hipMemcpyDeviceToDevice, upd));
+        log_now.clear();
+        point_scene_at_current_set();
+        return ATN_OK;
+    }
+
+    hipEvent_t ev_scene = nullptr, ev_stage = nullptr;
+    hipStream_t scene_stream = nullptr;             // updates run here when frames are in flight: not behind the newest frame
+    hipStream_t upd = nullptr;                      // the stream of the update in progress (scene_stream, or `stream` with one frame in flight)
+    uint64_t scene_epoch = 0, bank_epoch = 0;       // bank_epoch travels with the bank (swap_bank)
+    bool stage_busy = false;
+    char* stage_p = nullptr;
+    size_t stage_cap = 0, stage_used = 0;
+
+    int begin_scene_update(size_t stage_bytes)
+    {
+        if (!ev_scene) { ATN_HIP(hipEventCreateWithFlags(&ev_scene, hipEventDisableTiming)); ATN_HIP(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming)); }
+        if (stage_busy) { ATN_HIP(hipEventSynchronize(ev_stage)); stage_busy = false; }       // the previous update's copies
+        stage_used = 0;
+        if (stage_bytes > stage_cap) {
+            if (stage_p) ATN_HIP(hipHostFree(stage_p));
+            stage_p = nullptr; stage_cap = 0;
+            const size_t cap = stage_bytes + stage_bytes / 2 + 4096;
+            ATN_HIP(hipHostMalloc((void**)&stage_p, cap, hipHostMallocDefault));
+            stage_cap = cap;
+        }
+        if (frames_in_flight > 1 && !scene_stream) ATN_HIP(hipStreamCreateWithFlags(&scene_stream, hipStreamNonBlocking));
+        upd = frames_in_flight > 1 ? scene_stream : stream;
+        if (frames_in_flight > 1 && n_spare_ready > 0 && !scene_in_place) {
+            // a frame may be reading the current set: write the other one.  (Several updates in a row -- geometry, LBVH,
+            // top layer -- flip once: no frame has been enqueued in between.)
+            if (frame_since_update) { int r = flip_scene_set(); if (r) return r; frame_since_update = false; }
+            return ATN_OK;
+        }
+        // in place, behind every frame in flight: a bank's ev_gather is recorded after its last kernel that reads the scene
+        // (the filter stream of pipelined SVGF frames never reads the scene)
+        if (upd != stream) {
+            for (int i = 0; i < n_spare_ready; i++) if (spare[i].ev_gather) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_gather, 0));
+            if (ev_gather) ATN_HIP(hipStreamWaitEvent(upd, ev_gather, 0));
+        }
+        return ATN_OK;
+    }
+    // host bytes -> device, through the arena (the caller's memory is free again when this returns)
+    int stage_copy(void* dst_dev, const void* src_host, size_t bytes)
+    {
+        if (!bytes) return ATN_OK;
+        const size_t off = (stage_used + 63) & ~(size_t)63;
+        if (off + bytes > stage_cap) return fail(ATN_ERR_INVALID_ARG, "staging arena too small (internal)");
+        std::memcpy(stage_p + off, src_host, bytes);
+        stage_used = off + bytes;
+        ATN_HIP(hipMemcpyAsync(dst_dev, stage_p + off, bytes, hipMemcpyHostToDevice, upd));
+        return ATN_OK;
+    }
+    int end_scene_update()
+    {
+        if (stage_used) { ATN_HIP(hipEventRecord(ev_stage, upd)); stage_busy = true; }
+        ATN_HIP(hipEventRecord(ev_scene, upd));
+        scene_epoch++;
+        if (upd == stream) bank_epoch = scene_epoch;       // this bank's stream is already behind the update
+        return ATN_OK;
+    }
+    // first thing a frame does on its bank's stream
+    int wait_scene_epoch()
+    {
+        if (bank_epoch != scene_epoch && ev_scene) ATN_HIP(hipStreamWaitEvent(stream, ev_scene, 0));
+        bank_epoch = scene_epoch;
+        bank_scene_set = cur_set;
+        frame_since_update = true;
         return ATN_OK;
     }
 
@@ -253,6 +407,10 @@ public:
             if (b.stream) (void)hipStreamDestroy(b.stream);
         }
         if (stream) (void)hipStreamDestroy(stream);
+        if (scene_stream) (void)hipStreamDestroy(scene_stream);
+        if (ev_scene) (void)hipEventDestroy(ev_scene);
+        if (ev_stage) (void)hipEventDestroy(ev_stage);
+        if (stage_p) (void)hipHostFree(stage_p);
     }
 
     // ≙ idaten::Renderer::UpdateSceneData, src/libidaten/kernel/renderer.cpp:12-131
@@ -260,6 +418,7 @@ public:
     {
         ATN_HIP(hipSetDevice(device));
         { int q = quiesce(); if (q) return q; }
+        drop_alt_set(); cur_set = 0; scene_in_place = false; frame_since_update = true;
         HostSceneImage img;
         std::string err;
         if (!build_host_image(img, s, err)) return fail(ATN_ERR_UNSUPPORTED, err);
@@ -364,7 +523,6 @@ public:
         if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
         if (!objs || n_objs == 0 || !top || n_top == 0) return fail(ATN_ERR_INVALID_ARG, "empty object or top-layer array");
         ATN_HIP(hipSetDevice(device));
-        { int q = quiesce(); if (q) return q; }
         if ((uint64_t)top_base + (uint64_t)n_top * kInnerBytes >= (1ull << 31)) return fail(ATN_ERR_UNSUPPORTED, "too many BVH nodes for 31-bit byte-offset links");
         if (n_mtxs && !mtxs) return fail(ATN_ERR_INVALID_ARG, "null matrix array");
         {
@@ -389,33 +547,42 @@ public:
         int32_t root = kLinkEnd;
         uint64_t counts[3] = { 0, 0, 0 };
         if (!emit_list(reinterpret_cast<char*>(rec.data()), lay, top, c, root, counts, err, top_base)) return fail(ATN_ERR_UNSUPPORTED, err);
-        const size_t need = ((size_t)top_base + top_bytes + 15) / 16;
-        if (need > nodes.n) {
-            // grow: keep the bottom-level lists (device-to-device), drop the old top layer
-            float4* bigger = nullptr;
-            ATN_HIP(hipMalloc((void**)&bigger, need * sizeof(float4)));
-            hipError_t e = hipMemcpyAsync(bigger, nodes.p, (size_t)top_base, hipMemcpyDeviceToDevice, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) { (void)hipFree(bigger); return fail(ATN_ERR_HIP, hipGetErrorString(e)); }
-            nodes.release();
-            nodes.p = bigger; nodes.n = need;
-        }
-        if (top_bytes) ATN_HIP(hipMemcpyAsync(reinterpret_cast<char*>(nodes.p) + top_base, rec.data(), top_bytes, hipMemcpyHostToDevice, stream));
-        std::vector<atn_object_param> ov(objs, objs + n_objs);
-        ATN_HIP(objects.upload(ov, stream));
         std::vector<float4> mv;
         if (n_mtxs) {
             mv.resize((size_t)n_mtxs * 4);
             for (uint32_t i = 0; i < n_mtxs; i++)
                 for (int r = 0; r < 4; r++)
                     mv[4 * (size_t)i + r] = make_float4(mtxs[i].m[r][0], mtxs[i].m[r][1], mtxs[i].m[r][2], mtxs[i].m[r][3]);
-            ATN_HIP(matrices.upload(mv, stream));
-            n_host_matrices = n_mtxs;
         }
-        ATN_HIP(hipStreamSynchronize(stream));
+        const size_t need = ((size_t)top_base + top_bytes + 15) / 16;
+        const size_t obj_bytes = (size_t)n_objs * sizeof(atn_object_param), mtx_bytes = mv.size() * sizeof(float4);
+        // Buffers that must grow are replaced behind a full stop (rare: the usual tick keeps every count); otherwise the
+        // update is enqueued behind the frames in flight and the host goes on.
+        const bool grow = need > nodes.n || n_objs > objects.n || mv.size() > matrices.n;
+        if (grow) {
+            { int q = quiesce(); if (q) return q; }
+            drop_alt_set();         // re-cloned from the grown buffers at the next flip
+            if (need > nodes.n) {
+                // keep the bottom-level lists (device-to-device), drop the old top layer
+                float4* bigger = nullptr;
+                ATN_HIP(hipMalloc((void**)&bigger, need * sizeof(float4)));
+                hipError_t e = hipMemcpyAsync(bigger, nodes.p, (size_t)top_base, hipMemcpyDeviceToDevice, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) { (void)hipFree(bigger); return fail(ATN_ERR_HIP, hipGetErrorString(e)); }
+                nodes.release();
+                nodes.p = bigger; nodes.n = need;
+            }
+            if (n_objs > objects.n) ATN_HIP(objects.resize(n_objs));
+            if (mv.size() > matrices.n) ATN_HIP(matrices.resize(mv.size()));
+        }
+        { int r = begin_scene_update(top_bytes + obj_bytes + mtx_bytes + 512); if (r) return r; }
+        { int r = stage_copy(reinterpret_cast<char*>(nodes.p) + top_base, rec.data(), top_bytes); if (r) return r; log_range(SB_NODES, top_base, top_bytes); }
+        { int r = stage_copy(objects.p, objs, obj_bytes); if (r) return r; log_range(SB_OBJECTS, 0, obj_bytes); }
+        if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; }
+        { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
         scene.root_link = root;
-        scene.nodes = nodes.p; scene.objects = objects.p; scene.matrices = matrices.p;
+        point_scene_at_current_set();
         tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;
         if (!flavour_forced) use_refill = tree_is_deep;
         return ATN_OK;
@@ -440,22 +607,23 @@ public:
                 if (tr[i].idx[v] < 0 || (uint32_t)tr[i].idx[v] >= n_scene_vtx) return fail(ATN_ERR_UNSUPPORTED, "triangle vertex index out of range");
         }
         ATN_HIP(hipSetDevice(device));
-        { int q = quiesce(); if (q) return q; }
-        if (n_vtx && pos) ATN_HIP(hipMemcpyAsync(vtx_pos.p + vtx_offset, pos, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
-        if (n_vtx && nml) ATN_HIP(hipMemcpyAsync(vtx_nml.p + vtx_offset, nml, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
-        if (n_tr) ATN_HIP(hipMemcpyAsync(tris.p + tri_offset, tr, (size_t)n_tr * sizeof(atn_triangle_param), hipMemcpyHostToDevice, stream));
+        const size_t vb = (size_t)n_vtx * sizeof(float4), tb = (size_t)n_tr * sizeof(atn_triangle_param);
+        { int r = begin_scene_update((pos ? vb : 0) + (nml ? vb : 0) + tb + 256); if (r) return r; }
+        if (n_vtx && pos) { int r = stage_copy(vtx_pos.p + vtx_offset, pos, vb); if (r) return r; log_range(SB_VTX_POS, (size_t)vtx_offset * sizeof(float4), vb); }
+        if (n_vtx && nml) { int r = stage_copy(vtx_nml.p + vtx_offset, nml, vb); if (r) return r; log_range(SB_VTX_NML, (size_t)vtx_offset * sizeof(float4), vb); }
+        if (n_tr) { int r = stage_copy(tris.p + tri_offset, tr, tb); if (r) return r; log_range(SB_TRIS, (size_t)tri_offset * sizeof(atn_triangle_param), tb); }
         // which triangles use the new vertices is not known here: repack every shading record (a copy of the scene arrays)
         { int r = repack_shade_tris(0, n_scene_tris); if (r) return r; }
-        ATN_HIP(hipStreamSynchronize(stream));
-        return ATN_OK;
+        return end_scene_update();
     }
 
     int repack_shade_tris(uint32_t first, uint32_t count)
     {
         if (!count) return ATN_OK;
-        hipLaunchKernelGGL(k_pack_shade_tris, dim3((count + 255) / 256), dim3(256), 0, stream, (const atn_triangle_param*)tris.p,
+        hipLaunchKernelGGL(k_pack_shade_tris, dim3((count + 255) / 256), dim3(256), 0, upd, (const atn_triangle_param*)tris.p,
                            (const float4*)vtx_pos.p, (const float4*)vtx_nml.p, first, count, shade_tris.p);
         ATN_HIP(hipGetLastError());
+        log_range(SB_SHADE, (size_t)first * kShadeTriQuads * sizeof(float4), (size_t)count * kShadeTriQuads * sizeof(float4));
         return ATN_OK;
     }
 
@@ -485,31 +653,31 @@ public:
     // Morton codes -> sort -> hierarchy -> links -> boxes, all enqueued on `stream`; the tree is left in lb.ref_nodes in
     // the reference's node order.  `tr` points at the first of the n triangles, `vtx` at the vertex array.
     int lbvh_enqueue(const atn_triangle_param* tr, uint32_t n, int32_t tri_id_offset, const float* bmin, const float* bmax,
-                     const float4* vtx, int32_t vtx_offset, uint32_t image_base = 0)
+                     const float4* vtx, int32_t vtx_offset, uint32_t image_base, hipStream_t st)
     {
         { int r = lbvh_reserve(n); if (r) return r; }
         const uint32_t rounds = radix_rounds(n), tile = kSortThreads * rounds, nb = (n + tile - 1) / tile, nn = 2 * n - 1;
         const dim3 b256(256);
         f3 mn, mx;
         mn.x = bmin[0]; mn.y = bmin[1]; mn.z = bmin[2]; mx.x = bmax[0]; mx.y = bmax[1]; mx.z = bmax[2];
-        hipLaunchKernelGGL(k_lbvh_morton, dim3((n + 255) / 256), b256, 0, stream, tr, vtx, vtx_offset, n, mn, mx, lb.codes[0].p, lb.indices[0].p);
+        hipLaunchKernelGGL(k_lbvh_morton, dim3((n + 255) / 256), b256, 0, st, tr, vtx, vtx_offset, n, mn, mx, lb.codes[0].p, lb.indices[0].p);
         for (uint32_t pass = 0; pass < 4; pass++) {
             const int in = pass & 1, out = in ^ 1;
-            hipLaunchKernelGGL(k_radix_count, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, n, pass * 8u, lb.counts.p, nb, rounds);
-            hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(64), 0, stream, lb.counts.p, nb, lb.totals.p);
-            hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kSortThreads), 0, stream, (const uint32_t*)lb.codes[in].p, (const uint32_t*)lb.indices[in].p,
+            hipLaunchKernelGGL(k_radix_count, dim3(nb), dim3(kSortThreads), 0, st, (const uint32_t*)lb.codes[in].p, n, pass * 8u, lb.counts.p, nb, rounds);
+            hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(64), 0, st, lb.counts.p, nb, lb.totals.p);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kSortThreads), 0, st, (const uint32_t*)lb.codes[in].p, (const uint32_t*)lb.indices[in].p,
                                lb.codes[out].p, lb.indices[out].p, n, pass * 8u, (const uint32_t*)lb.counts.p, nb, (const uint32_t*)lb.totals.p, rounds);
         }
         LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p, lb.last.p };
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), b256, 0, stream, (const uint32_t*)lb.codes[0].p, n, t, lb.arrived.p);
-        hipLaunchKernelGGL(k_lbvh_links, dim3((nn + 255) / 256), b256, 0, stream, n, tri_id_offset, t, (const uint32_t*)lb.indices[0].p, lb.ref_nodes.p,
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), b256, 0, st, (const uint32_t*)lb.codes[0].p, n, t, lb.arrived.p);
+        hipLaunchKernelGGL(k_lbvh_links, dim3((nn + 255) / 256), b256, 0, st, n, tri_id_offset, t, (const uint32_t*)lb.indices[0].p, lb.ref_nodes.p,
                            image_base, lb.offs.p);
         {
             const uint32_t nblk = (n + kBoundsBlock - 1) / kBoundsBlock, nsup = (nblk + kBoundsSuper - 1) / kBoundsSuper;
-            hipLaunchKernelGGL(k_lbvh_bounds_block, dim3(nblk), dim3(kBoundsBlock), 0, stream, n, t, (const uint32_t*)lb.indices[0].p, tr, vtx, vtx_offset,
+            hipLaunchKernelGGL(k_lbvh_bounds_block, dim3(nblk), dim3(kBoundsBlock), 0, st, n, t, (const uint32_t*)lb.indices[0].p, tr, vtx, vtx_offset,
                                lb.ref_nodes.p, lb.arrived.p, lb.pre.p, lb.suf.p);
-            hipLaunchKernelGGL(k_lbvh_bounds_super, dim3(nsup), dim3(64), 0, stream, n, (const LbvhBox*)lb.pre.p, lb.sup.p);
-            hipLaunchKernelGGL(k_lbvh_bounds_cross, dim3((n + 255) / 256), b256, 0, stream, n, t, (const LbvhBox*)lb.pre.p, (const LbvhBox*)lb.suf.p,
+            hipLaunchKernelGGL(k_lbvh_bounds_super, dim3(nsup), dim3(64), 0, st, n, (const LbvhBox*)lb.pre.p, lb.sup.p);
+            hipLaunchKernelGGL(k_lbvh_bounds_cross, dim3((n + 255) / 256), b256, 0, st, n, t, (const LbvhBox*)lb.pre.p, (const LbvhBox*)lb.suf.p,
                                (const LbvhBox*)lb.sup.p, lb.ref_nodes.p);
         }
         ATN_HIP(hipGetLastError());
@@ -535,7 +703,7 @@ public:
         if (lb.vtx.n < n_vtx) ATN_HIP(lb.vtx.resize(n_vtx));
         ATN_HIP(hipMemcpyAsync(lb.tris.p, tr, (size_t)n * sizeof(atn_triangle_param), hipMemcpyHostToDevice, stream));
         ATN_HIP(hipMemcpyAsync(lb.vtx.p, vtx, (size_t)n_vtx * sizeof(float4), hipMemcpyHostToDevice, stream));
-        { int r = lbvh_enqueue(lb.tris.p, n, tri_id_offset, bmin, bmax, lb.vtx.p, vtx_offset); if (r) return r; }
+        { int r = lbvh_enqueue(lb.tris.p, n, tri_id_offset, bmin, bmax, lb.vtx.p, vtx_offset, 0, stream); if (r) return r; }
         ATN_HIP(hipMemcpyAsync(out, lb.ref_nodes.p, (size_t)(2 * n - 1) * sizeof(atn_bvh_node), hipMemcpyDeviceToHost, stream));
         if (out_codes) ATN_HIP(hipMemcpyAsync(out_codes, lb.codes[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         if (out_indices) ATN_HIP(hipMemcpyAsync(out_indices, lb.indices[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
@@ -560,16 +728,18 @@ public:
         if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
-        { int q = quiesce(); if (q) return q; }
+        { int r = begin_scene_update(0); if (r) return r; }
         // a caller may have written the scene arrays in place (atn_scene_device_arrays): refresh this mesh's shading records
         { int r = repack_shade_tris(tri_offset, n); if (r) return r; }
-        { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list]); if (r) return r; }
+        { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list], upd); if (r) return r; }
         const uint32_t nn = 2 * n - 1;
-        hipLaunchKernelGGL(k_lbvh_emit, dim3((nn + 255) / 256), dim3(256), 0, stream, n, (const atn_bvh_node*)lb.ref_nodes.p, (const uint32_t*)lb.offs.p,
+        hipLaunchKernelGGL(k_lbvh_emit, dim3((nn + 255) / 256), dim3(256), 0, upd, n, (const atn_bvh_node*)lb.ref_nodes.p, (const uint32_t*)lb.offs.p,
                            (const atn_triangle_param*)tris.p, (const float4*)vtx_pos.p, nodes.p);
         ATN_HIP(hipGetLastError());
+        log_range(SB_NODES, list_base[list], list_bytes[list]);
         // the root is node 0 = an inner record at the start of the region: the TLAS leaves' root link stays valid
-        if (sync) ATN_HIP(hipStreamSynchronize(stream));
+        { int r = end_scene_update(); if (r) return r; }
+        if (sync) ATN_HIP(hipStreamSynchronize(upd));
         return ATN_OK;
     }
 
@@ -883,6 +1053,8 @@ public:
             }
         }
         frame_seq++;
+        rc = wait_scene_epoch();
+        if (rc) return rc;
         rc = ensure_frame(d->width, d->height, d->maxDepth);
         if (rc) return rc;
         PathBuffers pb = buffers(count);
@@ -1069,6 +1241,8 @@ public:
             swap_bank(spare[frame_seq % (uint64_t)(frames_in_flight - 1)]);
         }
         frame_seq++;
+        rc = wait_scene_epoch();
+        if (rc) return rc;
         hipStream_t fs = pipelined ? sv_stream : stream;       // the stream the filter passes run on
         rc = ensure_frame(d->width, d->height, d->maxDepth);
         if (rc) return rc;
@@ -1239,19 +1413,19 @@ int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAI
 int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
                     const atn_bvh_node* top_nodes, uint32_t n_top_nodes)
 {
-    CTX_QUIET_OR_FAIL(ctx);
+    CTX_OR_FAIL(ctx);      // enqueued behind the frames in flight (begin_scene_update), no host stop
     return guarded(ctx, [&] { return ctx->r.updateBVH(objects, n_objects, matrices, n_matrices, top_nodes, n_top_nodes); });
 }
 int atn_update_geometry(atn_ctx* ctx, const atn_vec4* vtx_pos, const atn_vec4* vtx_nml, uint32_t n_vertices, uint32_t vtx_offset,
                         const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset)
 {
-    CTX_QUIET_OR_FAIL(ctx);
+    CTX_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.updateGeometry(vtx_pos, vtx_nml, n_vertices, vtx_offset, triangles, n_triangles, tri_offset); });
 }
 int atn_lbvh_rebuild_list(atn_ctx* ctx, uint32_t list_index, uint32_t tri_offset, uint32_t n_triangles, const float* bbox_min, const float* bbox_max)
 {
-    CTX_QUIET_OR_FAIL(ctx);
-    return guarded(ctx, [&] { return ctx->r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, true); });
+    CTX_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, false); });
 }
 int atn_lbvh_build(atn_ctx* ctx, const atn_triangle_param* triangles, uint32_t n_triangles, int32_t tri_id_offset,
                    const float* bbox_min, const float* bbox_max, const atn_vec4* vtx_pos, uint32_t n_vertices, int32_t vtx_offset,
@@ -1265,6 +1439,9 @@ int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void**
 {
     CTX_QUIET_OR_FAIL(ctx);
     if (!ctx->r.has_scene) return ctx->r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    // the caller writes these arrays itself from now on: one copy of the scene, updates in place behind the frames in flight
+    { int q = ctx->r.quiesce(); if (q) return q; }
+    ctx->r.drop_alt_set(); ctx->r.scene_in_place = true;
     if (vtx_pos) *vtx_pos = ctx->r.vtx_pos.p;
     if (vtx_nml) *vtx_nml = ctx->r.vtx_nml.p;
     if (triangles) *triangles = ctx->r.tris.p;
@@ -1509,7 +1686,7 @@ int atn_mgpu_lbvh_rebuild_list(atn_mgpu* mg, uint32_t list_index, uint32_t tri_o
     return mg_guarded(mg, [&] { return mg->m.on_all([&](int i) {
         PathTracing& r = *mg->m.shard[i];
         if (hipSetDevice(r.device) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipSetDevice");
-        return r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, true); }); });
+        return r.lbvh_rebuild_list(list_index, tri_offset, n_triangles, bbox_min, bbox_max, false); }); });
 }
 int atn_mgpu_update_camera(atn_mgpu* mg, const atn_camera_param* camera)
 {

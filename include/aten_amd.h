@@ -70,6 +70,11 @@ int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_ob
 /* ≙ idaten::Renderer::updateCamera (renderer.cpp:202-205). */
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
 
+/* Scene updates between frames -- atn_update_tlas, atn_update_geometry, atn_lbvh_rebuild_list -- return when they are
+ * ENQUEUED: the caller's arrays have been copied (they may be reused at once), the frames in flight keep running, and
+ * every frame rendered afterwards sees the update.  With atn_set_frames_in_flight > 1 the mutable part of the scene is
+ * double-buffered on the device for this. */
+
 /* ---- dynamic geometry: the per-tick sequence of the reference's deformation renderer
  * (src/deformation_renderer/main.cpp:636-710): skinned vertices -> LBVHBuilder::build into the renderer's node list ->
  * Renderer::updateGeometry -> Renderer::updateBVH (= atn_update_tlas). */
@@ -82,7 +87,9 @@ int atn_update_geometry(atn_ctx* ctx, const atn_vec4* vtx_pos, const atn_vec4* v
                         const atn_triangle_param* triangles, uint32_t n_triangles, uint32_t tri_offset);
 /* The scene arrays in device memory (float4[n_vertices] x 2, atn_triangle_param[n_triangles]) for a caller whose own HIP
  * skinning kernel writes them in place (≙ the interop VBO the reference's skinning writes, main.cpp:673-676).  Waits for
- * the frames in flight; the pointers stay valid until the next atn_upload_scene. */
+ * the frames in flight and switches the context to ONE copy of the scene, updated in place behind the frames in flight
+ * (the caller's kernel must itself run after them, e.g. after atn_synchronize); the pointers stay valid until the next
+ * atn_upload_scene. */
 int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void** triangles);
 /* ≙ lbvh_.build(nodes[deformPos], tris, tri_offset_, sceneBbox, vtxPos, ...) (main.cpp:686-693; idaten::LBVHBuilder::onBuild,
  * src/libidaten/kernel/LBVHBuilder.cu:700-810): rebuild bottom-level list `list_index` ON THE DEVICE as an LBVH over the

@@ -199,6 +199,37 @@ def test_deformation_with_frames_in_flight_and_shards(orc, room):
         r.close(); mg.close()
 
 
+def test_every_frame_in_flight_sees_its_own_scene_version(orc, room):
+    """Three frames in flight, a deformation tick before every frame, nothing waited for in between: the mutable part of
+    the scene is double-buffered (updates go to the set no recent frame reads, on their own stream), so the running mean
+    over the six frames must be the oracle's mean over the six DIFFERENT scenes -- a frame that read a half-updated
+    tree or the wrong tick's vertices would show."""
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    seeds = orc.init_sampler(W, H, 0)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs0); r.updateCamera(c); r.initSampler(W, H, 0)
+        r.set_frames_in_flight(3)
+        film = None
+        phases = [0.5, 1.3, 2.2, 2.9, 3.7, 4.4]
+        for f, t in enumerate(phases):
+            fs, d = tick_data(b, oid, t)
+            push_tick(r, fs, d)
+            got = r.render(W, H, frame=f, download=(f == len(phases) - 1))
+            film = orc.render(oracle_scene_with_lbvh(orc, fs, d), c, seeds, W, H, frame=f, film=film)
+        assert (got[..., 3] == len(phases)).all()
+        assert same_frame(got, film)
+        # and the hit records of the last version, through the probe (which waits for everything)
+        rays = orc.generate_paths(c, seeds, W, H, 0, 0)
+        wi, _ = orc.trace_closest(oracle_scene_with_lbvh(orc, fs, d), rays)
+        assert r.trace_closest(rays).tobytes() == wi.tobytes()
+    finally:
+        r.close()
+
+
 def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
     from aten_amd.renderer import PathTracing
     b, oid, cam = room

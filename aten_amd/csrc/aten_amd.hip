@@ -856,7 +856,10 @@ public:
     bool use_refill = false, tree_is_deep = false, flavour_forced = false;
     uint32_t simple_block = 64;     // threads per block of the plain walk's fused launches: one wave per block retires on its own (1-2 % over 256)
     static constexpr size_t kRefillMinNodes = 2048;
-    static constexpr uint32_t kRefillMinPaths = 1900u * 1000u;      // measured crossover on sponza_lod: 1.74 M paths plain 5.19 vs refill 5.25 ms, 2.07 M 6.11 vs 5.96
+    // Re-measured after the burst walk (r02_e, sponza_lod, 3 frames in flight, ms per frame of an N-way shard: refill 4.29 /
+    // 2.31 / 1.29 / 0.71 vs plain 5.51 / 2.93 / 1.39 / 0.75 at 2.07 M / 1.04 M / 0.52 M / 0.26 M paths): the r01 crossover of
+    // 1.9 M paths is gone, deep trees take the refill walk at every size that fills the machine at all
+    static constexpr uint32_t kRefillMinPaths = 128u * 1000u;
 
     uint32_t trace_grid(uint32_t n_jobs) const
     {

@@ -953,7 +953,9 @@ public:
         }
         else {
             // the refill walk wants the machine to itself; the plain walk gains from a second batch down to ~0.8 M paths
-            nb = use_refill ? 1 : (n_slots >= 800u * 1000u ? 2 : 1);
+            // (with frames in flight the next frame fills the gaps a second batch was for: measured r02_e on Cornell, 3 in
+            // flight, 1.04 M paths: 1 batch 0.82 ms, 2 batches 0.96; 2.07 M paths: 1.66 vs 1.63)
+            nb = use_refill ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
             if (nb > n_batches) nb = n_batches;
         }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;

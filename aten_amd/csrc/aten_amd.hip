@@ -207,10 +207,21 @@ public:
         DevBuf<float4> nodes, vtx_pos, vtx_nml, shade_tris, matrices;
         DevBuf<atn_triangle_param> tris;
         DevBuf<atn_object_param> objects;
-    } alt;
-    bool alt_ready = false, frame_since_update = true, scene_in_place = false;
-    int cur_set = 0, bank_scene_set = 0;            // bank_scene_set: the set this bank's last frame read (travels with the bank)
+        int id = 0;                 // which set this is (banks remember the id their last frame read)
+        uint64_t tick = 0;          // the update after which this set was complete
+        void release() { nodes.release(); vtx_pos.release(); vtx_nml.release(); shade_tris.release(); matrices.release(); tris.release(); objects.release(); }
+    };
+    // One set per frame in flight, up to three: the set written by a tick is the one that was current longest ago, so
+    // its last readers are (frames in flight) ticks old and have normally finished -- the tick does not wait.
+    static constexpr int kMaxSceneSets = 3;
+    SceneSet alt[kMaxSceneSets - 1];
+    int n_alt = 0;                                  // allocated sets besides the current one
+    bool frame_since_update = true, scene_in_place = false;
+    int cur_set = 0, bank_scene_set = 0;            // ids; bank_scene_set: the set this bank's last frame read (travels with the bank)
+    uint64_t cur_tick = 0, tick_counter = 0;
     std::vector<SceneRange> log_now;                // what the updates since the last flip wrote into the current set
+    struct TickLog { uint64_t tick; std::vector<SceneRange> ranges; };
+    std::vector<TickLog> log_hist;                  // the last kMaxSceneSets - 1 finished ticks
 
     char* set_ptr(int b)
     {
@@ -220,12 +231,12 @@ public:
         default: return (char*)objects.p;
         }
     }
-    char* alt_ptr(int b)
+    static char* alt_ptr(SceneSet& a, int b)
     {
         switch (b) {
-        case SB_NODES: return (char*)alt.nodes.p; case SB_VTX_POS: return (char*)alt.vtx_pos.p; case SB_VTX_NML: return (char*)alt.vtx_nml.p;
-        case SB_SHADE: return (char*)alt.shade_tris.p; case SB_MATRICES: return (char*)alt.matrices.p; case SB_TRIS: return (char*)alt.tris.p;
-        default: return (char*)alt.objects.p;
+        case SB_NODES: return (char*)a.nodes.p; case SB_VTX_POS: return (char*)a.vtx_pos.p; case SB_VTX_NML: return (char*)a.vtx_nml.p;
+        case SB_SHADE: return (char*)a.shade_tris.p; case SB_MATRICES: return (char*)a.matrices.p; case SB_TRIS: return (char*)a.tris.p;
+        default: return (char*)a.objects.p;
         }
     }
     size_t set_bytes(int b)
@@ -239,39 +250,63 @@ public:
     void log_range(int b, size_t off, size_t bytes) { if (bytes) log_now.push_back(SceneRange{ b, off, bytes }); }
     void drop_alt_set()
     {
-        alt.nodes.release(); alt.vtx_pos.release(); alt.vtx_nml.release(); alt.shade_tris.release(); alt.matrices.release();
-        alt.tris.release(); alt.objects.release();
-        alt_ready = false; log_now.clear();
+        for (int k = 0; k < n_alt; k++) alt[k].release();
+        n_alt = 0; log_now.clear(); log_hist.clear();
     }
     void point_scene_at_current_set()
     {
         scene.nodes = nodes.p; scene.tris = tris.p; scene.shade_tris = shade_tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
         scene.objects = objects.p; scene.matrices = matrices.p;
     }
-    // switch to the other set (see above); everything is enqueued on `stream`
+    // switch to the set that was current longest ago (see above); everything is enqueued on `upd`
     int flip_scene_set()
     {
-        if (!alt_ready) {
-            ATN_HIP(alt.nodes.resize(nodes.n)); ATN_HIP(alt.vtx_pos.resize(vtx_pos.n)); ATN_HIP(alt.vtx_nml.resize(vtx_nml.n));
-            ATN_HIP(alt.shade_tris.resize(shade_tris.n)); ATN_HIP(alt.matrices.resize(matrices.n));
-            ATN_HIP(alt.tris.resize(tris.n)); ATN_HIP(alt.objects.resize(objects.n));
-            for (int b = 0; b < SB_COUNT; b++)
-                if (set_bytes(b)) ATN_HIP(hipMemcpyAsync(alt_ptr(b), set_ptr(b), set_bytes(b), hipMemcpyDeviceToDevice, upd));
-            alt_ready = true;
+        // the tick that just ended (the updates since the last flip) becomes history
+        if (!log_now.empty()) {
+            log_hist.push_back(TickLog{ cur_tick, std::move(log_now) });
             log_now.clear();
+            if (log_hist.size() > (size_t)(kMaxSceneSets - 1)) log_hist.erase(log_hist.begin());
         }
-        const int target = 1 - cur_set;
-        // the frames that still read the target set (two flips ago): its writers go behind them
-        for (int i = 0; i < n_spare_ready; i++)
-            if (spare[i].scene_set == target && spare[i].ev_gather) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_gather, 0));
-        if (bank_scene_set == target && ev_gather) ATN_HIP(hipStreamWaitEvent(upd, ev_gather, 0));
-        nodes.swap(alt.nodes); vtx_pos.swap(alt.vtx_pos); vtx_nml.swap(alt.vtx_nml); shade_tris.swap(alt.shade_tris);
-        matrices.swap(alt.matrices); tris.swap(alt.tris); objects.swap(alt.objects);
-        cur_set = target;
-        // what the previous update wrote into the other set (now `alt`) is missing here
-        for (const SceneRange& r : log_now)
-            ATN_HIP(hipMemcpyAsync(set_ptr(r.buf) + r.off, alt_ptr(r.buf) + r.off, r.bytes, hipMemcpyDeviceToDevice, upd));
-        log_now.clear();
+        const int want = (frames_in_flight < kMaxSceneSets ? frames_in_flight : kMaxSceneSets) - 1;     // sets besides the current one
+        SceneSet* t = nullptr;
+        if (n_alt < want) {
+            // a new set: a clone of the current one
+            t = &alt[n_alt];
+            ATN_HIP(t->nodes.resize(nodes.n)); ATN_HIP(t->vtx_pos.resize(vtx_pos.n)); ATN_HIP(t->vtx_nml.resize(vtx_nml.n));
+            ATN_HIP(t->shade_tris.resize(shade_tris.n)); ATN_HIP(t->matrices.resize(matrices.n));
+            ATN_HIP(t->tris.resize(tris.n)); ATN_HIP(t->objects.resize(objects.n));
+            for (int b = 0; b < SB_COUNT; b++)
+                if (set_bytes(b)) ATN_HIP(hipMemcpyAsync(alt_ptr(*t, b), set_ptr(b), set_bytes(b), hipMemcpyDeviceToDevice, upd));
+            // ids 0 .. kMaxSceneSets-1, none in use twice
+            bool used[kMaxSceneSets] = {};
+            used[cur_set] = true;
+            for (int k = 0; k < n_alt; k++) used[alt[k].id] = true;
+            for (int id = 0; id < kMaxSceneSets; id++) if (!used[id]) { t->id = id; break; }
+            t->tick = cur_tick;
+            n_alt++;
+        }
+        else {
+            if (n_alt == 0) return ATN_OK;      // (one frame in flight never gets here)
+            t = &alt[0];
+            for (int k = 1; k < n_alt; k++) if (alt[k].tick < t->tick) t = &alt[k];
+            // the frames that still read it: its writers go behind them
+            for (int i = 0; i < n_spare_ready; i++)
+                if (spare[i].scene_set == t->id && spare[i].ev_gather) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_gather, 0));
+            if (bank_scene_set == t->id && ev_gather) ATN_HIP(hipStreamWaitEvent(upd, ev_gather, 0));
+            // what the ticks since its own wrote into the other sets is missing there: the current set has all of it
+#ifndef ATN_DEBUG_NO_REPLAY      /* (the tests' negative control: without the replay test_ticks_touching_different_ranges_are_replayed fails) */
+            for (const TickLog& L : log_hist)
+                if (L.tick > t->tick)
+                    for (const SceneRange& r : L.ranges)
+                        ATN_HIP(hipMemcpyAsync(alt_ptr(*t, r.buf) + r.off, set_ptr(r.buf) + r.off, r.bytes, hipMemcpyDeviceToDevice, upd));
+#endif
+        }
+        // swap: the target becomes the members, the old current takes its slot
+        nodes.swap(t->nodes); vtx_pos.swap(t->vtx_pos); vtx_nml.swap(t->vtx_nml); shade_tris.swap(t->shade_tris);
+        matrices.swap(t->matrices); tris.swap(t->tris); objects.swap(t->objects);
+        std::swap(cur_set, t->id);
+        t->tick = cur_tick;                 // the old current set is complete up to the tick that just ended
+        cur_tick = ++tick_counter;          // the tick being written now
         point_scene_at_current_set();
         return ATN_OK;
     }
@@ -304,6 +339,7 @@ public:
             if (frame_since_update) { int r = flip_scene_set(); if (r) return r; frame_since_update = false; }
             return ATN_OK;
         }
+        log_now.clear();        // (no other set to replay into)
         // in place, behind every frame in flight: a bank's ev_gather is recorded after its last kernel that reads the scene
         // (the filter stream of pipelined SVGF frames never reads the scene)
         if (upd != stream) {

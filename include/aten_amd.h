@@ -73,7 +73,7 @@ int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
 /* Scene updates between frames -- atn_update_tlas, atn_update_geometry, atn_lbvh_rebuild_list -- return when they are
  * ENQUEUED: the caller's arrays have been copied (they may be reused at once), the frames in flight keep running, and
  * every frame rendered afterwards sees the update.  With atn_set_frames_in_flight > 1 the mutable part of the scene is
- * double-buffered on the device for this. */
+ * kept once per frame in flight (up to three copies) on the device for this. */
 
 /* ---- dynamic geometry: the per-tick sequence of the reference's deformation renderer
  * (src/deformation_renderer/main.cpp:636-710): skinned vertices -> LBVHBuilder::build into the renderer's node list ->

@@ -230,6 +230,54 @@ def test_every_frame_in_flight_sees_its_own_scene_version(orc, room):
         r.close()
 
 
+def test_ticks_touching_different_ranges_are_replayed(orc, room):
+    """The scene sets behind the frames in flight are kept complete by replaying, device to device, the ranges earlier
+    ticks wrote into the other sets.  Here consecutive ticks move DIFFERENT halves of the mesh's vertices (and rebuild
+    its tree over all of them): a set that missed the other half's last move would build the tree over stale vertices.
+    Three frames in flight, eight ticks, no waiting; the oracle gets the composite geometry of every tick."""
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    seeds = orc.init_sampler(W, H, 0)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs0); r.updateCamera(c); r.initSampler(W, H, 0)
+        r.set_frames_in_flight(3)
+        n, t0, v0 = d0["n"], d0["t0"], d0["v0"]
+        state = {k: fs0.arrays[k].copy() for k in ("vtx_pos", "vtx_nml", "triangles")}
+        film = None
+        for f, t in enumerate([0.6, 1.1, 1.9, 2.4, 3.0, 3.8, 4.1, 4.9]):
+            fs, d = tick_data(b, oid, t)
+            half = f % 2
+            tr = slice(t0 + half * (n // 2), t0 + (half + 1) * (n // 2))                  # this tick's triangles ...
+            vr = slice(v0 + 3 * half * (n // 2), v0 + 3 * (half + 1) * (n // 2))          # ... and their (unshared) vertices
+            for k, sl in (("vtx_pos", vr), ("vtx_nml", vr), ("triangles", tr)):
+                state[k][sl] = fs.arrays[k][sl]
+                fs.arrays[k][...] = state[k]            # the scene as it is after this tick: what the oracle renders
+            used = state["vtx_pos"][d["v0"]:d["v1"], :3]
+            d = dict(d, bmin=used.min(0), bmax=used.max(0))
+            r.updateGeometry(vtx_pos=state["vtx_pos"][vr], vtx_nml=state["vtx_nml"][vr], vtx_offset=vr.start,
+                             triangles=state["triangles"][tr], tri_offset=tr.start)
+            r.lbvh_rebuild_list(d["list"], d["t0"], d["n"], d["bmin"], d["bmax"])
+            if f % 3 == 0:
+                r.updateBVH(fs)                                                            # (the top layer only now and then)
+                top = (fs.arrays["objects"].copy(), fs.arrays["matrices"].copy(), fs.arrays["bvh_lists"][0].copy())
+            else:                                                                          # the oracle keeps the last top layer too
+                fs.arrays["objects"][...] = top[0]; fs.arrays["matrices"][...] = top[1]; fs.replace_bvh_list(0, top[2])
+            got = r.render(W, H, frame=f, download=(f == 7))
+            ofs = oracle_scene_with_lbvh(orc, fs, d)
+            film = orc.render(ofs, c, seeds, W, H, frame=f, film=film)
+        assert (got[..., 3] == 8).all()
+        assert same_frame(got, film)
+        rays = orc.generate_paths(c, seeds, W, H, 0, 0)
+        wi, _ = orc.trace_closest(ofs, rays)
+        assert r.trace_closest(rays).tobytes() == wi.tobytes()
+        assert (wi["objid"] == len(fs.arrays["objects"]) - 1).sum() > 300
+    finally:
+        r.close()
+
+
 def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
     from aten_amd.renderer import PathTracing
     b, oid, cam = room

@@ -24,7 +24,7 @@ SYMBOLS = [
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples",
     "atn_material_table", "atn_compact", "atn_compact2", "atn_compact3", "atn_sizeof_scene_desc", "atn_sizeof_destination",
     "atn_abi_version",
-    "atn_update_geometry", "atn_scene_device_arrays", "atn_lbvh_rebuild_list", "atn_lbvh_build",
+    "atn_download_path_cost", "atn_update_geometry", "atn_scene_device_arrays", "atn_lbvh_rebuild_list", "atn_lbvh_build",
     "atn_mgpu_update_geometry", "atn_mgpu_lbvh_rebuild_list",
     "atn_mgpu_create", "atn_mgpu_destroy", "atn_mgpu_last_error", "atn_mgpu_shard_count", "atn_mgpu_shard_device",
     "atn_mgpu_upload_scene", "atn_mgpu_update_tlas", "atn_mgpu_update_camera", "atn_mgpu_init_sampler",
@@ -56,6 +56,7 @@ def lib():
         l.atn_upload_scene.argtypes = [vp, vp]
         l.atn_update_camera.argtypes = [vp, vp]
         l.atn_update_tlas.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
+        l.atn_download_path_cost.argtypes = [vp, vp]
         l.atn_update_geometry.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32]
         l.atn_scene_device_arrays.argtypes = [vp, vp, vp, vp]
         l.atn_lbvh_rebuild_list.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]

@@ -120,6 +120,8 @@ public:
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
     DevBuf<unsigned long long> stats;
+    DevBuf<uint32_t> cost, cost_film;       // per-slot / per-pixel {node visits, triangle tests} of the last count_stats frame
+    int32_t cost_w = 0, cost_h = 0;
     int32_t film_w = 0, film_h = 0;
     int32_t rank = 0, world = 1;
     uint32_t n_slots = 0;
@@ -856,6 +858,7 @@ public:
         pb.q_count = cb; pb.sh_count = cb + counters_depth;
         pb.fetch_closest = cb + 2 * counters_depth; pb.fetch_shadow = cb + 3 * counters_depth;
         pb.stats = count ? stats.p : nullptr;
+        pb.cost = count ? cost.p : nullptr;
         return pb;
     }
 
@@ -1098,9 +1101,16 @@ public:
         if (rc) return rc;
         rc = ensure_frame(d->width, d->height, d->maxDepth);
         if (rc) return rc;
-        PathBuffers pb = buffers(count);
         FrameParams fp = frame_params(*d);
-        if (count) ATN_HIP(hipMemsetAsync(stats.p, 0, 64, stream));
+        if (count) {
+            ATN_HIP(hipMemsetAsync(stats.p, 0, 64, stream));
+            ATN_HIP(cost.resize((size_t)2 * n_slots));
+            ATN_HIP(cost_film.resize((size_t)2 * d->width * d->height));
+            ATN_HIP(hipMemsetAsync(cost.p, 0, (size_t)2 * n_slots * sizeof(uint32_t), stream));
+            ATN_HIP(hipMemsetAsync(cost_film.p, 0, (size_t)2 * d->width * d->height * sizeof(uint32_t), stream));
+            cost_w = d->width; cost_h = d->height;
+        }
+        PathBuffers pb = buffers(count);
 
         const uint32_t g_all = (n_slots + 255u) / 256u;
         rc = run_paths<false>(d, fp, count, prof, SvgfShade{}, SvgfFrame{});
@@ -1115,6 +1125,7 @@ public:
         if (frames_in_flight > 1) ATN_HIP(hipEventRecord(ev_gather, stream));
 
         if (count) {
+            hipLaunchKernelGGL(k_cost_to_pixels, dim3(g_all), dim3(256), 0, stream, fp, (const uint32_t*)cost.p, cost_film.p);
             ATN_HIP(hipMemcpyAsync(host_stats, stats.p, 64, hipMemcpyDeviceToHost, stream));
         }
         if (out_host) {
@@ -1654,6 +1665,19 @@ int atn_upload_film(atn_ctx* ctx, int32_t width, int32_t height, const atn_vec4*
     });
 }
 
+int atn_download_path_cost(atn_ctx* ctx, uint32_t* out_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!out_host) return r.fail(ATN_ERR_INVALID_ARG, "null output");
+    if (!r.cost_film.p || r.cost_w <= 0) return r.fail(ATN_ERR_INVALID_ARG, "no frame has been rendered with count_stats = 1");
+    return guarded(ctx, [&]() -> int {
+        if (hipSetDevice(r.device) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipSetDevice");
+        if (hipMemcpyAsync(out_host, r.cost_film.p, (size_t)2 * r.cost_w * r.cost_h * sizeof(uint32_t), hipMemcpyDeviceToHost, r.stream) != hipSuccess
+            || hipStreamSynchronize(r.stream) != hipSuccess) return r.fail(ATN_ERR_HIP, "cost map download");
+        return ATN_OK;
+    });
+}
 int atn_get_stats(atn_ctx* ctx, uint64_t out[8])
 {
     CTX_QUIET_OR_FAIL(ctx);

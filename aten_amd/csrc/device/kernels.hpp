@@ -40,6 +40,7 @@ struct PathBuffers {
     uint32_t* sh_count; // [maxDepth]
     uint32_t* fetch_closest;    // [maxDepth] dynamic job-fetch cursors of the trace kernels
     uint32_t* fetch_shadow;     // [maxDepth]
+    uint32_t* cost;     // [2 * slots] node visits / triangle tests of the pixel's walks this sample (count_stats frames; else null)
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
 };
 
@@ -304,6 +305,10 @@ struct ClosestJob {
         pb.isect[slot] = make_float4(__int_as_float(h.objid), h.a, h.b, __int_as_float(h.tri));
         return false;
     }
+    ATN_DEV void cost(uint32_t slot, uint32_t nodes, uint32_t tris) const
+    {
+        if (pb.cost) { atomicAdd(&pb.cost[2u * slot], nodes); atomicAdd(&pb.cost[2u * slot + 1u], tris); }
+    }
 };
 
 template <bool COUNT, bool REFILL>
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
 {
     const uint32_t count = pb.q_count[bounce];
     const ClosestJob job{ pb, pb.queue[bounce & 1], kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
     trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_closest[bounce], job, &tc);
     if (COUNT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[0], (unsigned long long)count);
@@ -724,6 +729,11 @@ struct ShadowJob {
         a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)
         b = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
     }
+    ATN_DEV void cost(uint32_t payload, uint32_t nodes, uint32_t tris) const
+    {
+        const uint32_t slot = payload & kShadowSlotMask;
+        if (pb.cost) { atomicAdd(&pb.cost[2u * slot], nodes); atomicAdd(&pb.cost[2u * slot + 1u], tris); }
+    }
     ATN_DEV bool finish(uint32_t payload, const Hit& h, bool isHit, float4& ra, float4& rb, float& rstop) const
     {
         const uint32_t slot = payload & kShadowSlotMask;
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
 {
     const uint32_t count = pb.sh_count[bounce];
     const ShadowJob<true> job{ pb, sc, kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
     trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_shadow[bounce], job, &tc);
     if (COUNT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[1], (unsigned long long)count);
@@ -834,6 +844,10 @@ struct FusedJob {
         }
         return c.finish(payload, h, is_hit, ra, rb, rstop);
     }
+    ATN_DEV void cost(uint32_t payload, uint32_t nodes, uint32_t tris) const
+    {
+        if (payload & 0x80000000u) s.cost(payload & 0x7fffffffu, nodes, tris); else c.cost(payload, nodes, tris);
+    }
 };
 
 template <bool REFILL, bool ALPHA>
@@ -842,7 +856,7 @@ __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
     trace_dispatch<false, REFILL>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }
 
@@ -947,6 +961,7 @@ struct BatchJob {
         out[j] = o;
         return false;
     }
+    ATN_DEV void cost(uint32_t, uint32_t, uint32_t) const {}
 };
 
 // The renderer's traversal core over caller-provided rays (parity probe, atn_trace_closest).
@@ -956,7 +971,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
                                                      unsigned long long* stats)
 {
     const BatchJob job{ sc, rays, out, t_min, t_max };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
     trace_dispatch<COUNT, REFILL>(sc, n, reinterpret_cast<uint32_t*>(&stats[7]), job, &tc);     // stats[7]: zeroed fetch cursor
     if (COUNT) { wave_add_stat(&stats[3], tc.nodes); wave_add_stat(&stats[4], tc.tris); }
 }
@@ -1059,5 +1074,21 @@ __global__ __launch_bounds__(256) void k_pack_shade_tris(const atn_triangle_para
     q[3] = vtx_nml[i0]; q[4] = vtx_nml[i1]; q[5] = vtx_nml[i2];
     q[6] = h1;
     q[7] = make_float4(h0.x, h0.y, h0.z, 0.0F);
+}
+} // namespace atn
+
+namespace atn {
+// The per-pixel cost map of a count_stats frame (≙ the heat map the reference builds from PathTimeProfiler's per-path GPU
+// timer, renderer/pathtracing/path_time_profiler.h:15-60 -- here the deterministic quantity behind the time: BVH node
+// visits and triangle tests of all the pixel's walks, closest and shadow, all samples of the frame).
+__global__ __launch_bounds__(256) void k_cost_to_pixels(FrameParams fp, const uint32_t* __restrict__ cost, uint32_t* __restrict__ out)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.n_slots) return;
+    int32_t x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    const uint32_t p = (uint32_t)(y * fp.width + x);
+    out[2u * p] = cost[2u * slot];
+    out[2u * p + 1u] = cost[2u * slot + 1u];
 }
 } // namespace atn

@@ -27,7 +27,9 @@ struct Hit {
     int32_t meshid;     // TLAS-leaf mesh id remembered for `prim.mesh_id < 0`
 };
 
-struct TravCounters { uint32_t nodes, tris; };
+// nodes / tris: the thread's totals (COUNT instantiations only); ray_*: the same for the walk in progress, handed to
+// Job::cost when the walk finishes (the per-pixel cost map, atn_download_path_cost)
+struct TravCounters { uint32_t nodes, tris, ray_nodes, ray_tris; };
 
 // Per-ray constants of aabb::hit: invdir = 1 / (dir + 1e-6), oxinvdir = -org * invdir.
 // The reference recomputes them at every node from the same inputs; hoisting is value-identical.
@@ -201,7 +203,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
                 q0 = ld16(nb, off);
                 q1 = ld16(nb, off + 16u);
             }
-            if (COUNT) cnt->nodes++;
+            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             bool box;
             if (all_finite) box = slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
             else box = slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
@@ -217,10 +219,10 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ld16(nb, off);
         const float4 q1 = ld16(nb, off + 16u);
-        if (COUNT) cnt->nodes++;
+        if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         if (w.node & kLinkLeafBit) {
             const float4 q2 = ld16(nb, off + 32u);
-            if (COUNT) cnt->tris++;
+            if (COUNT) { cnt->tris++; cnt->ray_tris++; }
             bool accept; float t;
             is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
             w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
@@ -259,6 +261,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
         if (w.node == kLinkEnd) {
             float4 ra, rb;
             float rstop;
+            if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
             if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start(w, sc, ra, rb, rstop);
         }
     }
@@ -275,7 +278,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ld16(nb, off);
         const float4 q1 = ld16(nb, off + 16u);
-        if (COUNT) cnt->nodes++;
+        if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         bool is_hit;
         if (!(w.node & kLinkTypeMask)) {
             // inner node, or a dead leaf (both links = its miss link).  An inner record's hit link is never kLinkEnd
@@ -287,7 +290,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
         }
         else if (w.node & kLinkLeafBit) {
             const float4 q2 = ld16(nb, off + 32u);
-            if (COUNT) cnt->tris++;
+            if (COUNT) { cnt->tris++; cnt->ray_tris++; }
             bool accept; float t;
             is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
             w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
@@ -347,7 +350,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
             const float4 q0 = ld16(nb, off);
             const float4 q1 = ld16(nb, off + 16u);
-            if (COUNT) cnt->nodes++;
+            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             bool is_hit;
             if (!(w.node & kLinkTypeMask)) {
                 // inner node, or a dead leaf (both links = its miss link).  An inner record's hit link is never kLinkEnd
@@ -359,7 +362,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             }
             else if (w.node & kLinkLeafBit) {
                 const float4 q2 = ld16(nb, off + 32u);
-                if (COUNT) cnt->tris++;
+                if (COUNT) { cnt->tris++; cnt->ray_tris++; }
                 bool accept; float t;
                 is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
                 w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
@@ -394,6 +397,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                 w.ray = w.wray;
             }
         }
+        if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
         if (job.finish(w.payload, w.hit, w.hit.objid >= 0, a, b, stop_t)) goto restart;
     }
 }

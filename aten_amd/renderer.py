@@ -164,6 +164,12 @@ class PathTracing:
         self._check(self._l.atn_upload_film(self._ctx, w, h, film.ctypes.data))
         self.width, self.height = w, h
 
+    def path_cost(self):
+        """uint32 [h, w, 2]: BVH node visits and triangle tests per pixel of the last frame rendered with count_stats=True."""
+        out = np.zeros((self.height, self.width, 2), np.uint32)
+        self._check(self._l.atn_download_path_cost(self._ctx, out.ctypes.data))
+        return out
+
     def stats(self):
         s = np.zeros(8, np.uint64)
         self._check(self._l.atn_get_stats(self._ctx, s.ctypes.data))

@@ -151,6 +151,11 @@ int atn_upload_film(atn_ctx* ctx, int32_t width, int32_t height, const atn_vec4*
  * {closest rays, shadow rays, shaded hits, closest node visits, closest triangle tests,
  *  shadow node visits, shadow triangle tests, 0}. */
 int atn_get_stats(atn_ctx* ctx, uint64_t out[8]);
+/* The per-pixel cost map of the last frame rendered with count_stats = 1: uint32 {BVH node visits, triangle tests}[h][w] of all
+ * the pixel's walks (closest and shadow, every sample and bounce).  ≙ the heat map the reference builds from its per-path GPU
+ * timer (PathTimeProfiler, src/libaten/renderer/pathtracing/path_time_profiler.h:15-60; ComputeTemperature maps it to colours) --
+ * the deterministic quantity behind that time.  Pixels of other ranks' tiles are 0. */
+int atn_download_path_cost(atn_ctx* ctx, uint32_t* out_host);
 
 /* Kernel classes for atn_get_kernel_times. */
 enum { ATN_K_GEN = 0, ATN_K_TRACE_CLOSEST = 1, ATN_K_SHADE = 2, ATN_K_TRACE_SHADOW = 3,

@@ -175,9 +175,11 @@ int32_t orc_ibl_tables(const atn_scene_desc* scene, float* cdf_v, float* cdf_u)
     return 0;
 }
 
-void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
+// cost_out (may be null): uint32 {BVH node visits, triangle tests}[h][w] of all the pixel's walks of this frame -- what the
+// product's atn_download_path_cost reports (its stand-in for the reference's PathTimeProfiler heat map)
+void orc_render_cost(const atn_scene_desc* scene, const atn_camera_param* camera,
     const uint32_t* seeds, uint32_t n_seeds, const orc_destination* dst, atn_vec4* film,
-    uint64_t* counters_out)
+    uint64_t* counters_out, uint32_t* cost_out)
 {
     Scene ctxt(scene);
     if (sampling_options().ibl_importance && ctxt.cfg().bg.envmap_tex_idx >= 0 && ctxt.cfg().bg.enable_env_map)
@@ -189,7 +191,7 @@ void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
     if (rrDepth > maxDepth) rrDepth = maxDepth - 1;     // pathtracing.cpp:282-284
 
     uint64_t c_closest = 0, c_shadow = 0, c_hits = 0, c_nodes = 0, c_tris = 0;
-    const bool count = counters_out != nullptr;
+    const bool count = counters_out != nullptr || cost_out != nullptr;
     if (dst->nthreads > 0) omp_set_num_threads(dst->nthreads);
 
 #pragma omp parallel for reduction(+:c_closest,c_shadow,c_hits,c_nodes,c_tris)
@@ -227,12 +229,20 @@ void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
             }
             c_closest += pc.closest_rays; c_shadow += pc.shadow_rays; c_hits += pc.hits;
             c_nodes += pc.trav.nodes; c_tris += pc.trav.tris;
+            if (cost_out) { cost_out[2 * (size_t)idx] = (uint32_t)pc.trav.nodes; cost_out[2 * (size_t)idx + 1] = (uint32_t)pc.trav.tris; }
         }
     }
     if (counters_out) {
         counters_out[0] = c_closest; counters_out[1] = c_shadow; counters_out[2] = c_hits;
         counters_out[3] = c_nodes; counters_out[4] = c_tris;
     }
+}
+
+void orc_render(const atn_scene_desc* scene, const atn_camera_param* camera,
+    const uint32_t* seeds, uint32_t n_seeds, const orc_destination* dst, atn_vec4* film,
+    uint64_t* counters_out)
+{
+    orc_render_cost(scene, camera, seeds, n_seeds, dst, film, counters_out, nullptr);
 }
 
 int orc_num_procs() { return omp_get_num_procs(); }

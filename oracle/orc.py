@@ -98,6 +98,16 @@ def material_table(scene, mtrl_id, nrm, wi, index, scramble, uv):
     return s, e
 
 
+def render_cost(scene, cam, seeds, width, height, max_depth=5, rr_depth=3, spp=1, frame=0):
+    """Per-pixel {BVH node visits, triangle tests} of one frame: uint32 [h, w, 2] (and the film)."""
+    film = np.zeros((height, width, 4), np.float32)
+    cost = np.zeros((height, width, 2), np.uint32)
+    d = Destination(width, height, max_depth, rr_depth, spp, frame, 1, 0)
+    lib().orc_render_cost(scene.ref(), C.c_void_p(cam.ctypes.data), C.c_void_p(seeds.ctypes.data), C.c_uint32(len(seeds)),
+                          C.byref(d), C.c_void_p(film.ctypes.data), None, C.c_void_p(cost.ctypes.data))
+    return cost, film
+
+
 def render(scene, cam, seeds, width, height, max_depth=5, rr_depth=3, spp=1, frame=0,
            film=None, progressive=True, nthreads=0, counters=False):
     """aten::PathTracing::render on the CPU oracle.  Returns film [h, w, 4] (row 0 = bottom)."""

@@ -346,6 +346,40 @@ def test_counters_match_oracle(gpu, orc, cornell):
     assert abs((s["closest_nodes"] + s["shadow_nodes"]) - int(cnt[3])) <= 2e-3 * int(cnt[3])
 
 
+def test_path_cost_map_matches_oracle(gpu, orc, cornell):
+    """atn_download_path_cost -- the per-pixel cost map (BVH node visits, triangle tests of all the pixel's walks) that
+    stands in for the heat map of the reference's per-path GPU timer (path_time_profiler.h:15-60): integer work, equal
+    to the oracle's per-pixel counters wherever the path did not diverge (Cornell: its shadow rays aim at an area
+    light, so they walk to the closest hit on both sides)."""
+    fs, c, seeds = _setup(gpu, orc, cornell, 96, 96)
+    gpu.reset()
+    film = gpu.render(96, 96, 5, 3, frame=0, count_stats=True)
+    got = gpu.path_cost()
+    want, wfilm = orc.render_cost(fs, c, seeds, 96, 96, 5, 3, frame=0)
+    assert got.shape == want.shape == (96, 96, 2)
+    same = (got == want).all(axis=-1)
+    assert same.mean() > 0.995, same.mean()
+    assert abs(int(got[..., 0].sum()) - int(want[..., 0].sum())) <= 2e-3 * int(want[..., 0].sum())
+    st = gpu.stats()
+    assert int(got[..., 0].sum()) == st["closest_nodes"] + st["shadow_nodes"]      # the map adds up to the frame's totals
+    assert int(got[..., 1].sum()) == st["closest_tris"] + st["shadow_tris"]
+    assert got[..., 0].max() > 1.5 * np.median(got[..., 0]) and got[..., 0].min() < 0.5 * np.median(got[..., 0])   # it is a map
+    # counting changes nothing in the image
+    gpu.reset()
+    assert gpu.render(96, 96, 5, 3, frame=0).tobytes() == film.tobytes()
+
+
+def test_path_cost_needs_a_counted_frame():
+    from aten_amd.renderer import AtenAmdError, PathTracing
+    r = PathTracing(0)
+    try:
+        r.width, r.height = 8, 8
+        with pytest.raises(AtenAmdError, match="count_stats"):
+            r.path_cost()
+    finally:
+        r.close()
+
+
 def test_spp_and_break_on_terminate_quirk(gpu, orc, cornell):
     """pathtracing.cpp:350-352: with spp > 1 the CPU renderer stops sampling a pixel after its first
     terminated path.  Reproduced behind break_on_terminate (default on)."""

@@ -73,6 +73,7 @@ public:
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
     int env_shade_items = 0, env_flavour = -1, env_first_simple = 1;
+    uint32_t env_simple_mask = 0;       // experiment: bit b = launch b of a sample on the plain walk
 
     // scene (HBM-resident after UpdateSceneData)
     DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint, shade_tris;
@@ -412,6 +413,7 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
+        if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -1046,7 +1048,7 @@ public:
                         prof_begin(prof, ATN_K_TRACE_FUSED, st);
                         // the first launch holds only primary rays: coherent, they finish together, and the refill bookkeeping buys
                         // nothing (sponza_lod 4.33 -> 4.30 ms, atrium 4K 221 -> 219 ms)
-                        const bool refill_now = use_refill && !(b == 0 && env_first_simple);
+                        const bool refill_now = use_refill && !((env_simple_mask >> b) & 1u) && !(b == 0 && env_first_simple);
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / simple_block)), tb(refill_now ? (uint32_t)kTraceBlock : simple_block);
                         const uint32_t lds = (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
                         if (refill_now) {

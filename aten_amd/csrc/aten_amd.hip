@@ -1045,10 +1045,12 @@ public:
                     const uint32_t g_fused = trace_grid(2u * n);
                     for (int32_t b = 0; b <= d->maxDepth; b++) {
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
-                        prof_begin(prof, ATN_K_TRACE_FUSED, st);
                         // the first launch holds only primary rays: coherent, they finish together, and the refill bookkeeping buys
                         // nothing (sponza_lod 4.33 -> 4.30 ms, atrium 4K 221 -> 219 ms)
                         const bool refill_now = use_refill && !((env_simple_mask >> b) & 1u) && !(b == 0 && env_first_simple);
+                        // (timed under "trace_closest" when it is a different kernel from the other launches: the roofline of
+                        // k_trace_fused<true, .> is about those)
+                        prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / simple_block)), tb(refill_now ? (uint32_t)kTraceBlock : simple_block);
                         const uint32_t lds = (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
                         if (refill_now) {

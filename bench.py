@@ -61,10 +61,13 @@ def profile_counters(scene, w, h, spp, depth, svgf):
 def kernel_entry(counters, prefix):
     if not counters:
         return None
+    # several instantiations may share the prefix (e.g. the first launch of a sample runs k_trace_fused<false, .>, the
+    # other five k_trace_fused<true, .>): the one with the most launches is the kernel the roofline is about
+    best = None
     for k, e in counters[1]["kernels"].items():
-        if k.startswith(prefix):
-            return e
-    return None
+        if k.startswith(prefix) and (best is None or e.get("launches_sampled", 0) > best.get("launches_sampled", 0)):
+            best = e
+    return best
 
 
 def usable_cpus():

@@ -525,7 +525,14 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL writes "Hostname : ... / Librccl path : ..." into the C library's stdout buffer, which would otherwise be
+        # flushed at exit, after the JSON line: drain both buffers first
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)      # the one JSON line, after every library has had its say
 
 

@@ -523,6 +523,14 @@ def main():
         }
     r.close()
     if use_dist:
+        # every rank drains its own buffers (RCCL's banner sits in the C library's) BEFORE rank 0 writes the JSON line
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL writes "Hostname : ... / Librccl path : ..." into the C library's stdout buffer, which would otherwise be

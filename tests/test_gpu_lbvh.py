@@ -278,6 +278,35 @@ def test_ticks_touching_different_ranges_are_replayed(orc, room):
         r.close()
 
 
+def test_tick_loop_soak(room):
+    """400 ticks + frames back to back with three frames in flight (an SVGF frame now and then): no hang, no growth of
+    device memory once the scene sets and the staging arena exist, a finite film."""
+    import torch
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    w, h = 320, 200
+    ticks = [tick_data(b, oid, 0.5 * k) for k in range(4)]
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(ticks[0][0]); r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h)); r.initSampler(w, h, 0)
+        r.set_frames_in_flight(3)
+        free0 = None
+        for i in range(400):
+            fs, d = ticks[i % 4]
+            push_tick(r, fs, d)
+            r.render(w, h, frame=i, download=False)
+            if i % 9 == 4:
+                r.svgf_render(w, h, frame=i, compute_motion=True, download=False)
+            if i == 60:
+                r.synchronize()
+                free0 = torch.cuda.mem_get_info()[0]
+        r.synchronize()
+        assert abs(free0 - torch.cuda.mem_get_info()[0]) < 64e6
+        assert np.isfinite(r.download_film()).all()
+    finally:
+        r.close()
+
+
 def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
     from aten_amd.renderer import PathTracing
     b, oid, cam = room

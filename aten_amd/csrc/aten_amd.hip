@@ -141,6 +141,7 @@ public:
         int32_t counters_depth = 0;
         uint64_t bank_epoch = 0;
         int scene_set = 0;
+        hipEvent_t ev_read[3] = {};     // [scene set id]: the last frame of this bank that read that set has finished with the scene
         hipStream_t stream = nullptr, bstream[kMaxBatches] = {};
         hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {}, ev_gather = nullptr;
     };
@@ -157,6 +158,7 @@ public:
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
         counters.swap(b.counters);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
+        for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
         for (int k = 0; k < kMaxBatches; k++) { std::swap(bstream[k], b.bstream[k]); std::swap(ev_join[k], b.ev_join[k]); }
     }
@@ -221,6 +223,7 @@ public:
     int n_alt = 0;                                  // allocated sets besides the current one
     bool frame_since_update = true, scene_in_place = false;
     int cur_set = 0, bank_scene_set = 0;            // ids; bank_scene_set: the set this bank's last frame read (travels with the bank)
+    hipEvent_t ev_read[3] = {};                     // the current bank's (see Bank::ev_read)
     uint64_t cur_tick = 0, tick_counter = 0;
     std::vector<SceneRange> log_now;                // what the updates since the last flip wrote into the current set
     struct TickLog { uint64_t tick; std::vector<SceneRange> ranges; };
@@ -293,9 +296,11 @@ public:
             t = &alt[0];
             for (int k = 1; k < n_alt; k++) if (alt[k].tick < t->tick) t = &alt[k];
             // the frames that still read it: its writers go behind them
+            // (per bank and set, not "the bank's last frame": an older frame of a bank may still be running behind a newer
+            // one that reads another set)
             for (int i = 0; i < n_spare_ready; i++)
-                if (spare[i].scene_set == t->id && spare[i].ev_gather) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_gather, 0));
-            if (bank_scene_set == t->id && ev_gather) ATN_HIP(hipStreamWaitEvent(upd, ev_gather, 0));
+                if (spare[i].ev_read[t->id]) ATN_HIP(hipStreamWaitEvent(upd, spare[i].ev_read[t->id], 0));
+            if (ev_read[t->id]) ATN_HIP(hipStreamWaitEvent(upd, ev_read[t->id], 0));
             // what the ticks since its own wrote into the other sets is missing there: the current set has all of it
 #ifndef ATN_DEBUG_NO_REPLAY      /* (the tests' negative control: without the replay test_ticks_touching_different_ranges_are_replayed fails) */
             for (const TickLog& L : log_hist)
@@ -368,6 +373,15 @@ public:
         ATN_HIP(hipEventRecord(ev_scene, upd));
         scene_epoch++;
         if (upd == stream) bank_epoch = scene_epoch;       // this bank's stream is already behind the update
+        return ATN_OK;
+    }
+    // a frame's last read of the scene is behind it on its stream
+    int record_scene_read()
+    {
+        if (frames_in_flight <= 1) return ATN_OK;
+        hipEvent_t& e = ev_read[bank_scene_set];
+        if (!e) ATN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ATN_HIP(hipEventRecord(e, stream));
         return ATN_OK;
     }
     // first thing a frame does on its bank's stream
@@ -445,10 +459,12 @@ public:
             }
             if (b.ev_fork) (void)hipEventDestroy(b.ev_fork);
             if (b.ev_gather) (void)hipEventDestroy(b.ev_gather);
+            for (auto& e : b.ev_read) if (e) (void)hipEventDestroy(e);
             if (b.stream) (void)hipStreamDestroy(b.stream);
         }
         if (stream) (void)hipStreamDestroy(stream);
         if (scene_stream) (void)hipStreamDestroy(scene_stream);
+        for (auto& e : ev_read) if (e) (void)hipEventDestroy(e);
         if (ev_scene) (void)hipEventDestroy(ev_scene);
         if (ev_stage) (void)hipEventDestroy(ev_stage);
         if (stage_p) (void)hipHostFree(stage_p);
@@ -1130,7 +1146,7 @@ public:
         else hipLaunchKernelGGL((k_gather<false>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
-        if (frames_in_flight > 1) ATN_HIP(hipEventRecord(ev_gather, stream));
+        if (frames_in_flight > 1) { ATN_HIP(hipEventRecord(ev_gather, stream)); rc = record_scene_read(); if (rc) return rc; }
 
         if (count) {
             hipLaunchKernelGGL(k_cost_to_pixels, dim3(g_all), dim3(256), 0, stream, fp, (const uint32_t*)cost.p, cost_film.p);
@@ -1343,6 +1359,8 @@ public:
             if (rc) return rc;
             if (pipelined) {
                 ATN_HIP(hipEventRecord(ev_gather, stream));         // this bank's "path pass done"
+                rc = record_scene_read();
+                if (rc) return rc;
                 ATN_HIP(hipStreamWaitEvent(fs, ev_gather, 0));
             }
         }

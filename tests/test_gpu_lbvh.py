@@ -314,6 +314,56 @@ def test_tick_loop_soak(room):
         r.close()
 
 
+def test_random_call_sequences_do_not_depend_on_frames_in_flight(room):
+    """The same pseudo-random sequence of calls -- frames, deformation ticks, camera moves, resets, counted frames, film
+    downloads, SVGF frames -- with one frame in flight and with two to four: every downloaded film must be the same, byte for byte (the
+    pipelining, the scene sets and the staging arena are invisible in the results)."""
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    w, h = 192, 128
+    ticks = [tick_data(b, oid, 0.7 * k) for k in range(5)]
+    cams = [create_camera(cam["pos"], cam["at"], cam["vfov"], w, h), create_camera((0.4, 1.2, 2.8), cam["at"], 50.0, w, h)]
+
+    def run(fif, seed):
+        rng = np.random.default_rng(seed)
+        r = PathTracing(0)
+        films = []
+        try:
+            r.UpdateSceneData(ticks[0][0]); r.updateCamera(cams[0]); r.initSampler(w, h, 0)
+            r.set_frames_in_flight(fif)
+            r.render(w, h, frame=0, download=False)
+            frame = 1
+            for _ in range(160):
+                op = rng.choice(["frame", "frame", "frame", "tick", "tick", "camera", "reset", "counted", "download", "svgf"])
+                if op == "frame":
+                    r.render(w, h, frame=frame, download=False); frame += 1
+                elif op == "tick":
+                    fs, d = ticks[int(rng.integers(0, 5))]
+                    push_tick(r, fs, d)
+                elif op == "camera":
+                    r.updateCamera(cams[int(rng.integers(0, 2))])
+                elif op == "reset":
+                    r.reset()
+                elif op == "svgf":
+                    films.append(r.svgf_render(w, h, frame=frame, compute_motion=True).copy()); frame += 1
+                elif op == "counted":
+                    r.render(w, h, frame=frame, download=False, count_stats=True); frame += 1
+                    films.append(r.path_cost().astype(np.float32).sum(axis=-1, keepdims=True).repeat(4, axis=-1))
+                else:
+                    films.append(r.download_film().copy())
+            films.append(r.download_film().copy())
+        finally:
+            r.close()
+        return films
+
+    for seed in (1, 2, 3):
+        a, c = run(1, seed), run(2 + seed % 3, seed)
+        assert len(a) == len(c) and len(a) > 5
+        for x, y in zip(a, c):
+            assert x.tobytes() == y.tobytes()
+        assert np.isfinite(a[-1]).all() and a[-1][..., :3].max() > 0
+
+
 def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
     from aten_amd.renderer import PathTracing
     b, oid, cam = room

@@ -364,6 +364,34 @@ def test_random_call_sequences_do_not_depend_on_frames_in_flight(room):
         assert np.isfinite(a[-1]).all() and a[-1][..., :3].max() > 0
 
 
+def test_tick_loop_on_shards_equals_single_context(room):
+    """The whole-node renderer through a run of ticks and frames (three shards sharing the GPU, two frames in flight on
+    every shard, nothing waited for): the assembled film equals the single context's, byte for byte."""
+    from aten_amd.renderer import MultiGpuPathTracing, PathTracing
+    b, oid, cam = room
+    w, h = 200, 136
+    ticks = [tick_data(b, oid, 0.6 * k) for k in range(4)]
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], w, h)
+    r = PathTracing(0)
+    mg = MultiGpuPathTracing([0, 0, 0])
+    try:
+        for x in (r, mg):
+            x.UpdateSceneData(ticks[0][0]); x.updateCamera(c); x.initSampler(w, h, 0)
+        r.set_frames_in_flight(3); mg.set_frames_in_flight(2)
+        for i in range(40):
+            fs, d = ticks[(i * 3) % 4]
+            for x in (r, mg):
+                push_tick(x, fs, d)
+                x.render(w, h, frame=i, download=False)
+                if i % 11 == 5:
+                    x.render(w, h, frame=100 + i, download=False)          # two frames on one tick
+        a, m = r.download_film(), mg.download_film()
+        assert a.tobytes() == m.tobytes()
+        assert (a[..., 3] == 40 + 4).all()
+    finally:
+        r.close(); mg.close()
+
+
 def test_rebuild_rejects_lists_of_another_shape(orc, room, sponza):
     from aten_amd.renderer import PathTracing
     b, oid, cam = room

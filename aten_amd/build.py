@@ -68,7 +68,18 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+def build_ref(force=False):
+    """oracle/_ref/libatenref.so from the reference's untouched sampler / math sources (oracle/Makefile `_ref`);
+    skipped where /root/reference does not exist (the GPU box uses the prebuilt file / the fixtures)."""
+    ref = os.environ.get("ATEN_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "src", "libaten", "sampler")):
+        return None
+    cmd = ["make", "-C", os.path.join(ROOT, "oracle"), "_ref", "REF=" + ref]
+    _run(cmd + (["-B"] if force else []))
+    return os.path.join(ROOT, "oracle", "_ref", "libatenref.so")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["host", "hip", "oracle"]
     for w in what:
-        {"host": build_host, "hip": build_hip, "oracle": build_oracle}[w](force=True)
+        {"host": build_host, "hip": build_hip, "oracle": build_oracle, "ref": build_ref}[w](force=True)

@@ -149,7 +149,11 @@ public:
     int frames_in_flight = 1, n_spare_ready = 0;
     uint64_t frame_seq = 0;
     hipEvent_t ev_gather = nullptr;         // the current bank's "film updated" event
-    hipEvent_t last_gather = nullptr;       // the previous frame's, when it ran on another bank
+    // the film is one running mean shared by every bank: its last writer (a render()'s k_gather, or reset()'s clear).  One
+    // event owned by the context, NOT by a bank -- svgf_render rotates banks without writing the film, so "the previous
+    // bank's ev_gather" is not the film's last writer.  (A wait refers to the record that precedes it; re-recording is fine.)
+    hipEvent_t ev_film = nullptr;
+    bool film_pending = false;
 
     void swap_bank(Bank& b)
     {
@@ -179,6 +183,9 @@ public:
                 ATN_HIP(hipEventCreateWithFlags(&b.ev_join[k], hipEventDisableTiming));
             }
         }
+        // the spare scene sets are only kept current while ticks flip through them: an in-place update (one frame in
+        // flight) is not logged, so sets kept across N -> 1 -> N would come back stale.  Re-clone at the next flip.
+        if (n != frames_in_flight) drop_alt_set();
         frames_in_flight = n;
         return ATN_OK;
     }
@@ -190,7 +197,7 @@ public:
         for (int i = 0; i < n_spare_ready; i++) ATN_HIP(hipStreamSynchronize(spare[i].stream));
         if (sv_stream) ATN_HIP(hipStreamSynchronize(sv_stream));
         if (scene_stream) ATN_HIP(hipStreamSynchronize(scene_stream));
-        last_gather = nullptr;
+        film_pending = false;
         sv_prepare_recorded[0] = sv_prepare_recorded[1] = false;
         return ATN_OK;
     }
@@ -347,6 +354,7 @@ public:
             if (frame_since_update) { int r = flip_scene_set(); if (r) return r; frame_since_update = false; }
             return ATN_OK;
         }
+        if (n_alt > 0 && frames_in_flight <= 1) drop_alt_set();   // written in place and unlogged: spare sets would miss this update (set_frames_in_flight quiesced)
         log_now.clear();        // (no other set to replay into)
         // in place, behind every frame in flight: a bank's ev_gather is recorded after its last kernel that reads the scene
         // (the filter stream of pipelined SVGF frames never reads the scene)
@@ -450,6 +458,7 @@ public:
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
         for (auto& e : sv_ev_prepare) if (e) (void)hipEventDestroy(e);
+        if (ev_film) (void)hipEventDestroy(ev_film);
         if (sv_stream) (void)hipStreamDestroy(sv_stream);
         for (int i = 0; i < n_spare_ready; i++) {
             Bank& b = spare[i];
@@ -821,6 +830,17 @@ public:
         return ATN_OK;
     }
 
+    // ≙ aten::getRandom(), src/libaten/sampler/sampler.cpp:20-23: the table as the kernels read it
+    int getRandom(uint32_t* out, uint32_t n)
+    {
+        if (!out || n == 0 || n > n_seeds) return fail(ATN_ERR_INVALID_ARG, "atn_get_random: null output or more entries than the sampler holds");
+        ATN_HIP(hipSetDevice(device));
+        { int q = quiesce(); if (q) return q; }
+        ATN_HIP(hipMemcpyAsync(out, seeds.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        ATN_HIP(hipStreamSynchronize(stream));
+        return ATN_OK;
+    }
+
     // ≙ aten::initSampler, src/libaten/sampler/sampler.cpp:8-18
     int initSampler(int32_t w, int32_t h, int32_t seed)
     {
@@ -1116,7 +1136,6 @@ public:
             if (count) { rc = quiesce(); if (rc) return rc; }       // the counters are one set, read back synchronously
             else {
                 // rotate: the bank that has been idle longest becomes the current one
-                last_gather = ev_gather;
                 swap_bank(spare[frame_seq % (uint64_t)(frames_in_flight - 1)]);
             }
         }
@@ -1140,13 +1159,17 @@ public:
         rc = run_paths<false>(d, fp, count, prof, SvgfShade{}, SvgfFrame{});
         if (rc) return rc;
         fp.slot_begin = 0; fp.slot_end = (int32_t)n_slots;
-        if (last_gather) ATN_HIP(hipStreamWaitEvent(stream, last_gather, 0));     // the film is a running mean: frame order
+        if (film_pending) ATN_HIP(hipStreamWaitEvent(stream, ev_film, 0));     // the film is a running mean: frame order
         prof_begin(prof, ATN_K_GATHER);
         if (d->sample == 1) hipLaunchKernelGGL((k_gather<true>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         else hipLaunchKernelGGL((k_gather<false>), dim3(g_all), dim3(256), 0, stream, pb, fp, film.p, tile_out.p);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
-        if (frames_in_flight > 1) { ATN_HIP(hipEventRecord(ev_gather, stream)); rc = record_scene_read(); if (rc) return rc; }
+        if (frames_in_flight > 1) {
+            ATN_HIP(hipEventRecord(ev_gather, stream)); rc = record_scene_read(); if (rc) return rc;
+            if (!ev_film) ATN_HIP(hipEventCreateWithFlags(&ev_film, hipEventDisableTiming));
+            ATN_HIP(hipEventRecord(ev_film, stream)); film_pending = true;
+        }
 
         if (count) {
             hipLaunchKernelGGL(k_cost_to_pixels, dim3(g_all), dim3(256), 0, stream, fp, (const uint32_t*)cost.p, cost_film.p);
@@ -1368,7 +1391,6 @@ public:
         prof_begin(prof, ATN_K_SVGF_PREPARE, fs);
         hipLaunchKernelGGL(k_svgf_prepare, gp, tp, 0, fs, sf);
         prof_end(prof);
-        if (pipelined) { ATN_HIP(hipEventRecord(sv_ev_prepare[slot], fs)); sv_prepare_recorded[slot] = true; }    // the slot is free again
         if (path_pass) sv_slot = 1 - sv_slot;
         if (d->frame > 0) {
             prof_begin(prof, ATN_K_SVGF_TEMPORAL, fs);
@@ -1384,6 +1406,9 @@ public:
             // frame 0: the temporal pass only re-puts the raw contribution (svgf.cpp:549-551)
             ATN_HIP(hipMemcpyAsync(sf.stages + (size_t)d->width * d->height, sf.stages, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToDevice, fs));
         }
+        // the slot is free again only now: k_svgf_temporal is the last reader of the hand-over planes (it re-reads
+        // sf.contribs[slot]); recording this right behind k_svgf_prepare let frame f + 2's k_svgf_sample_end overwrite them
+        if (pipelined) { ATN_HIP(hipEventRecord(sv_ev_prepare[slot], fs)); sv_prepare_recorded[slot] = true; }
         prof_begin(prof, ATN_K_SVGF_VARIANCE, fs);
         hipLaunchKernelGGL(k_svgf_variance, gp, tp, 0, fs, sf);
         prof_end(prof);
@@ -1414,6 +1439,10 @@ public:
             ATN_HIP(hipSetDevice(device));
             { int q = quiesce(); if (q) return q; }
             ATN_HIP(hipMemsetAsync(film.p, 0, film.n * sizeof(float4), stream));
+            if (frames_in_flight > 1) {     // the next frame runs on another bank's stream: its k_gather goes behind the clear
+                if (!ev_film) ATN_HIP(hipEventCreateWithFlags(&ev_film, hipEventDisableTiming));
+                ATN_HIP(hipEventRecord(ev_film, stream)); film_pending = true;
+            }
         }
         return ATN_OK;
     }
@@ -1526,6 +1555,8 @@ int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void**
     return ATN_OK;
 }
 int atn_init_sampler(atn_ctx* ctx, int32_t w, int32_t h, int32_t seed) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.initSampler(w, h, seed); }); }
+int atn_get_random(atn_ctx* ctx, uint32_t* out_host, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.getRandom(out_host, n); }); }
+uint32_t atn_random_count(atn_ctx* ctx) { return ctx ? ctx->r.n_seeds : 0; }
 int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n) { CTX_QUIET_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.setRandom(seeds, n); }); }
 
 int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
@@ -1904,6 +1935,26 @@ int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t s
     C_HIP(r, out.resize(n));
     hipLaunchKernelGGL(atn::k_cmj_samples, dim3(1), dim3(64), 0, r.stream, index, dimension, scramble, n, out.p);
     C_HIP(r, hipMemcpyAsync(out_host, out.p, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
+int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble,
+                  int32_t draws, float* out_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (n == 0 || draws <= 0 || !index || !dimension || !scramble || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "bad cmj batch");
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<uint32_t> di, dd, ds; atn::DevBuf<float> out;
+    C_HIP(r, di.resize(n)); C_HIP(r, dd.resize(n)); C_HIP(r, ds.resize(n)); C_HIP(r, out.resize((size_t)n * draws));
+    C_HIP(r, hipMemcpyAsync(di.p, index, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(dd.p, dimension, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(ds.p, scramble, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    hipLaunchKernelGGL(atn::k_cmj_batch, dim3((n + 255) / 256), dim3(256), 0, r.stream, n, (const uint32_t*)di.p,
+                       (const uint32_t*)dd.p, (const uint32_t*)ds.p, (int)draws, out.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, 4 * (size_t)n * draws, hipMemcpyDeviceToHost, r.stream));
     C_HIP(r, hipStreamSynchronize(r.stream));
     return ATN_OK;
 }

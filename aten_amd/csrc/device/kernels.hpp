@@ -995,6 +995,16 @@ __global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim
     }
 }
 
+// one thread per (index, dimension, scramble) triple: `draws` successive nextSample()
+__global__ void __launch_bounds__(256) k_cmj_batch(uint32_t n, const uint32_t* __restrict__ index, const uint32_t* __restrict__ dim,
+                                                   const uint32_t* __restrict__ scramble, int draws, float* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Cmj s; s.idx = index[k]; s.dim = dim[k]; s.scramble = scramble[k];
+    for (int d = 0; d < draws; d++) out[(size_t)k * draws + d] = cmj_next(s);
+}
+
 __global__ void __launch_bounds__(256) k_sample_texture(DevScene sc, int32_t texid, uint32_t n, const float* __restrict__ uv, float* out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

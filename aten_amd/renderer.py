@@ -64,6 +64,8 @@ class PathTracing:
         from . import layout as L
         pos = None if vtx_pos is None else np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
         nml = None if vtx_nml is None else np.ascontiguousarray(vtx_nml, np.float32).reshape(-1, 4)
+        if pos is not None and nml is not None and len(pos) != len(nml):
+            raise ValueError("updateGeometry: %d positions but %d normals (the C ABI takes ONE vertex count for both arrays)" % (len(pos), len(nml)))
         nv = len(pos) if pos is not None else (len(nml) if nml is not None else 0)
         tr = None if triangles is None else np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
         self._check(self._l.atn_update_geometry(self._ctx, pos.ctypes.data if pos is not None else None, nml.ctypes.data if nml is not None else None,
@@ -102,6 +104,12 @@ class PathTracing:
     def setRandom(self, seeds):
         seeds = np.ascontiguousarray(seeds, np.uint32)
         self._check(self._l.atn_set_random(self._ctx, seeds.ctypes.data, len(seeds)))
+
+    def getRandom(self):
+        out = np.zeros(self._l.atn_random_count(self._ctx), np.uint32)
+        if len(out):
+            self._check(self._l.atn_get_random(self._ctx, out.ctypes.data, len(out)))
+        return out
 
     def setScreenShard(self, rank, world):
         self._check(self._l.atn_set_screen_shard(self._ctx, rank, world))
@@ -254,6 +262,16 @@ class PathTracing:
         self._check(self._l.atn_cmj_samples(self._ctx, index, dimension, scramble, n, out.ctypes.data))
         return out
 
+    def cmj_batch(self, index, dimension, scramble, draws=1):
+        index = np.ascontiguousarray(index, np.uint32); dimension = np.ascontiguousarray(dimension, np.uint32)
+        scramble = np.ascontiguousarray(scramble, np.uint32)
+        if not (len(index) == len(dimension) == len(scramble)):
+            raise ValueError("index, dimension and scramble must have one entry per triple")
+        out = np.zeros((len(index), draws), np.float32)
+        self._check(self._l.atn_cmj_batch(self._ctx, len(index), index.ctypes.data, dimension.ctypes.data,
+                                          scramble.ctypes.data, draws, out.ctypes.data))
+        return out
+
     def material_table(self, mtrl_id, nrm, wi, index, scramble, uv):
         n = len(nrm)
         nrm = np.ascontiguousarray(nrm, np.float32); wi = np.ascontiguousarray(wi, np.float32)
@@ -339,6 +357,8 @@ class MultiGpuPathTracing:
         from . import layout as L
         pos = None if vtx_pos is None else np.ascontiguousarray(vtx_pos, np.float32).reshape(-1, 4)
         nml = None if vtx_nml is None else np.ascontiguousarray(vtx_nml, np.float32).reshape(-1, 4)
+        if pos is not None and nml is not None and len(pos) != len(nml):
+            raise ValueError("updateGeometry: %d positions but %d normals (the C ABI takes ONE vertex count for both arrays)" % (len(pos), len(nml)))
         nv = len(pos) if pos is not None else (len(nml) if nml is not None else 0)
         tr = None if triangles is None else np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
         self._check(self._l.atn_mgpu_update_geometry(self._mg, pos.ctypes.data if pos is not None else None, nml.ctypes.data if nml is not None else None,

@@ -113,6 +113,10 @@ int atn_lbvh_build(atn_ctx* ctx, const atn_triangle_param* triangles, uint32_t n
 int atn_init_sampler(atn_ctx* ctx, int32_t width, int32_t height, int32_t seed);
 /* Same, with caller-provided seeds (aten::getRandom()). */
 int atn_set_random(atn_ctx* ctx, const uint32_t* seeds, uint32_t n);
+/* ≙ aten::getRandom() (src/libaten/sampler/sampler.cpp:20-23): the first n entries of the table the kernels
+ * read, copied back from HBM; atn_random_count = its size (0 before atn_init_sampler / atn_set_random). */
+int atn_get_random(atn_ctx* ctx, uint32_t* out_host, uint32_t n);
+uint32_t atn_random_count(atn_ctx* ctx);
 
 /* Screen-space sharding for multi-GPU: the image is cut into 8x8-pixel tiles, tile t (row-major)
  * is rendered by rank t % world.  Default (0, 1) = whole image.  No reference analogue (the
@@ -285,6 +289,10 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
                       atn_intersection* out_host, uint64_t* stats_out);
 /* n successive CMJ::nextSample() (src/libaten/sampler/cmj.h:32-37). */
 int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t scramble, int32_t n, float* out_host);
+/* For each of n (index, dimension, scramble) triples: CMJ::init then `draws` x nextSample()
+ * (src/libaten/sampler/cmj.h:21-37); out_host[k * draws + d]. */
+int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble,
+                  int32_t draws, float* out_host);
 /* material::sampleMaterial / samplePDF / sampleBSDF tables (src/libaten/material/material_impl.h:24-206).
  * out_sample: n*7 {dir, bsdf, pdf}; out_eval: n*5 {samplePDF, sampleBSDF.bsdf, sampleBSDF.pdf} at wo = dir. */
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,

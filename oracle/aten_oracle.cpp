@@ -30,6 +30,45 @@ void orc_cmj_samples(uint32_t index, uint32_t dimension, uint32_t scramble, int 
     for (int i = 0; i < n; i++) out[i] = c.nextSample();
 }
 
+// n successive CMJ::nextSample2D(): out[2i] = x, out[2i+1] = y (cmj.h:39-44)
+void orc_cmj_samples2d(uint32_t index, uint32_t dimension, uint32_t scramble, int n, float* out)
+{
+    CMJ c; c.init(index, dimension, scramble);
+    for (int i = 0; i < n; i++) c.nextSample2D(out[2 * i], out[2 * i + 1]);
+}
+
+// per triple k: init(idx[k], dim[k], scr[k]) then `draws` x nextSample()  (twin of oracle/ref_driver.cpp)
+void orc_cmj_batch(int32_t n, const uint32_t* idx, const uint32_t* dim, const uint32_t* scr, int32_t draws, float* out)
+{
+    for (int32_t k = 0; k < n; k++) {
+        CMJ c; c.init(idx[k], dim[k], scr[k]);
+        for (int32_t d = 0; d < draws; d++) out[(size_t)k * draws + d] = c.nextSample();
+    }
+}
+
+// The oracle's restatements of math/math.h's scalar helpers, by the kinds of ref_math_kat (oracle/ref_driver.cpp),
+// so that tests/test_ref_pin.py can hold them against the reference's own header.
+void orc_math_kat(int32_t kind, int32_t n, const float* a, const float* b, const float* c, float* out)
+{
+    for (int32_t i = 0; i < n; i++) {
+        switch (kind) {
+        case 0: out[i] = fmax_(a[i], b[i]); break;                       // math.h:146-150
+        case 1: out[i] = fmin_(a[i], b[i]); break;                       // math.h:172-176
+        case 2: out[i] = clamp_(a[i], b[i], c[i]); break;                // math.h:179-183
+        case 3: out[i] = saturate_(a[i]); break;                         // math.h:185-189
+        case 4: out[i] = ToonSpecular::sign(a[i]); break;                             // math.h:62-73
+        case 5: out[i] = mix(a[i], b[i], c[i]); break;                   // math.h:294-300
+        case 6: out[i] = a[i] * (1.0F - c[i]) + b[i] * c[i]; break;      // math.h:191-194 (lerp, as in orc_core.h's bilinear)
+        case 7: out[i] = isCloseUlps(a[i], b[i], 2500) ? 1.0F : 0.0F; break;   // math.h:308-340
+        case 8: out[i] = (std::isnan(a[i]) || std::isinf(a[i])) ? 1.0F : 0.0F; break;   // math.h:196-204
+        case 9: out[i] = sqr(a[i]); break;                               // math.h:42-45
+        case 10: out[i] = inversesqrt(a[i]); break;                      // math.h:33-40
+        case 11: out[i] = Deg2Rad(a[i]); break;                          // math.h:18-21
+        default: out[i] = 0.0F;
+        }
+    }
+}
+
 void orc_create_camera(atn_camera_param* out, const float* origin, const float* lookat, const float* up,
     float vfov, float z_near, float z_far, int32_t width, int32_t height)
 {

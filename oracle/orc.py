@@ -42,6 +42,31 @@ def cmj_samples(index, dimension, scramble, n):
     return out
 
 
+def cmj_samples2d(index, dimension, scramble, n):
+    out = np.zeros((n, 2), np.float32)
+    lib().orc_cmj_samples2d(C.c_uint32(index), C.c_uint32(dimension), C.c_uint32(scramble), n, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def cmj_batch(index, dimension, scramble, draws=1):
+    index = np.ascontiguousarray(index, np.uint32); dimension = np.ascontiguousarray(dimension, np.uint32)
+    scramble = np.ascontiguousarray(scramble, np.uint32)
+    out = np.zeros((len(index), draws), np.float32)
+    lib().orc_cmj_batch(len(index), C.c_void_p(index.ctypes.data), C.c_void_p(dimension.ctypes.data),
+                        C.c_void_p(scramble.ctypes.data), draws, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def math_kat(kind, a, b=None, c=None):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, np.float32)
+    c = np.zeros_like(a) if c is None else np.ascontiguousarray(c, np.float32)
+    out = np.zeros_like(a)
+    lib().orc_math_kat(kind, len(a), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(c.ctypes.data),
+                       C.c_void_p(out.ctypes.data))
+    return out
+
+
 def create_camera(pos, at, vfov, width, height, up=(0, 1, 0), znear=0.1, zfar=10000.0):
     from aten_amd import layout as L
     cam = np.zeros((), L.CAMERA_PARAM)

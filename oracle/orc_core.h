@@ -88,6 +88,12 @@ struct CMJ {
         m_dimension++;
         return x;
     }
+    void nextSample2D(float& x, float& y)                           // cmj.h:39-44
+    {
+        int32_t idx = permute(m_idx, CMJ_DIM * CMJ_DIM, 0xa399d265 * m_dimension * m_scramble);
+        cmj(idx, CMJ_DIM, m_dimension * m_scramble, x, y);
+        m_dimension++;
+    }
 };
 
 // ---------------------------------------------------------------------------------------

@@ -1,8 +1,10 @@
-"""Mints the golden vectors under tests/golden/ from the CPU oracle (oracle/liboracle.so).
+"""Mints the golden vectors under tests/golden/oracle_golden.npz.
 
-The reference itself cannot be built in this image (empty glm / tinyobjloader / stb / nanovdb
-submodules), so these are ORACLE outputs, not reference outputs: they pin the oracle against
-regressions and give the GPU tests fixed expected values.  Scene inputs: assets/cornellbox/orig.obj
+`seeds_*` and `cmj_*` (the integer rows) come from the REFERENCE itself: oracle/_ref/libatenref.so =
+the untouched sampler/cmj.h + sampler/sampler.cpp compiled here (`make -C oracle _ref`).  The float
+path of the reference cannot be built in this image (empty glm / tinyobjloader / stb / nanovdb
+submodules), so everything else is an ORACLE output, not a reference output: it pins the oracle
+against regressions and gives the GPU tests fixed expected values.  Scene inputs: assets/cornellbox/orig.obj
 (fan triangulation) and assets/sponza/sponza_lod.{obj,sbvh}; our BVH builder for Cornell.
 
     python tests/golden/make_golden.py
@@ -16,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from aten_amd.scene import scenedefs  # noqa: E402
 from oracle import orc  # noqa: E402
+from oracle import ref  # noqa: E402  (the reference's own sampler sources; build container only)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -24,9 +27,9 @@ CMJ_CASES = [(0, 0, 0x12345678), (17, 4, 0x9e3779b9), (255, 0, 1), (100, 7, 0xde
 
 def main():
     g = {}
-    g["seeds_512"] = orc.init_sampler(512, 512, 0)[:64]
+    g["seeds_512"] = ref.init_sampler(512, 512, 0)[:64]
     for i, (idx, dim, scr) in enumerate(CMJ_CASES):
-        g["cmj_%d" % i] = orc.cmj_samples(idx, dim, scr, 1024)
+        g["cmj_%d" % i] = ref.cmj_samples(idx, dim, scr, 1024)
 
     fs, cam = scenedefs.cornell_box()
     W = H = 64

@@ -278,6 +278,56 @@ def test_ticks_touching_different_ranges_are_replayed(orc, room):
         r.close()
 
 
+def test_frames_in_flight_n_to_1_to_n_keeps_scene_sets_current(orc, room):
+    """Advisor finding of round 2: with ONE frame in flight an update is written in place and not logged, so spare scene
+    sets kept from an earlier N > 1 phase came back stale after switching to N > 1 again.  Ticks move different halves of
+    the mesh while the number of frames in flight goes 3 -> 1 -> 3 -> 1 -> 2; the closest-hit records after every phase
+    are the oracle's over the composite geometry."""
+    from aten_amd.renderer import PathTracing
+    b, oid, cam = room
+    fs0, d0 = tick_data(b, oid, 0.0)
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    seeds = orc.init_sampler(W, H, 0)
+    rays = orc.generate_paths(c, seeds, W, H, 0, 0)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs0); r.updateCamera(c); r.initSampler(W, H, 0)
+        n, t0, v0 = d0["n"], d0["t0"], d0["v0"]
+        state = {k: fs0.arrays[k].copy() for k in ("vtx_pos", "vtx_nml", "triangles")}
+        f = 0
+        # (frames in flight, [(time, half of the mesh that moves)])
+        phases = [(3, [(0.6, 0), (1.1, 1), (1.9, 0), (2.4, 1)]), (1, [(3.0, 0)]), (3, [(3.8, 1), (4.1, 1)]),
+                  (1, [(4.9, 1), (5.5, 0)]), (2, [(6.1, 1), (6.6, 1), (7.2, 1)])]
+        for nfl, ticks in phases:
+            r.set_frames_in_flight(nfl)
+            for t, half in ticks:
+                fs, d = tick_data(b, oid, t)
+                tr = slice(t0 + half * (n // 2), t0 + (half + 1) * (n // 2))
+                vr = slice(v0 + 3 * half * (n // 2), v0 + 3 * (half + 1) * (n // 2))
+                for k, sl in (("vtx_pos", vr), ("vtx_nml", vr), ("triangles", tr)):
+                    state[k][sl] = fs.arrays[k][sl]
+                    fs.arrays[k][...] = state[k]
+                used = state["vtx_pos"][d["v0"]:d["v1"], :3]
+                d = dict(d, bmin=used.min(0), bmax=used.max(0))
+                r.updateGeometry(vtx_pos=state["vtx_pos"][vr], vtx_nml=state["vtx_nml"][vr], vtx_offset=vr.start,
+                                 triangles=state["triangles"][tr], tri_offset=tr.start)
+                r.lbvh_rebuild_list(d["list"], d["t0"], d["n"], d["bmin"], d["bmax"])
+                if f == 0:
+                    r.updateBVH(fs)
+                    top = (fs.arrays["objects"].copy(), fs.arrays["matrices"].copy(), fs.arrays["bvh_lists"][0].copy())
+                else:
+                    fs.arrays["objects"][...] = top[0]; fs.arrays["matrices"][...] = top[1]; fs.replace_bvh_list(0, top[2])
+                r.render(W, H, frame=f, download=False)
+                f += 1
+            ofs = oracle_scene_with_lbvh(orc, fs, d)
+            wi, _ = orc.trace_closest(ofs, rays)
+            assert r.trace_closest(rays).tobytes() == wi.tobytes(), "after the phase with %d frame(s) in flight" % nfl
+        with pytest.raises(ValueError):
+            r.updateGeometry(vtx_pos=state["vtx_pos"][:6], vtx_nml=state["vtx_nml"][:3])
+    finally:
+        r.close()
+
+
 def test_tick_loop_soak(room):
     """600 ticks + frames back to back with two to four frames in flight (an SVGF frame now and then): no hang, no growth of
     device memory once the scene sets and the staging arena exist, a finite film."""

@@ -298,3 +298,42 @@ def test_svgf_frames_in_flight_equal_serial(sponza):
         for a, b in zip(got, want):
             assert a.tobytes() == b.tobytes(), n
         assert hist.tobytes() == want_hist.tobytes(), n
+
+
+def test_film_order_survives_svgf_frames_between_renders(sponza):
+    """Advisor finding of round 2: an SVGF frame between two render() calls rotates the banks without writing the film, so
+    "the previous bank's last event" was not the film's last writer and two k_gather passes (running mean, read-modify-write)
+    could overlap or swap.  The film's writers are now ordered by their own event.  Deep frames followed by depth-1 frames
+    (which reach their gather first), SVGF frames never downloaded in between, 3 and 4 frames in flight == serial."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene.camera import create_camera
+    fs, cam = sponza
+    w, h = 320, 180
+
+    def run(in_flight):
+        r = PathTracing(0)
+        try:
+            r.UpdateSceneData(fs)
+            r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+            r.initSampler(w, h, 0)
+            r.set_frames_in_flight(in_flight)
+            films = []
+            f = 0
+            for rep in range(6):
+                r.render(w, h, 8, 3, frame=f, download=False); f += 1
+                r.svgf_render(w, h, 4, 3, frame=rep, compute_motion=True, download=False)
+                r.render(w, h, 1, 3, frame=f, download=False); f += 1
+                r.render(w, h, 1, 3, frame=f, download=False); f += 1
+                if rep == 2:
+                    r.reset()               # the clear is a film writer too (ordered before the next frame's gather)
+                    f = 0
+                if rep in (1, 5):
+                    films.append(r.download_film().copy())
+            return films
+        finally:
+            r.close()
+    want = run(1)
+    assert (want[1][..., 3] == 9).all()
+    for n in (3, 4):
+        for a, b in zip(run(n), want):
+            assert a.tobytes() == b.tobytes(), n

@@ -43,6 +43,20 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def kernel_sources_sha16():
+    """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over every file under aten_amd/csrc and include/,
+    in path order.  Recorded in profiles/*counters*.json when the PMC passes are collected (tools/pmc_to_json.py) and
+    recomputed by bench.py, which refuses counters taken on other kernels (no .git on the GPU box: a content hash, not a
+    commit id)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(_walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",)))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_host(force=False):
     srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp"), os.path.join(CSRC, "host", "camera.cpp")]
     deps = srcs + _walk(os.path.join(ROOT, "include"), (".h",))

@@ -40,7 +40,7 @@ struct DevBuf {
         if (count <= n && p) return hipSuccess;
         release();
         if (count == 0) return hipSuccess;
-        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T) + 256);     // slack: the walk's pair fetch reads 32 B past a record
         if (e == hipSuccess) n = count;
         return e;
     }

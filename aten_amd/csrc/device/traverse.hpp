@@ -19,6 +19,10 @@
 
 namespace atn {
 
+#ifndef ATN_LEAF_STASH
+#define ATN_LEAF_STASH 0        /* measured negative: VMEM instructions -18 %, VALU +48 %, time +7 % */
+#endif
+
 struct Hit {
     float t;
     int32_t objid;      // instance object id (TLAS leaf), -1 = miss
@@ -135,6 +139,12 @@ struct Walk {
     float t_max, stop_t;
     uint32_t payload;
     int32_t node, objid, meshid, top_hit, top_miss;
+#if ATN_LEAF_STASH
+    // first two quarters of the leaf / TLAS-leaf record the lane stands on, fetched by the burst's load instructions
+    // (see inner_burst); `stash` = the typed link they belong to
+    float4 sq0, sq1;
+    int32_t stash;
+#endif
 };
 
 ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t)
@@ -146,16 +156,87 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
     slab_setup(w.wray, mk3(a), mk3(b));
     w.ray = w.wray;
     w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+    // (w.stash is left alone: a stale stash still holds the bytes of the record its link names)
 }
 
 #ifndef ATN_TREELET_LDS
 #define ATN_TREELET_LDS 1       /* 0: keep the treelet REGION (hot records contiguous at the head of the image) but read it from global memory */
 #endif
+#ifndef ATN_PAIR_FETCH
+#define ATN_PAIR_FETCH 0        /* 1: a burst step fetches 64 B (the record and the one behind it) and may take two steps */
+#endif
 #ifndef ATN_INNER_BURST
-#define ATN_INNER_BURST 4
+#define ATN_INNER_BURST 5
 #endif
 constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
 
+
+#ifndef ATN_BURST_HOIST
+#define ATN_BURST_HOIST 1
+#endif
+
+// both 16-byte halves of a record through ONE address computation (the second load takes an immediate offset)
+ATN_DEV void ld32(const char* base, uint32_t byte_off, float4& a, float4& b)
+{
+    const float4* p = reinterpret_cast<const float4*>(base + byte_off);
+    a = p[0]; b = p[1];
+}
+
+// A burst of inner-node steps with ONE form of the slab test (FAST: hardware min/max, valid when every live lane's slab
+// constants are finite; else the select form, valid for all inputs).  See walk_iteration.
+template <bool COUNT, bool TREELET, int BURST, bool FAST>
+ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treelet, uint32_t treelet_bytes, float t_min, TravCounters* cnt)
+{
+#pragma unroll 1
+    for (int k = 0; k < BURST; k++) {
+#if ATN_LEAF_STASH
+        // What the per-CU L1 (TCP) charges for a 16-byte wave load is 16 cycles + ~0.5 per distinct 64-byte chunk beyond
+        // one per quad of lanes -- WHATEVER the exec mask (profiles/r03_calibration.json: 16 active lanes cost 16.8
+        // cycles, 64 cost 39).  The trace kernels are bound by exactly that unit, so a load instruction should carry as
+        // many lanes as it can: the lanes that reached a triangle leaf or a TLAS leaf ride along with the next burst
+        // step's two loads (their record's first two quarters are what they need), park the data, and the leaf step
+        // below issues ONE load (the third quarter) instead of three for a handful of lanes.
+        if (w.node != kLinkEnd && w.node != w.stash) {
+            const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
+            float4 q0, q1;
+            ld32(nb, off, q0, q1);
+            if (!(w.node & kLinkTypeMask)) {
+                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+                w.node = __float_as_int(box ? q0.w : q1.w);
+            }
+            else {
+                w.sq0 = q0; w.sq1 = q1; w.stash = w.node;
+            }
+        }
+#else
+        if (!(w.node & kLinkTypeMask)) {
+            const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
+            float4 q0, q1;
+            if (TREELET) {
+                const bool in_lds = off < treelet_bytes;
+                float4 g0, g1;      // deliberately not initialised: only the lanes that load them select them
+                if (!in_lds) ld32(nb, off, g0, g1);
+                const uint32_t loff = in_lds ? off : 0u;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f l0 = *reinterpret_cast<const v4f*>(treelet + loff);
+                v4f l1 = *reinterpret_cast<const v4f*>(treelet + loff + 16u);
+                asm volatile("" : "+v"(l0), "+v"(l1));
+                q0 = make_float4(in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w);
+                q1 = make_float4(in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w);
+            }
+            else {
+                ld32(nb, off, q0, q1);
+            }
+            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+            const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                  : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+            w.node = __float_as_int(box ? q0.w : q1.w);
+        }
+#endif
+    }
+}
 
 // One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
 // 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
@@ -177,6 +258,12 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
     // link is its miss link): a list that ends here ended on a MISS.
     const bool live = w.node != kLinkEnd;
+    // the slab form is wave-uniform: chosen ONCE per burst, outside the step loop (inside it the choice costs ~8 scalar
+    // instructions and two branches on every step)
+#if ATN_BURST_HOIST
+    if (all_finite) inner_burst<COUNT, TREELET, BURST, true>(w, nb, treelet, treelet_bytes, t_min, cnt);
+    else inner_burst<COUNT, TREELET, BURST, false>(w, nb, treelet, treelet_bytes, t_min, cnt);
+#else
 #pragma unroll 1
     for (int k = 0; k < BURST; k++) {
         if (!(w.node & kLinkTypeMask)) {
@@ -203,22 +290,49 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
                 q0 = ld16(nb, off);
                 q1 = ld16(nb, off + 16u);
             }
+#if ATN_PAIR_FETCH
+            // the record that FOLLOWS this one in the image: in walk (pre-)order that is the hit-link target of an inner
+            // node more often than not, so one memory round trip can serve two tree levels (same decisions, same order)
+            const float4 s0 = ld16(nb, off + 32u);
+            const float4 s1 = ld16(nb, off + 48u);
+#endif
             if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             bool box;
             if (all_finite) box = slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
             else box = slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
             w.node = __float_as_int(box ? q0.w : q1.w);
+#if ATN_PAIR_FETCH
+            if (w.node == (int32_t)(off + 32u)) {       // an inner record (type bits 0) right behind this one: already here
+                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+                bool box2;
+                if (all_finite) box2 = slab_hit_fast(w.ray, mk3(s0), mk3(s1), t_min, w.t_max);
+                else box2 = slab_hit_exact(w.ray, mk3(s0), mk3(s1), t_min, w.t_max);
+                w.node = __float_as_int(box2 ? s0.w : s1.w);
+            }
+#endif
         }
     }
+#endif
     bool ended = live && w.node == kLinkEnd;    // this lane's walk left a list in this iteration ...
     bool is_hit = false;                        // ... and this was the result of its last step
 
     // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
+#if ATN_LEAF_STASH && ATN_BURST_HOIST
+    // only the lanes whose record head was fetched by the burst (a lane that stepped onto a leaf in the burst's last step
+    // gets it in the next burst's first step and is served by the next leaf step)
+    const bool staged = w.node != kLinkEnd && (w.node & kLinkTypeMask) && w.node == w.stash;
+    const bool at_tlas = staged && (w.node & kLinkTypeMask) == kLinkTlasBit;
+    if (staged) {
+        const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
+        const float4 q0 = w.sq0;
+        const float4 q1 = w.sq1;
+#else
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
     if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ld16(nb, off);
         const float4 q1 = ld16(nb, off + 16u);
+#endif
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         if (w.node & kLinkLeafBit) {
             const float4 q2 = ld16(nb, off + 32u);
@@ -445,6 +559,9 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
     w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
     w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
     w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+#if ATN_LEAF_STASH
+    w.stash = kLinkEnd; w.sq0 = make_float4(0, 0, 0, 0); w.sq1 = w.sq0;
+#endif
 
     for (;;) {
         // ---- refill

@@ -12,6 +12,7 @@ declare -A SETS
 SETS[1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 SETS[2]="SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 SETS[3]="TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+SETS[4]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum"
 SETS[5]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 SETS[6]="FETCH_SIZE"
 SETS[7]="WRITE_SIZE"

@@ -13,6 +13,11 @@ Formulas (MI355X: 256 CUs, 1024 SIMDs, 8 XCDs; MI355X_MICROARCH.md for the peaks
   l2_hit_rate       = TCC_HIT / (TCC_HIT + TCC_MISS)
   l1_hit_rate       = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_ACCESSES
   l1_stall          = TCP_PENDING_STALL_CYCLES / 256 / cycles   (share of the launch a CU's L1 sits on pending misses)
+  tcp_lane_accesses_per_cu_cycle  = TCP_TOTAL_ACCESSES / 256 / cycles        (one per lane and load; ceiling = 64 B/clk data path)
+  tcp_cache_accesses_per_cu_cycle = TCP_TOTAL_CACHE_ACCESSES / 256 / cycles  (one per distinct 64-B chunk a quad of lanes touches: tag rate)
+  tcp_active        = TCP_GATE_EN2 / 256 / cycles
+The ceilings of the last three are MEASURED: profiles/r03_calibration.json (tools/valu_calib.hip).
+`kernel_sources_sha16` = aten_amd.build.kernel_sources_sha16() of the tree the passes ran on; bench.py refuses a mismatch.
 """
 import csv
 import glob
@@ -20,6 +25,8 @@ import json
 import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(n):
@@ -32,7 +39,8 @@ def main(d, workload):
     for f in sorted(glob.glob(os.path.join(d, "pass*", "*counter_collection.csv"))):
         for row in csv.DictReader(open(f)):
             acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    out = {"workload": workload, "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_collect.sh); per-launch averages over all dispatches of a kernel",
+    from aten_amd.build import kernel_sources_sha16
+    out = {"workload": workload, "kernel_sources_sha16": kernel_sources_sha16(), "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_collect.sh); per-launch averages over all dispatches of a kernel",
            "kernels": {}}
     for k in sorted(acc):
         if k.startswith("__amd") or not k.startswith("k_"):
@@ -45,6 +53,14 @@ def main(d, workload):
             e["cycles"] = round(cyc)
             if g("SQ_ACTIVE_INST_VALU") is not None:
                 e["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") / 256.0 / cyc, 4)
+            if g("SQ_INSTS_VALU") is not None:
+                e["valu_insts_per_simd_cycle"] = round(g("SQ_INSTS_VALU") / 1024.0 / cyc, 4)
+            if g("TCP_TOTAL_ACCESSES_sum") is not None:
+                e["tcp_lane_accesses_per_cu_cycle"] = round(g("TCP_TOTAL_ACCESSES_sum") / 256.0 / cyc, 4)
+            if g("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
+                e["tcp_cache_accesses_per_cu_cycle"] = round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / 256.0 / cyc, 4)
+            if g("TCP_GATE_EN2_sum") is not None:
+                e["tcp_active"] = round(g("TCP_GATE_EN2_sum") / 256.0 / cyc, 4)
             if g("TCP_PENDING_STALL_CYCLES_sum") is not None:
                 e["l1_stall"] = round(g("TCP_PENDING_STALL_CYCLES_sum") / 256.0 / cyc, 4)
         if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):

@@ -9,7 +9,7 @@ TAG=$1; NAME=$2; WORKLOAD=$3; shift 3
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG/$NAME
 mkdir -p "$OUT" profiles
-bash tools/pmc_collect.sh "$OUT/pmc" "1 2 3 5 6 7" "$@" > "$OUT/pmc.log" 2>&1
+bash tools/pmc_collect.sh "$OUT/pmc" "1 2 3 4 5 6 7" "$@" > "$OUT/pmc.log" 2>&1
 python tools/pmc_to_json.py "$OUT/pmc" "$WORKLOAD" > "profiles/${TAG}_counters_${NAME}.json"
 cp "profiles/${TAG}_counters_${NAME}.json" "$OUT/"
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/${TAG}_${NAME}_pmc.txt"

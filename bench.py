@@ -46,21 +46,39 @@ def profile_counters(scene, w, h, spp, depth, svgf):
     (they need the profiler around the process), so the fractions below combine those counters with the launch
     durations measured live here.  None when no committed profile matches the workload."""
     import glob
+    from aten_amd.build import kernel_sources_sha16
     tag = "%s %dx%d %dspp %d-bounce%s" % (scene, w, h, spp, depth, " svgf" if svgf else "")
-    best = None
+    sha = kernel_sources_sha16()
+    best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*counters*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload", "") == tag:
+        if d.get("workload", "") != tag:
+            continue
+        # counters are only valid for the kernels they were taken on: the record carries the hash of aten_amd/csrc +
+        # include/ at collection time; a file from other sources is REFUSED (named in the output, not used)
+        if d.get("kernel_sources_sha16") == sha:
             best = (os.path.relpath(f, ROOT), d)
-    return best
+        else:
+            stale = os.path.relpath(f, ROOT)
+    return best, stale, sha
+
+
+def load_calibration():
+    """Measured ceilings of the counters the roofline is built from (tools/valu_calib.hip -> profiles/*calibration.json)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*calibration.json")))
+    if not fs:
+        return None, None
+    return os.path.relpath(fs[-1], ROOT), json.load(open(fs[-1]))
 
 
 def kernel_entry(counters, prefix):
-    if not counters:
+    if not counters or not counters[0]:
         return None
+    counters = counters[0]
     # several instantiations may share the prefix (e.g. the first launch of a sample runs k_trace_fused<false, .>, the
     # other five k_trace_fused<true, .>): the one with the most launches is the kernel the roofline is about
     best = None
@@ -145,6 +163,389 @@ def main_mgpu(args):
     m.close()
 
 
+
+def run_workload(args, cfg, ctx):
+    """One benchmark workload end to end: W warm-up frames, the timed K frames, the same frames with HIP events, the same
+    frames with ONE frame in flight (latency), a counting pass, an isolated-kernel pass, the CPU baseline.  Returns the
+    result dict on rank 0 (None elsewhere).  cfg: scene, width, height, spp, depth, svgf, all_samples, frames_in_flight,
+    experiment, cpu_baseline; ctx: torch, dist, rank, local_rank, world, use_dist."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    rank, local_rank, world, use_dist = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["use_dist"]
+    from aten_amd.interop import tensor_from_ptr
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.camera import create_camera
+
+    scene = cfg["scene"]
+    W, H, spp, depth, rr = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"], 3
+    svgf, steps, warmup = cfg["svgf"], args.steps, args.warmup
+    in_flight = cfg["frames_in_flight"]
+    if scene == "sponza":
+        ex = set(x for x in cfg.get("experiment", "").split(",") if x)
+        fs, cam = scenedefs.sponza_lod(textures="notex" not in ex, ibl="noibl" not in ex)
+        workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh (stand-in for missing sponza.obj)" % (W, H, spp, depth)
+        if ex:
+            workload += " EXPERIMENT " + "+".join(sorted(ex))
+    elif scene == "atrium":
+        fs, cam = scenedefs.atrium()
+        workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; synthetic Sponza-class scale-up, stand-in "
+                    "for the missing Crytek Sponza blob) %dx%d %dspp %d-bounce%s" % (len(fs.arrays["triangles"]), W, H, spp, depth,
+                                                                                 " all samples traced" if cfg["all_samples"] else ""))
+    else:
+        fs, cam = scenedefs.cornell_box()
+        workload = "cornell box %dx%d %dspp %d-bounce NEE" % (W, H, spp, depth)
+    brk = not cfg["all_samples"]
+    camera = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+
+    dev = "cuda:%d" % local_rank
+    r = PathTracing(local_rank)
+    r.UpdateSceneData(fs)
+    r.updateCamera(camera)
+    r.initSampler(W, H, 0)
+    r.setScreenShard(rank, world)
+    if svgf:
+        in_flight = min(in_flight, 2)   # SVGF hands a frame over through two slots: 2 in flight is its depth
+    r.set_frames_in_flight(in_flight)
+
+    # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
+    # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
+    # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
+    ext_streams = {}        # the renderer's stream of the frame just enqueued (one per bank of frames in flight)
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
+    full = [None]
+
+    def step(frame, profile):
+        if svgf:
+            r.svgf_render(W, H, depth, rr, spp=spp, frame=frame, compute_motion=True, download=False, profile=profile)
+            return
+        r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
+                 profile=profile)
+        if use_dist:
+            n = r.tile_slots()
+            k = frame & 1
+            if stage[k] is None:
+                stage[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+                gathered[k] = torch.empty((world * n, 4), dtype=torch.float32, device=dev)
+                ev_ready[k] = torch.cuda.Event()
+                ev_free[k] = torch.cuda.Event()
+                ev_free[k].record(comm_stream)
+            if full[0] is None:
+                full[0] = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            sp = r.stream_ptr()
+            if sp not in ext_streams:
+                ext_streams[sp] = torch.cuda.ExternalStream(sp, device=dev)
+            ext_stream = ext_streams[sp]
+            with torch.cuda.stream(ext_stream):
+                ext_stream.wait_event(ev_free[k])           # the exchange of frame f - 2 has read stage[k]
+                stage[k].copy_(tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev))
+                ev_ready[k].record(ext_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev_ready[k])
+                dist.all_gather_into_tensor(gathered[k], stage[k])
+                r.assemble_tiles(gathered[k].data_ptr(), world, full[0].data_ptr(), comm_stream.cuda_stream)
+                ev_free[k].record(comm_stream)
+
+    def sync_all():
+        r.synchronize()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(n):
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i, False)      # the timed region carries no instrumentation: no event records, no counters
+        sync_all()
+        e = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
+
+    for i in range(warmup):
+        step(i, False)
+    r.reset()
+    elapsed = timed(steps)
+    final_img = None
+    if cfg.get("dump") and rank == 0:
+        final_img = full[0].cpu().numpy() if use_dist else r.download_film()
+
+    # the same K frames with ONE frame in flight: what a caller that waits for every frame sees (frame LATENCY); `value`
+    # above is THROUGHPUT with `in_flight` frames overlapping (progressive accumulation never waits for a frame)
+    latency_ms = None
+    if in_flight > 1:
+        r.set_frames_in_flight(1)
+        r.reset()
+        for i in range(min(warmup, 2)):
+            step(i, False)
+        r.reset()
+        latency_ms = 1e3 * timed(steps) / steps
+        r.set_frames_in_flight(in_flight)
+
+    # the same K frames once more with every launch bracketed by HIP events on the stream it runs on: per-kernel
+    # durations of the timed workload, measured live (the events cost ~2 % of a frame, which is why `value` is not
+    # taken from this region)
+    r.reset()
+    r.reset_kernel_times()
+    sync_all()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        step(i, True)
+    sync_all()
+    elapsed_events = time.perf_counter() - t1
+    ktimes = r.kernel_times()
+
+    ms_per_step = 1e3 * elapsed / steps
+    mrays = W * H * spp / 1e6 / (elapsed / steps)
+
+    # work counters of the same frames (untimed pass) for the roofline model
+    r.reset()
+    tot = dict(closest_rays=0, shadow_rays=0, hits=0, closest_nodes=0, closest_tris=0, shadow_nodes=0, shadow_tris=0)
+    n_count = min(steps, 4)
+    for i in range(n_count):
+        r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False,
+                 count_stats=True)
+        st = r.stats()
+        for k in tot:
+            tot[k] += st[k]
+    per_frame = {k: v / n_count for k, v in tot.items()}
+
+    # the same frames once more with one kernel in flight at a time: per-kernel durations of isolated kernels
+    # (in the timed region up to three batches of the frame overlap on separate streams, so a launch shares the GPU)
+    r.set_path_batches(1)
+    r.set_frames_in_flight(1)
+    r.reset()
+    r.reset_kernel_times()
+    n_excl = min(steps, 10)
+    for i in range(n_excl):
+        if svgf:
+            r.svgf_render(W, H, depth, rr, spp=spp, frame=i, compute_motion=True, download=False, profile=True)
+        else:
+            r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False, profile=True)
+    r.synchronize()
+    ktimes_excl = r.kernel_times()
+    r.set_path_batches(3)
+    r.set_frames_in_flight(in_flight)      # (SVGF: the path pass of frame f + 1 overlaps the filters of frame f)
+
+    frames_prof = steps
+    kernel_count_batches = max(1, round(ktimes["gen_path"][1] / max(frames_prof * spp, 1)))
+    if ktimes["trace_fused"][1]:
+        # the frame's trace work runs as depth + 1 launches of k_trace_fused (shadow rays of bounce b + closest-hit
+        # rays of bounce b + 1): that kernel is the dominant one
+        dominant, tkey = "k_trace_fused", "trace_fused"
+        nodes = per_frame["closest_nodes"] + per_frame["shadow_nodes"]
+        tris = per_frame["closest_tris"] + per_frame["shadow_tris"]
+        rays = per_frame["closest_rays"] + per_frame["shadow_rays"]
+    else:
+        dominant, tkey = "k_trace_closest", "trace_closest"
+        nodes, tris, rays = per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"]
+    bytes_per_frame = algorithmic_bytes(nodes, tris, rays)
+    own_bytes_per_frame = 32 * (nodes - tris) + 48 * tris + 56 * rays       # this layout: 32-B inner records, 48-B leaf records
+    tc_ms, tc_n = ktimes[tkey]
+    launches_per_frame = max(tc_n / max(frames_prof, 1), 1)
+    avg_launch_ms = tc_ms / max(tc_n, 1)
+    # With frames in flight (or several batches per frame) a launch shares the GPU with other launches, so its wall
+    # duration says nothing about how hard IT drives the machine; the roofline fractions use the duration of the same
+    # launch with one kernel in flight at a time (the isolated pass above -- also the mode the PMC passes run in, the
+    # profiler serialises dispatches), the overlapped duration is reported next to it.
+    overlapped = kernel_count_batches > 1 or in_flight > 1
+    iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
+    roof_ms = iso_ms if overlapped else avg_launch_ms
+    avg_launch_s = max(roof_ms * 1e-3, 1e-12)
+    scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[scene]
+    prof, stale, sha = (profile_counters(scene_tag, W, H, spp, depth, svgf) if world == 1 else (None, None, None))
+    pk = kernel_entry((prof,), dominant) if prof else None
+    cal_file, cal = load_calibration()
+    ceil = cal["ceilings"] if cal else {}
+    # Candidate roofs for the dominant kernel, each a fraction <= 1 of a limit: HBM and L2 against the guide's peaks; the
+    # per-CU L1 (TCP) and VALU issue against ceilings MEASURED on this chip with tools/valu_calib.hip (rocprofiler's derived
+    # VALUBusy falls back to a gfx94x formula and reads up to 1.4 here: SQ_ACTIVE_INST_VALU is just 4 per instruction).
+    # Counters: committed PMC passes of this workload (per launch) -- only if taken on THESE kernel sources; duration:
+    # HIP events above.  `bound` names the largest fraction.
+    fractions, extra = {}, {}
+    if pk:
+        scale = 1.0
+        if pk.get("cycles") and roof_ms > 0:
+            scale = (pk["cycles"] / 2.4e6) / roof_ms        # rates are per cycle of the PROFILED run: rescale by the duration ratio
+        if "hbm_bytes" in pk:
+            fractions["hbm"] = pk["hbm_bytes"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        if "l2_bytes_max" in pk:
+            fractions["l2"] = pk["l2_bytes_max"] / avg_launch_s / 1e9 / L2_PEAK_GBS
+        if pk.get("tcp_lane_accesses_per_cu_cycle") is not None and ceil.get("tcp_accesses_per_cu_cycle_rows"):
+            # a 16-byte wave load occupies 64 lane slots of the TCP whatever its exec mask; the unit moves 4 slots (64 B) per clock
+            slots = pk["tcp_lane_accesses_per_cu_cycle"] * scale / ceil["tcp_accesses_per_cu_cycle_rows"]
+            tags = (pk.get("tcp_cache_accesses_per_cu_cycle") or 0.0) * scale / (ceil.get("tcp_cache_accesses_per_cu_cycle_random") or 1e30)
+            fractions["l1"] = max(slots, tags)
+            extra["l1_lane_slots"] = round(slots, 4); extra["l1_tag_lookups"] = round(tags, 4)
+            extra["tcp_active"] = pk.get("tcp_active")
+        if pk.get("valu_insts_per_simd_cycle") is not None and ceil.get("valu_insts_per_simd_cycle_fma"):
+            fractions["valu"] = pk["valu_insts_per_simd_cycle"] * scale / ceil["valu_insts_per_simd_cycle_fma"]
+            if ceil.get("valu_insts_per_simd_cycle_walkmix"):
+                extra["valu_vs_packed_mix_ceiling"] = round(pk["valu_insts_per_simd_cycle"] * scale / ceil["valu_insts_per_simd_cycle_walkmix"], 4)
+    bound = max(fractions, key=fractions.get) if fractions else "hbm"
+    units = {"hbm": ("GB/s", HBM_PEAK_GBS), "l2": ("GB/s", L2_PEAK_GBS),
+             "l1": ("TCP lane slots per CU per clock (16 B each)", ceil.get("tcp_accesses_per_cu_cycle_rows", 4.0)),
+             "valu": ("VALU wave-instructions per SIMD per clock", ceil.get("valu_insts_per_simd_cycle_fma", 0.5))}
+    frac = fractions.get(bound)
+    roofline = {
+        "kernel": dominant, "bound": bound,
+        "achieved": round(frac * units[bound][1], 4) if frac is not None else None, "peak": units[bound][1], "unit": units[bound][0],
+        "frac": round(frac, 4) if frac is not None else None,
+        "traffic": pk.get("hbm_bytes") if pk else None,
+        "fractions": {k: round(v, 4) for k, v in fractions.items()},
+        "fraction_detail": extra,
+        "calibration": ({"file": cal_file, "git_head": cal.get("git_head"),
+                         "ceilings_used": {k: ceil.get(k) for k in ("valu_insts_per_simd_cycle_fma", "valu_insts_per_simd_cycle_walkmix",
+                                                                    "tcp_accesses_per_cu_cycle_rows", "tcp_cache_accesses_per_cu_cycle_random")}} if cal else None),
+        "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
+        "roofline_launch_ms": round(roof_ms, 5),
+        "algorithmic": {"bytes_per_launch": round(bytes_per_frame / launches_per_frame),
+                        "GBps": round(bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
+                        "bytes_per_launch_this_layout": round(own_bytes_per_frame / launches_per_frame),
+                        "GBps_this_layout": round(own_bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
+                        "note": "SURVEY 8(d): 48 B per node visit + 80 B per triangle test + 56 B per ray (reference layout); "
+                                "this layout reads 32 B per inner visit and 48 B per leaf visit.  A rate, not a fraction of a roof: "
+                                "the records are served by L1/L2"},
+        "pmc": ({"file": prof[0], "kernel_sources_sha16": sha, "lane_utilisation": pk.get("lane_utilisation"), "l1_hit_rate": pk.get("l1_hit_rate"),
+                 "l2_hit_rate": pk.get("l2_hit_rate"), "l1_stall": pk.get("l1_stall"),
+                 "valu_insts_per_simd_cycle": pk.get("valu_insts_per_simd_cycle"),
+                 "valu_useful": round(fractions["valu"] * pk["lane_utilisation"], 4) if pk.get("lane_utilisation") and "valu" in fractions else None,
+                 "avg_launch_ms_profiled": round(pk["cycles"] / 2.4e6, 5) if pk.get("cycles") else None} if pk else
+                {"file": None, "kernel_sources_sha16": sha, "refused_stale_file": stale,
+                 "note": "no PMC record taken on these kernel sources (run tools/profile_round.sh): counter-derived fractions omitted"}),
+        "note": "fractions: hbm = (FETCH_SIZE*2 + WRITE_SIZE) / t / 8 TB/s; l2 = TCC_REQ*128 B / t / 34.5 TB/s (upper bound); "
+                "l1 = max(TCP_TOTAL_ACCESSES, i.e. 64 lane slots per 16-B wave load, / measured 3.95 slots per CU-clock; "
+                "TCP_TOTAL_CACHE_ACCESSES / measured 1.62 tag lookups per CU-clock); valu = SQ_INSTS_VALU per SIMD-clock / measured "
+                "0.35 (v_fma_f32, 8 waves per SIMD); DESIGN.md section 6",
+    }
+    # k_shade: the one kernel with material HBM traffic.  Compulsory bytes = the path state it must read and write once
+    # per queue entry (80 B in: queue entry, ray, hit, throughput, seed; 16 B throughput out; per hit the next ray 32 B,
+    # the shadow ray 48 B and two queue entries 8 B; per miss the contribution read-modify-write 32 B).
+    sh_ms, sh_n = ktimes["shade"]
+    sk = kernel_entry((prof,), "k_shade") if prof else None
+    shade = None
+    if sh_n:
+        if overlapped and ktimes_excl["shade"][1]:
+            sh_ms, sh_n = ktimes_excl["shade"][0] * (frames_prof / max(n_excl, 1)), ktimes_excl["shade"][1] * (frames_prof / max(n_excl, 1))
+        sh_launch_s = sh_ms * 1e-3 / sh_n
+        entries, hits = per_frame["closest_rays"], per_frame["hits"]
+        comp = (96 * entries + 88 * hits + 32 * (entries - hits)) / max(sh_n / max(frames_prof, 1), 1)
+        shade = {"kernel": "k_shade", "bound": "hbm", "avg_launch_ms": round(sh_launch_s * 1e3, 5), "launches": sh_n,
+                 "compulsory_bytes_per_launch": round(comp),
+                 "compulsory_GBps": round(comp / sh_launch_s / 1e9, 1),
+                 "traffic": sk.get("hbm_bytes") if sk else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "achieved": round(sk["hbm_bytes"] / sh_launch_s / 1e9, 1) if sk and "hbm_bytes" in sk else None,
+                 "frac": round(sk["hbm_bytes"] / sh_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sk and "hbm_bytes" in sk else None,
+                 "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None}
+    roofline["shade"] = shade
+    if overlapped:
+        roofline["note"] += ("; %d frames in flight x %d batches per frame run on separate streams: avg_launch_ms (what rocprofv3 --kernel-trace "
+                             "of this command shows) is the wall duration of a launch that shares the GPU, roofline_launch_ms the same launch "
+                             "with one kernel in flight at a time, which the fractions use" % (in_flight, kernel_count_batches))
+    kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
+    kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
+    svgf_info = None
+    if svgf:
+        # compulsory HBM bytes per pixel and launch (every input plane read once, every output written once; the
+        # filter taps themselves are L2 hits): a-trous reads normal+depth, albedo+id, colour+variance and writes one
+        # plane (+ the temporary colour on the first and the output on the last iteration).  The launch duration is the
+        # ISOLATED one (one kernel in flight): in the timed region the filters of frame f overlap the path pass of f + 1.
+        px = W * H
+        at_ms, at_n = ktimes_excl["svgf_atrous"]
+        at_bytes = px * (48 + 16) + px * 32 / max(at_n / max(n_excl, 1), 1)
+        at_launch_ms = at_ms / max(at_n, 1)
+        ak = kernel_entry((prof,), "k_svgf_atrous") if prof else None
+        svgf_info = {"passes_ms_per_frame": {k: kernel_ms_per_frame[k] for k in kernel_ms_per_frame if k.startswith("svgf")},
+                     "passes_ms_per_frame_isolated": {k: v for k, v in kernel_ms_per_frame_isolated.items() if k.startswith("svgf")},
+                     "atrous": {"bound": "hbm", "compulsory_bytes_per_launch": int(at_bytes), "avg_launch_ms_isolated": round(at_launch_ms, 5),
+                                "achieved": round(at_bytes / (at_launch_ms * 1e-3) / 1e9, 1) if at_n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(at_bytes / (at_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if at_n else None,
+                                "traffic": ak.get("hbm_bytes") if ak else None},
+                     "filter_ms_per_frame": round(sum(v for k, v in kernel_ms_per_frame.items() if k.startswith("svgf")), 4),
+                     "filter_ms_per_frame_isolated": round(sum(v for k, v in kernel_ms_per_frame_isolated.items() if k.startswith("svgf")), 4)}
+    ray_segments = per_frame["closest_rays"] + per_frame["shadow_rays"]
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and cfg["cpu_baseline"]:
+        from oracle import orc     # the cpu_baseline leg is the only place bench.py touches oracle/
+        # bounded sample of the same workload: the benchmarked frame itself (same scene / camera / seeds / size) when a
+        # CPU frame takes seconds (1080p 1 spp: ~1.2 s with 16 threads); 1/6 linear resolution for the 4K 8-spp config,
+        # whose full frame would take minutes
+        cw, ch = W, H
+        if W * H * spp > 4 * 1920 * 1080:
+            cw, ch = max(W // 6, 8), max(H // 6, 8)
+        ccam = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], cw, ch)
+        cseeds = orc.init_sampler(cw, ch, 0)
+
+        cpu_svgf = orc.Svgf() if svgf else None
+
+        def cpu_frame(f, nthreads=0):
+            if cpu_svgf is not None:
+                cpu_svgf.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, compute_motion=True, nthreads=nthreads)
+            elif brk or spp == 1:
+                orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, nthreads=nthreads)
+            else:       # every sample traced: spp passes of one sample (same work as the GPU's all-samples mode)
+                for i in range(spp):
+                    orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=1, frame=f * spp + i, nthreads=nthreads)
+
+        def cpu_median(nthreads, min_frames, budget_s):
+            cpu_frame(0, nthreads)      # warm-up
+            ts = []
+            t_all = time.perf_counter()
+            while (len(ts) < min_frames or time.perf_counter() - t_all < budget_s / 3) and time.perf_counter() - t_all < budget_s:
+                t1 = time.perf_counter()
+                cpu_frame(len(ts), nthreads)
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts)), len(ts)
+
+        n_cpu = usable_cpus()
+        budget = cfg.get("cpu_budget_s", 16.0)
+        med, nfr = cpu_median(n_cpu, 5 if budget >= 16 else 3, budget)
+        cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": n_cpu, "logical_cpus": orc.lib().orc_num_procs(),
+                        "kind": "port", "sample": ("the benchmarked frame itself: " if (cw, ch) == (W, H) else "reduced frame: ") + "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
+                        "ms_per_frame_sample": round(1e3 * med, 2)}
+        if cfg.get("cpu_8_threads", True):
+            med8, nfr8 = cpu_median(8, 2, 8.0)      # the reference app's own setting (host_renderer/main.cpp:18-23,271)
+            cpu_baseline["value_8_threads"] = round(cw * ch * spp / 1e6 / med8, 4)
+            cpu_baseline["frames_8_threads"] = nfr8
+
+    if final_img is not None:
+        np.save(cfg["dump"], final_img)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5) and not svgf)
+            else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_frame_latency": round(latency_ms, 4) if latency_ms is not None else round(ms_per_step, 4),
+            "throughput_note": ("value / ms_per_step are THROUGHPUT with %d frames in flight (progressive accumulation enqueues frames back to back; "
+                                "one frame's launch tails overlap the next frame's bulk); ms_per_frame_latency is the same K frames with one frame "
+                                "in flight, i.e. what a caller that waits for each frame sees" % in_flight) if in_flight > 1 else "one frame in flight: throughput = latency",
+            "ms_per_step_with_events": round(1e3 * elapsed_events / steps, 4),
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
+                       "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
+                       "frames_in_flight": in_flight,
+                       "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"]))},
+            "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / steps), 2),
+            "work_per_frame": {k: round(v) for k, v in per_frame.items()},
+            "kernel_ms_per_frame": kernel_ms_per_frame,
+            "kernel_ms_per_frame_isolated": kernel_ms_per_frame_isolated,
+            "roofline": roofline,
+            "svgf": svgf_info,
+            "cpu_baseline": cpu_baseline,
+        }
+    r.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +565,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="the default run (Sponza stand-in, 1 GPU) also times the 250 K-triangle procedural atrium at the same 1080p 1 spp "
+                         "5-bounce protocol and reports it under `companion` (SURVEY 8(d): the stand-in AND a synthetic scale-up); this skips it")
     ap.add_argument("--experiment", default="", help="traffic experiments on the sponza scene, not a benchmark configuration: "
                     "'notex' (no textures), 'noibl' (white background instead of the environment map), 'notex,noibl'")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
@@ -205,323 +609,28 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from aten_amd.interop import tensor_from_ptr
-    from aten_amd.renderer import PathTracing
-    from aten_amd.scene import scenedefs
-    from aten_amd.scene.camera import create_camera
 
-    W, H, spp, depth, rr = args.width, args.height, args.spp, args.depth, 3
-    if args.scene == "sponza":
-        ex = set(x for x in args.experiment.split(",") if x)
-        fs, cam = scenedefs.sponza_lod(textures="notex" not in ex, ibl="noibl" not in ex)
-        workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh (stand-in for missing sponza.obj)" % (W, H, spp, depth)
-        if ex:
-            workload += " EXPERIMENT " + "+".join(sorted(ex))
-    elif args.scene == "atrium":
-        fs, cam = scenedefs.atrium()
-        workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; stand-in for the missing "
-                    "Crytek Sponza blob) %dx%d %dspp %d-bounce%s" % (len(fs.arrays["triangles"]), W, H, spp, depth,
-                                                                 " all samples traced" if args.all_samples else ""))
-    else:
-        fs, cam = scenedefs.cornell_box()
-        workload = "cornell box %dx%d %dspp %d-bounce NEE" % (W, H, spp, depth)
-    brk = not args.all_samples
-    camera = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}
+    cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
+           "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
+           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump}
+    out = run_workload(args, cfg, ctx)
 
-    dev = "cuda:%d" % local_rank
-    r = PathTracing(local_rank)
-    r.UpdateSceneData(fs)
-    r.updateCamera(camera)
-    r.initSampler(W, H, 0)
-    r.setScreenShard(rank, world)
-    if args.svgf:
-        args.frames_in_flight = min(args.frames_in_flight, 2)   # SVGF hands a frame over through two slots: 2 in flight is its depth
-    r.set_frames_in_flight(args.frames_in_flight)
+    # "sponza_lod for oracle-checked runs AND a synthetic scale-up for perf -- say which one every time".  The
+    # headline stand-in is a 1.5 MB tree that lives in L1/L2; the atrium (250 K triangles, 17 MB of records) does not fit
+    # an XCD's L2 and has real L2 / HBM traffic.  Same protocol, own roofline and CPU baseline, under `companion`.
+    default_line = (args.scene == "sponza" and (args.width, args.height, args.spp, args.depth) == (1920, 1080, 1, 5) and not args.svgf
+                    and not args.experiment and world == 1 and not use_dist)
+    if default_line and not args.no_companion:
+        ccfg = dict(cfg, scene="atrium", dump=None, cpu_budget_s=9.0, cpu_8_threads=False)
+        comp = run_workload(args, ccfg, dict(ctx, use_dist=False))
+        if rank == 0 and comp is not None:
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_frame_latency", "config", "ray_segments_per_frame",
+                    "Mray_segments_per_s", "work_per_frame", "kernel_ms_per_frame_isolated", "roofline", "cpu_baseline")
+            out["companion"] = {k: comp[k] for k in keep}
+            out["companion"]["why"] = ("the headline stand-in (sponza_lod, 12 852 triangles) is cache-resident; this synthetic Sponza-class "
+                                       "scale-up is the workload whose tree does not fit an XCD's L2")
 
-    # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
-    # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
-    # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
-    ext_streams = {}        # the renderer's stream of the frame just enqueued (one per bank of frames in flight)
-    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
-    stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
-    full = None
-
-    def step(frame, profile):
-        nonlocal full
-        if args.svgf:
-            r.svgf_render(W, H, depth, rr, spp=spp, frame=frame, compute_motion=True, download=False, profile=profile)
-            return
-        r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
-                 profile=profile)
-        if use_dist:
-            n = r.tile_slots()
-            k = frame & 1
-            if stage[k] is None:
-                stage[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
-                gathered[k] = torch.empty((world * n, 4), dtype=torch.float32, device=dev)
-                ev_ready[k] = torch.cuda.Event()
-                ev_free[k] = torch.cuda.Event()
-                ev_free[k].record(comm_stream)
-            if full is None:
-                full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-            sp = r.stream_ptr()
-            if sp not in ext_streams:
-                ext_streams[sp] = torch.cuda.ExternalStream(sp, device=dev)
-            ext_stream = ext_streams[sp]
-            with torch.cuda.stream(ext_stream):
-                ext_stream.wait_event(ev_free[k])           # the exchange of frame f - 2 has read stage[k]
-                stage[k].copy_(tensor_from_ptr(r.tile_device_ptr(), (n, 4), dev))
-                ev_ready[k].record(ext_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev_ready[k])
-                dist.all_gather_into_tensor(gathered[k], stage[k])
-                r.assemble_tiles(gathered[k].data_ptr(), world, full.data_ptr(), comm_stream.cuda_stream)
-                ev_free[k].record(comm_stream)
-
-    def sync_all():
-        r.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i, False)
-    r.reset()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, False)      # the timed region carries no instrumentation: no event records, no counters
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_img = None
-    if args.dump and rank == 0:
-        final_img = full.cpu().numpy() if use_dist else r.download_film()
-
-    # the same K frames once more with every launch bracketed by HIP events on the stream it runs on: per-kernel
-    # durations of the timed workload, measured live (the events cost ~2 % of a frame, which is why `value` is not
-    # taken from this region)
-    r.reset()
-    r.reset_kernel_times()
-    sync_all()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
-    sync_all()
-    elapsed_events = time.perf_counter() - t1
-    ktimes = r.kernel_times()
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    mrays = W * H * spp / 1e6 / (elapsed / args.steps)
-
-    # work counters of the same frames (untimed pass) for the roofline model
-    r.reset()
-    tot = dict(closest_rays=0, shadow_rays=0, hits=0, closest_nodes=0, closest_tris=0, shadow_nodes=0, shadow_tris=0)
-    n_count = min(args.steps, 4)
-    for i in range(n_count):
-        r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False,
-                 count_stats=True)
-        s = r.stats()
-        for k in tot:
-            tot[k] += s[k]
-    per_frame = {k: v / n_count for k, v in tot.items()}
-
-    # the same frames once more with one kernel in flight at a time: per-kernel durations of isolated kernels
-    # (in the timed region up to three batches of the frame overlap on separate streams, so a launch shares the GPU)
-    r.set_path_batches(1)
-    r.set_frames_in_flight(1)
-    r.reset()
-    r.reset_kernel_times()
-    n_excl = min(args.steps, 10)
-    for i in range(n_excl):
-        if args.svgf:
-            r.svgf_render(W, H, depth, rr, spp=spp, frame=i, compute_motion=True, download=False, profile=True)
-        else:
-            r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False, profile=True)
-    r.synchronize()
-    ktimes_excl = r.kernel_times()
-    r.set_path_batches(3)
-    r.set_frames_in_flight(args.frames_in_flight)      # (SVGF: the path pass of frame f + 1 overlaps the filters of frame f)
-
-    frames_prof = args.steps
-    kernel_count_batches = max(1, round(ktimes["gen_path"][1] / max(frames_prof * spp, 1)))
-    if ktimes["trace_fused"][1]:
-        # the frame's trace work runs as depth + 1 launches of k_trace_fused (shadow rays of bounce b + closest-hit
-        # rays of bounce b + 1): that kernel is the dominant one
-        dominant, tkey = "k_trace_fused", "trace_fused"
-        nodes = per_frame["closest_nodes"] + per_frame["shadow_nodes"]
-        tris = per_frame["closest_tris"] + per_frame["shadow_tris"]
-        rays = per_frame["closest_rays"] + per_frame["shadow_rays"]
-    else:
-        dominant, tkey = "k_trace_closest", "trace_closest"
-        nodes, tris, rays = per_frame["closest_nodes"], per_frame["closest_tris"], per_frame["closest_rays"]
-    bytes_per_frame = algorithmic_bytes(nodes, tris, rays)
-    own_bytes_per_frame = 32 * (nodes - tris) + 48 * tris + 56 * rays       # this layout: 32-B inner records, 48-B leaf records
-    tc_ms, tc_n = ktimes[tkey]
-    launches_per_frame = max(tc_n / max(frames_prof, 1), 1)
-    avg_launch_ms = tc_ms / max(tc_n, 1)
-    # With frames in flight (or several batches per frame) a launch shares the GPU with other launches, so its wall
-    # duration says nothing about how hard IT drives the machine; the roofline fractions use the duration of the same
-    # launch with one kernel in flight at a time (the isolated pass above -- also the mode the PMC passes run in, the
-    # profiler serialises dispatches), the overlapped duration is reported next to it.
-    in_flight = args.frames_in_flight
-    overlapped = kernel_count_batches > 1 or in_flight > 1
-    iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
-    roof_ms = iso_ms if overlapped else avg_launch_ms
-    avg_launch_s = max(roof_ms * 1e-3, 1e-12)
-    scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[args.scene]
-    prof = profile_counters(scene_tag, W, H, spp, depth, args.svgf) if world == 1 else None
-    pk = kernel_entry(prof, dominant)
-    # Three candidate roofs for the dominant kernel, each a fraction <= 1 of a hardware limit; `bound` names the
-    # largest, `frac` is that fraction.  HBM and L2 bytes and the VALU counters come from the committed PMC passes of
-    # this workload (per launch), the duration from the HIP events above.
-    fractions = {}
-    if pk:
-        if "hbm_bytes" in pk:
-            fractions["hbm"] = pk["hbm_bytes"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
-        if "l2_bytes_max" in pk:
-            fractions["l2"] = pk["l2_bytes_max"] / avg_launch_s / 1e9 / L2_PEAK_GBS
-        if "valu_busy" in pk:
-            # issue slots are per cycle: rescale the profiled run's busy fraction by the duration ratio
-            prof_ms = pk["cycles"] / 2.4e6
-            fractions["valu"] = pk["valu_busy"] * (prof_ms / roof_ms) if roof_ms > 0 else pk["valu_busy"]
-    bound = max(fractions, key=fractions.get) if fractions else "hbm"
-    units = {"hbm": ("GB/s", HBM_PEAK_GBS), "l2": ("GB/s", L2_PEAK_GBS), "valu": ("VALU issue slots busy", 1.0)}
-    frac = fractions.get(bound)
-    roofline = {
-        "kernel": dominant, "bound": bound,
-        "achieved": round(frac * units[bound][1], 3) if frac is not None else None, "peak": units[bound][1], "unit": units[bound][0],
-        "frac": round(frac, 4) if frac is not None else None,
-        "traffic": pk.get("hbm_bytes") if pk else None,
-        "fractions": {k: round(v, 4) for k, v in fractions.items()},
-        "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
-        "roofline_launch_ms": round(roof_ms, 5),
-        "algorithmic": {"bytes_per_launch": round(bytes_per_frame / launches_per_frame),
-                        "GBps": round(bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
-                        "bytes_per_launch_this_layout": round(own_bytes_per_frame / launches_per_frame),
-                        "GBps_this_layout": round(own_bytes_per_frame / launches_per_frame / avg_launch_s / 1e9, 1),
-                        "note": "SURVEY 8(d): 48 B per node visit + 80 B per triangle test + 56 B per ray (reference layout); "
-                                "this layout reads 32 B per inner visit and 48 B per leaf visit.  A rate, not a fraction of a roof: "
-                                "the records are served by L1/L2"},
-        "pmc": ({"file": prof[0], "lane_utilisation": pk.get("lane_utilisation"), "l1_hit_rate": pk.get("l1_hit_rate"),
-                 "l2_hit_rate": pk.get("l2_hit_rate"), "l1_stall": pk.get("l1_stall"), "valu_busy_profiled": pk.get("valu_busy"),
-                 "valu_useful": round(pk["valu_busy"] * pk["lane_utilisation"], 4) if pk.get("lane_utilisation") and pk.get("valu_busy") else None,
-                 "avg_launch_ms_profiled": round(pk["cycles"] / 2.4e6, 5) if pk.get("cycles") else None} if pk else None),
-        "note": "fractions: hbm = (FETCH_SIZE*2 + WRITE_SIZE) / t / 8 TB/s; l2 = TCC_REQ*128 B / t / 34.5 TB/s (upper bound); "
-                "valu = SQ_ACTIVE_INST_VALU / 256 CUs / cycles (rocprofiler's VALUBusy); formulas in DESIGN.md section 6",
-    }
-    # k_shade: the one kernel with material HBM traffic.  Compulsory bytes = the path state it must read and write once
-    # per queue entry (80 B in: queue entry, ray, hit, throughput, seed; 16 B throughput out; per hit the next ray 32 B,
-    # the shadow ray 48 B and two queue entries 8 B; per miss the contribution read-modify-write 32 B).
-    sh_ms, sh_n = ktimes["shade"]
-    sk = kernel_entry(prof, "k_shade")
-    shade = None
-    if sh_n:
-        if overlapped and ktimes_excl["shade"][1]:
-            sh_ms, sh_n = ktimes_excl["shade"][0] * (frames_prof / max(n_excl, 1)), ktimes_excl["shade"][1] * (frames_prof / max(n_excl, 1))
-        sh_launch_s = sh_ms * 1e-3 / sh_n
-        entries, hits = per_frame["closest_rays"], per_frame["hits"]
-        comp = (96 * entries + 88 * hits + 32 * (entries - hits)) / max(sh_n / max(frames_prof, 1), 1)
-        shade = {"kernel": "k_shade", "bound": "hbm", "avg_launch_ms": round(sh_launch_s * 1e3, 5), "launches": sh_n,
-                 "compulsory_bytes_per_launch": round(comp),
-                 "compulsory_GBps": round(comp / sh_launch_s / 1e9, 1),
-                 "traffic": sk.get("hbm_bytes") if sk else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "achieved": round(sk["hbm_bytes"] / sh_launch_s / 1e9, 1) if sk and "hbm_bytes" in sk else None,
-                 "frac": round(sk["hbm_bytes"] / sh_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sk and "hbm_bytes" in sk else None,
-                 "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None}
-    roofline["shade"] = shade
-    if overlapped:
-        roofline["note"] += ("; %d frames in flight x %d batches per frame run on separate streams: avg_launch_ms (what rocprofv3 --kernel-trace "
-                             "of this command shows) is the wall duration of a launch that shares the GPU, roofline_launch_ms the same launch "
-                             "with one kernel in flight at a time, which the fractions use" % (in_flight, kernel_count_batches))
-    kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
-    kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
-    svgf_info = None
-    if args.svgf:
-        # compulsory HBM bytes per pixel and launch (every input plane read once, every output written once; the
-        # filter taps themselves are L2 hits): a-trous reads normal+depth, albedo+id, colour+variance and writes one
-        # plane (+ the temporary colour on the first and the output on the last iteration)
-        px = W * H
-        at_ms, at_n = ktimes["svgf_atrous"]
-        at_bytes = px * (48 + 16) + px * 32 / max(at_n / max(frames_prof, 1), 1)
-        at_launch_ms = at_ms / max(at_n, 1)
-        svgf_info = {"passes_ms_per_frame": {k: kernel_ms_per_frame[k] for k in kernel_ms_per_frame if k.startswith("svgf")},
-                     "atrous": {"bound": "hbm", "compulsory_bytes_per_launch": int(at_bytes), "avg_launch_ms": round(at_launch_ms, 5),
-                                "achieved": round(at_bytes / (at_launch_ms * 1e-3) / 1e9, 1) if at_n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(at_bytes / (at_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if at_n else None},
-                     "filter_ms_per_frame": round(sum(v for k, v in kernel_ms_per_frame.items() if k.startswith("svgf")), 4)}
-    ray_segments = per_frame["closest_rays"] + per_frame["shadow_rays"]
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import orc     # the cpu_baseline leg is the only place bench.py touches oracle/
-        # bounded sample of the same workload: the benchmarked frame itself (same scene / camera / seeds / size) when a
-        # CPU frame takes seconds (1080p 1 spp: ~1.2 s with 16 threads); 1/6 linear resolution for the 4K 8-spp config,
-        # whose full frame would take minutes
-        cw, ch = W, H
-        if W * H * spp > 4 * 1920 * 1080:
-            cw, ch = max(W // 6, 8), max(H // 6, 8)
-        ccam = orc.create_camera(cam["pos"], cam["at"], cam["vfov"], cw, ch)
-        cseeds = orc.init_sampler(cw, ch, 0)
-
-        cpu_svgf = orc.Svgf() if args.svgf else None
-
-        def cpu_frame(f, nthreads=0):
-            if cpu_svgf is not None:
-                cpu_svgf.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, compute_motion=True, nthreads=nthreads)
-            elif brk or spp == 1:
-                orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=spp, frame=f, nthreads=nthreads)
-            else:       # every sample traced: spp passes of one sample (same work as the GPU's all-samples mode)
-                for i in range(spp):
-                    orc.render(fs, ccam, cseeds, cw, ch, depth, rr, spp=1, frame=f * spp + i, nthreads=nthreads)
-
-        def cpu_median(nthreads, min_frames, budget_s):
-            cpu_frame(0, nthreads)      # warm-up
-            ts = []
-            t_all = time.perf_counter()
-            while (len(ts) < min_frames or time.perf_counter() - t_all < budget_s / 3) and time.perf_counter() - t_all < budget_s:
-                t1 = time.perf_counter()
-                cpu_frame(len(ts), nthreads)
-                ts.append(time.perf_counter() - t1)
-            return float(np.median(ts)), len(ts)
-
-        n_cpu = usable_cpus()
-        med, nfr = cpu_median(n_cpu, 5, 16.0)
-        med8, nfr8 = cpu_median(8, 2, 8.0)      # the reference app's own setting (host_renderer/main.cpp:18-23,271)
-        cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": n_cpu, "logical_cpus": orc.lib().orc_num_procs(),
-                        "kind": "port", "sample": ("the benchmarked frame itself: " if (cw, ch) == (W, H) else "reduced frame: ") + "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
-                        "ms_per_frame_sample": round(1e3 * med, 2),
-                        "value_8_threads": round(cw * ch * spp / 1e6 / med8, 4), "frames_8_threads": nfr8}
-
-    if final_img is not None:
-        np.save(args.dump, final_img)
-
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "Mrays/sec (W*H*spp/1e6/s, reference definition), Sponza 1080p 1spp 5-bounce" if (args.scene == "sponza" and (W, H, spp, depth) == (1920, 1080, 1, 5) and not args.svgf)
-            else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
-            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
-                       "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
-                       "frames_in_flight": args.frames_in_flight,
-                       "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"]))},
-            "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / args.steps), 2),
-            "work_per_frame": {k: round(v) for k, v in per_frame.items()},
-            "kernel_ms_per_frame": kernel_ms_per_frame,
-            "kernel_ms_per_frame_isolated": kernel_ms_per_frame_isolated,
-            "roofline": roofline,
-            "svgf": svgf_info,
-            "cpu_baseline": cpu_baseline,
-        }
-    r.close()
     if use_dist:
         # every rank drains its own buffers (RCCL's banner sits in the C library's) BEFORE rank 0 writes the JSON line
         sys.stdout.flush()

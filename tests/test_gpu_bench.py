@@ -1,0 +1,60 @@
+"""bench.py as the driver runs it, on one GPU: the JSON contract, the companion workload, and -- with --force-gather --
+the N > 1 exchange step (RCCL all_gather_into_tensor of the tile buffers + atn_assemble_tiles_on) with a world of one,
+so that the multi-GPU bench path runs every round even when no 8-GPU node is available."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, tmp_path, name):
+    dump = str(tmp_path / (name + ".npy"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-companion", "--dump", dump] + extra,
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    return json.loads(lines[-1]), np.load(dump)      # the JSON line is the LAST line of stdout, whatever RCCL printed before
+
+
+@pytest.mark.gpu
+def test_force_gather_film_equals_plain_film(tmp_path):
+    plain, film_plain = run_bench([], tmp_path, "plain")
+    gath, film_gath = run_bench(["--force-gather"], tmp_path, "gather")
+    assert film_plain.shape == (1080, 1920, 4)
+    assert film_gath.tobytes() == film_plain.tobytes()
+    assert (film_plain[..., 3] == 3).all()
+    for d in (plain, gath):
+        assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 0
+        assert d["roofline"]["kernel"] == "k_trace_fused" and d["ms_per_frame_latency"] >= 0.9 * d["ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_default_line_carries_roofline_companion_and_cpu_baseline():
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "companion", "ms_per_frame_latency"):
+        assert k in d, k
+    assert "sponza_lod" in d["config"]["workload"] and "atrium" in d["companion"]["config"]["workload"]
+    for w in (d, d["companion"]):
+        rf = w["roofline"]
+        assert rf["bound"] in ("hbm", "l2", "l1", "valu") and rf["avg_launch_ms"] > 0
+        assert rf["calibration"] and rf["calibration"]["file"].startswith("profiles/")
+        # counters are used only when taken on these kernel sources; otherwise the record says which file was refused
+        assert rf["pmc"]["kernel_sources_sha16"]
+        if rf["pmc"]["file"] is None:
+            assert rf["frac"] is None and "refused_stale_file" in rf["pmc"]
+        else:
+            assert 0 < rf["frac"] <= 1.0 and set(rf["fractions"]) >= {"hbm", "l2", "l1", "valu"}
+        cb = w["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1

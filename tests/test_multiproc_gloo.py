@@ -71,3 +71,30 @@ def test_bench_self_launch_command():
     assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
     free = b.launcher_cmd(2, [])
     assert int(free[free.index("--master-port") + 1]) > 0
+
+
+def test_bench_refuses_counters_taken_on_other_kernel_sources(tmp_path, monkeypatch):
+    """bench.py's roofline uses committed PMC counters only when they were collected on the kernel sources it is running
+    (content hash of aten_amd/csrc + include/); a record from other sources is named and refused, never used silently."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from aten_amd.build import kernel_sources_sha16
+    sha = kernel_sources_sha16()
+    assert len(sha) == 16 and sha == kernel_sources_sha16()
+    (tmp_path / "profiles").mkdir()
+    tag = "sponza_lod 1920x1080 1spp 5-bounce"
+    rec = {"workload": tag, "kernel_sources_sha16": "0" * 16, "kernels": {"k_trace_fused<true, false>": {"launches_sampled": 5}}}
+    (tmp_path / "profiles" / "r00_counters_x.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    best, stale, got = b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)
+    assert best is None and stale == os.path.join("profiles", "r00_counters_x.json") and got == sha
+    rec["kernel_sources_sha16"] = sha
+    (tmp_path / "profiles" / "r01_counters_x.json").write_text(json.dumps(rec))
+    best, stale, _ = b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)
+    assert best[0] == os.path.join("profiles", "r01_counters_x.json") and stale is not None
+    assert b.kernel_entry((best,), "k_trace_fused")["launches_sampled"] == 5
+    assert b.profile_counters("cornell", 1920, 1080, 1, 5, False)[0] is None

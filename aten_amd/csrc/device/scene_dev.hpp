@@ -70,6 +70,33 @@ static_assert(sizeof(DevMaterial) == 80, "DevMaterial");
 // (image/image.cpp:76-80) -- for an integer k in 0..255, i.e. an 8-bit image the caller converted with one IEEE operation,
 // is stored as packed RGBA8 and converted back with the same operation on fetch -- bit-identical values at a quarter of the bytes (sponza_lod: 50 MB of float4 texels -> 12.5 MB, 32 texels
 // per 128-byte line instead of 8).  Anything else (HDR environment maps, filtered images) stays float4.
+// Texel order (ATN_TEX_TILED): 64-byte SECTORS of 4 x 4 RGBA8 texels / 2 x 2 float4 texels, sectors row-major over the image
+// (width and height padded to whole sectors), so a 128-byte line is an 8 x 4 / 4 x 2 block instead of a 32 x 1 / 8 x 1 strip:
+// neighbouring pixels' point lookups share sectors in both directions.  Values are untouched (same texel, other address).
+#ifndef ATN_TEX_TILED
+#define ATN_TEX_TILED 0        /* measured (r03, profiles/r03_shade_texture_tiling.txt): k_shade FETCH_SIZE -0.4 % / -0.5 %: the lookups are incoherent, row-major stays */
+#endif
+__host__ __device__ inline uint32_t tex_log2_tile(int32_t format) { return format ? 2u : 1u; }      // RGBA8: 4 x 4, float4: 2 x 2
+__host__ __device__ inline size_t tex_storage_texels(int32_t width, int32_t height, int32_t format)
+{
+#if ATN_TEX_TILED
+    const uint32_t l = tex_log2_tile(format), m = (1u << l) - 1u;
+    return (size_t)(((uint32_t)width + m) >> l) * (((uint32_t)height + m) >> l) << (2 * l);
+#else
+    return (size_t)width * height;
+#endif
+}
+__host__ __device__ inline uint32_t tex_texel_index(int32_t width, int32_t format, int32_t x, int32_t y)
+{
+#if ATN_TEX_TILED
+    const uint32_t l = tex_log2_tile(format), m = (1u << l) - 1u;
+    const uint32_t per_row = ((uint32_t)width + m) >> l;
+    return ((((uint32_t)y >> l) * per_row + ((uint32_t)x >> l)) << (2 * l)) + (((uint32_t)y & m) << l) + ((uint32_t)x & m);
+#else
+    return (uint32_t)(y * width + x);
+#endif
+}
+
 struct DevTexture {
     uint32_t offset;    // first texel in `texels` (format 0) or `texels8` (format 1)
     int32_t width, height;

@@ -352,6 +352,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         // (aten::Image::Load multiplies by `norm = 1.0F / 255`, image/image.cpp:76-80)
         int32_t fmt = 0;
         const size_t at8 = img.texels8.size();
+        std::vector<uint32_t> packed(n);
         for (int32_t cand = 1; cand <= 2 && !fmt && n > 0; cand++) {
             auto decode = [cand](uint32_t k) { return cand == 1 ? (float)k / 255.0F : (float)k * (1.0F / 255); };
             auto code = [&](float v, uint32_t& k) {
@@ -359,26 +360,34 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
                 k = (uint32_t)(v * 255.0F + 0.5F);
                 return k <= 255u && decode(k) == v;
             };
-            img.texels8.resize(at8 + n);
             bool ok = true;
             for (size_t j = 0; j < n && ok; j++) {
                 uint32_t r = 0, g = 0, b = 0, a = 0;
                 ok = code(t.texels[j].x, r) && code(t.texels[j].y, g) && code(t.texels[j].z, b) && code(t.texels[j].w, a);
-                img.texels8[at8 + j] = r | (g << 8) | (b << 16) | (a << 24);
+                packed[j] = r | (g << 8) | (b << 16) | (a << 24);
             }
             if (ok) fmt = cand;
         }
         const bool unorm8 = fmt != 0;
         img.textures[i].width = t.width; img.textures[i].height = t.height;
+        // texel (x, y) goes to tex_texel_index(): 64-byte sectors of 4 x 4 / 2 x 2 texels (scene_dev.hpp); padding texels are 0
+        const size_t ns = tex_storage_texels(t.width, t.height, fmt);
         if (unorm8) {
             img.textures[i].offset = (uint32_t)at8; img.textures[i].format = fmt;
+            img.texels8.resize(at8 + ns, 0u);
+            for (int32_t y = 0; y < t.height; y++)
+                for (int32_t x = 0; x < t.width; x++)
+                    img.texels8[at8 + tex_texel_index(t.width, fmt, x, y)] = packed[(size_t)y * t.width + x];
         }
         else {
-            img.texels8.resize(at8);
             const size_t at = img.texels.size();
             img.textures[i].offset = (uint32_t)at; img.textures[i].format = 0;
-            img.texels.resize(at + n);
-            for (size_t j = 0; j < n; j++) img.texels[at + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
+            img.texels.resize(at + ns, make_float4(0, 0, 0, 0));
+            for (int32_t y = 0; y < t.height; y++)
+                for (int32_t x = 0; x < t.width; x++) {
+                    const atn_vec4& c = t.texels[(size_t)y * t.width + x];
+                    img.texels[at + tex_texel_index(t.width, 0, x, y)] = make_float4(c.x, c.y, c.z, c.w);
+                }
         }
     }
 

@@ -440,7 +440,12 @@ def run_workload(args, cfg, ctx):
                  "traffic": sk.get("hbm_bytes") if sk else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "achieved": round(sk["hbm_bytes"] / sh_launch_s / 1e9, 1) if sk and "hbm_bytes" in sk else None,
                  "frac": round(sk["hbm_bytes"] / sh_launch_s / 1e9 / HBM_PEAK_GBS, 4) if sk and "hbm_bytes" in sk else None,
-                 "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None}
+                 "traffic_over_compulsory": round(sk["hbm_bytes"] / comp, 2) if sk and "hbm_bytes" in sk and comp else None,
+                 "traffic_lower_bound": sk.get("hbm_bytes_lower") if sk else None,
+                 "traffic_over_compulsory_lower_bound": round(sk["hbm_bytes_lower"] / comp, 2) if sk and sk.get("hbm_bytes_lower") and comp else None,
+                 "traffic_note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's correction: streaming reads make 128-B requests tallied at 64 B); "
+                                 "a random texel / environment-map lookup makes ONE 64-B request (measured: profiles/r03_calibration.json, "
+                                 "k_cal_hbm_gather), so for this kernel the x2 over-counts the lookups: the truth lies between the two bounds"}
     roofline["shade"] = shade
     if overlapped:
         roofline["note"] += ("; %d frames in flight x %d batches per frame run on separate streams: avg_launch_ms (what rocprofv3 --kernel-trace "

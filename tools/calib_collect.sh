@@ -17,7 +17,9 @@ SETS[2]="SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_IN
 SETS[3]="TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
 SETS[4]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"
 SETS[5]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
-for i in 1 2 3 4 5; do
+SETS[6]="FETCH_SIZE GRBM_GUI_ACTIVE"
+SETS[7]="TCC_BUBBLE_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_sum"
+for i in 1 2 3 4 5 6 7; do
   timeout 300 rocprofv3 --pmc ${SETS[$i]} --output-format csv -d "$OUT/pass$i" -o pmc -- "$OUT/valu_calib" > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$? : ${SETS[$i]}"
 done

@@ -78,6 +78,16 @@ def main(d):
                 e["tcp_cache_accesses_per_cu_cycle"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc, 4)
             if "SQ_INSTS_VMEM_RD" in c:
                 e["vmem_rd_insts_per_cu_cycle"] = round(c["SQ_INSTS_VMEM_RD"] / 256.0 / cyc, 5)
+        if "FETCH_SIZE" in c and "lookups_16B" in p:
+            e["fetch_size_bytes_per_lookup_raw"] = round(c["FETCH_SIZE"] * 1024.0 / p["lookups_16B"], 2)
+            if "TCC_EA0_RDREQ_sum" in c:
+                e["tcc_ea_rdreq_per_lookup"] = round(c["TCC_EA0_RDREQ_sum"] / p["lookups_16B"], 4)
+                e["tcc_ea_rdreq_32B_per_lookup"] = round(c.get("TCC_EA0_RDREQ_32B_sum", 0.0) / p["lookups_16B"], 4)
+                if "TCC_BUBBLE_sum" in c:
+                    e["tcc_bubble_per_lookup"] = round(c["TCC_BUBBLE_sum"] / p["lookups_16B"], 4)
+        if "FETCH_SIZE" in c and "hops" in p and "64MB" in str(p.get("table", "")):
+            hops_total = p["lane_hops_per_us"] * p["ms"] * 1e3
+            e["fetch_size_bytes_per_hop_raw"] = round(c["FETCH_SIZE"] * 1024.0 / hops_total, 2)
         kernels.append(e)
 
     def find(k, **kw):
@@ -102,6 +112,16 @@ def main(d):
         "lane_loads_per_cu_per_us_random": find("k_cal_l1_gather", variant="random (one").get("lane_loads_per_cu_per_us"),
         "lane_loads_per_cu_per_us_rows": find("k_cal_l1_gather", variant="rows").get("lane_loads_per_cu_per_us"),
     }
+    ceil["fetch_size_raw_bytes_per_random_16B_lookup"] = find("k_cal_hbm_gather").get("fetch_size_bytes_per_lookup_raw")
+    ceil["tcc_ea_rdreq_per_random_16B_lookup"] = find("k_cal_hbm_gather").get("tcc_ea_rdreq_per_lookup")
+    ceil["tcc_ea_rdreq_32B_per_random_16B_lookup"] = find("k_cal_hbm_gather").get("tcc_ea_rdreq_32B_per_lookup")
+    st = find("k_cal_hbm_stream")
+    ceil["stream_fetch_size_raw_bytes_per_16B"] = st.get("fetch_size_bytes_per_lookup_raw")
+    ceil["stream_tcc_ea_rdreq_per_16B"] = st.get("tcc_ea_rdreq_per_lookup")
+    ceil["stream_tcc_bubble_per_16B"] = st.get("tcc_bubble_per_lookup")
+    ceil["random_tcc_bubble_per_lookup"] = find("k_cal_hbm_gather").get("tcc_bubble_per_lookup")
+    ceil["stream_GBps"] = st.get("useful_GBps")
+    ceil["hbm_random_16B_lookups_per_us"] = find("k_cal_hbm_gather").get("lookups_per_us")
     for w in (1, 5, 8):
         for tab, key in (("16KB", "l1"), ("1MB", "l2"), ("64MB", "mall")):
             e = find("k_cal_l1_chase<%d>" % w, table=tab)

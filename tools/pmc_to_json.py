@@ -68,6 +68,10 @@ def main(d, workload):
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
             e["hbm_bytes"] = round(g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024)
             e["hbm_read_bytes"] = round(g("FETCH_SIZE") * 1024 * 2)
+            # FETCH_SIZE = 64 B per fabric read request.  A streaming read makes 128-byte requests (hence the guide's x2),
+            # a random 16-byte lookup ONE 64-byte request (profiles/r03_calibration.json: k_cal_hbm_gather 63.8 B and 1.00
+            # request per lookup, k_cal_hbm_stream 8.0 B per 16 B): for a kernel that mixes both the truth lies between
+            e["hbm_bytes_lower"] = round(g("FETCH_SIZE") * 1024 + g("WRITE_SIZE") * 1024)
             e["hbm_write_bytes"] = round(g("WRITE_SIZE") * 1024)
         if g("TCC_REQ_sum") is not None:
             e["l2_bytes_max"] = round(g("TCC_REQ_sum") * 128)

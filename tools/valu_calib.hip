@@ -119,6 +119,37 @@ __global__ void __launch_bounds__(256) k_cal_l1_gather(const float4* __restrict_
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+// ---- HBM side: independent 16-byte point lookups in a table far larger than the caches (the shape of a texel / environment
+// map lookup of an incoherent path): what do FETCH_SIZE and TCC_EA0_RDREQ read PER LOOKUP?  (the guide's "x2" correction of
+// FETCH_SIZE is calibrated on streaming reads only)
+__global__ void __launch_bounds__(256) k_cal_hbm_gather(const float4* __restrict__ table, uint32_t mask, float* out, int iters)
+{
+    uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 99991u;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int i = 0; i < iters; i++) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x = x * 1664525u + 1013904223u;
+            v[k] = table[(x >> 4) & mask];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
+// streaming twin: every lane reads consecutive 16-byte records (1 KiB per wave load, whole 128-byte lines)
+__global__ void __launch_bounds__(256) k_cal_hbm_stream(const float4* __restrict__ table, uint32_t n_rec, float* out)
+{
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_rec; i += gridDim.x * 256u) {
+        const float4 v = table[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
 // ---- L1 / L2: dependent chain, one hop = the two 16-B halves of a 32-B record, next index from the data --------------
 template <int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(256) k_cal_l1_chase(const float4* __restrict__ table, uint32_t mask, float* out, int hops)
@@ -229,6 +260,21 @@ int main()
             run(1); run(5); run(8);
             CK(hipFree(t));
         }
+    }
+    {
+        // 1 GiB of float4 (2^26 records): beyond L2 (32 MiB) and the Infinity Cache (256 MiB)
+        const uint32_t n_rec = 1u << 26;
+        float4* big; CK(hipMalloc(&big, (size_t)n_rec * sizeof(float4)));
+        CK(hipMemset(big, 0, (size_t)n_rec * sizeof(float4)));
+        const int iters = 64;
+        float ms = best_of([&] { hipLaunchKernelGGL(k_cal_hbm_gather, dim3(full), dim3(256), 0, 0, (const float4*)big, n_rec - 1, out, iters); });
+        double lookups = (double)full * 256 * iters * 4;
+        printf("{\"kernel\": \"k_cal_hbm_gather\", \"table\": \"1 GiB\", \"ms\": %.4f, \"lookups_16B\": %.0f, \"lookups_per_us\": %.1f, \"useful_GBps\": %.1f}\n",
+               ms, lookups, lookups / (ms * 1e3), lookups * 16 / (ms * 1e6));
+        ms = best_of([&] { hipLaunchKernelGGL(k_cal_hbm_stream, dim3(full), dim3(256), 0, 0, (const float4*)big, n_rec, out); });
+        printf("{\"kernel\": \"k_cal_hbm_stream\", \"table\": \"1 GiB\", \"ms\": %.4f, \"lookups_16B\": %.0f, \"bytes\": %.0f, \"useful_GBps\": %.1f}\n",
+               ms, (double)n_rec, (double)n_rec * 16, (double)n_rec * 16 / (ms * 1e6));
+        CK(hipFree(big));
     }
     CK(hipFree(out));
     return 0;

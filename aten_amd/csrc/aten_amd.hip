@@ -71,6 +71,7 @@ public:
     int n_batches = 3;
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
+    bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
     int env_shade_items = 0, env_flavour = -1, env_first_simple = 1;
     uint32_t env_simple_mask = 0;       // experiment: bit b = launch b of a sample on the plain walk
@@ -432,6 +433,7 @@ public:
         ATN_HIP(hipEventCreateWithFlags(&ev_gather, hipEventDisableTiming));
         // experiment knobs (tools/variants.sh): read once here, never inside a frame
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
+        if (const char* e = std::getenv("ATEN_AMD_SVGF_ATROUS4")) env_atrous4 = e[0] != '0';     // 0: the one-pixel-per-thread a-trous kernel
         if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
@@ -1416,7 +1418,14 @@ public:
         sf.cv = sv_cv[cur]; sf.cv_out = sv_spare;
         for (int32_t i = 0; i < sv_atrous_iters; i++) {
             prof_begin(prof, ATN_K_SVGF_ATROUS, fs);
-            hipLaunchKernelGGL(k_svgf_atrous, gp, tp, 0, fs, sf, i);
+            if (env_atrous4) {
+                // four pixels per thread (svgf.hpp, k_svgf_atrous4): the thread grid covers the 2 x 2 pixel GROUPS of pitch 2^i
+                const int32_t s = 1 << i;
+                const int32_t nx = ((d->width + 2 * s - 1) / (2 * s)) * s, ny = ((d->height + 2 * s - 1) / (2 * s)) * s;
+                const dim3 g4((((nx + 7) / 8) + 7) / 8 * 8, (ny + 31) / 32);
+                hipLaunchKernelGGL(k_svgf_atrous4, g4, tp, 0, fs, sf, i);
+            }
+            else hipLaunchKernelGGL(k_svgf_atrous, gp, tp, 0, fs, sf, i);
             prof_end(prof);
         }
         prof_begin(prof, ATN_K_SVGF_PREPARE, fs);

@@ -128,3 +128,30 @@ def test_8spp_8bounce_vs_oracle_640x360(ctx, orc, atrium, brk):
     # inside only if all eight are (0.95^8 = 0.66), while with the break most pixels stop after their first sample
     assert frac >= (0.90 if brk else 0.60), (brk, frac)
     assert mean_err <= 1e-2, (brk, mean_err)
+
+
+def test_companion_workload_1080p_vs_oracle(ctx, orc, atrium):
+    """The workload bench.py reports under `companion` (atrium, 1920x1080, 1 spp, 5 bounces), at its full size against the
+    oracle: primary rays, `Intersection` records and visit counters byte for byte (2 M walks through the 17 MB tree), the
+    per-launch work counters of a frame equal to the oracle's within the path-flip band, two frames within the frame
+    tolerance of the 5-bounce Disney scene."""
+    fs, cam = atrium
+    w, h = 1920, 1080
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], w, h)
+    ctx.updateCamera(c)
+    ctx.initSampler(w, h, 0)
+    ctx.setScreenShard(0, 1)
+    seeds = orc.init_sampler(w, h, 0)
+    rays = orc.generate_paths(c, seeds, w, h, 0, 0)
+    assert ctx.generate_paths(w, h, 0, 0).tobytes() == rays.tobytes()
+    want_i, wst = orc.trace_closest(fs, rays)
+    got_i, gst = ctx.trace_closest(rays, stats=True)
+    assert got_i.tobytes() == want_i.tobytes()
+    assert np.array_equal(gst, wst)
+    for frame in (0, 5):
+        ctx.reset()
+        got = ctx.render(w, h, 5, 3, frame=frame)
+        want = orc.render(fs, c, seeds, w, h, 5, 3, frame=frame)
+        frac, mean_err = frame_tolerance_report(got, want)
+        assert frac >= 0.97, (frame, frac)
+        assert mean_err <= 5e-3, (frame, mean_err)

@@ -281,6 +281,7 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
             for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
             __syncthreads();
         }
+        trace_shared_init(sh);
         trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {

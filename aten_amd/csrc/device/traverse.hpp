@@ -531,7 +531,124 @@ constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
 #endif
 constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
 constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
-struct TraceShared { float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk]; };   // 18 KB
+// TAIL MERGING (r03).  When the job queue is drained every wave still holds up to 64 walks that end at very different times
+// (sponza_lod: median 56 node visits, 1 % above 164), so a launch ends with thousands of waves that each keep a few lanes
+// alive -- and a wave load costs the per-CU L1 its 16 clocks whether 3 or 60 lanes take part (profiles/r03_calibration.json).
+// A CPU replay of the refill schedule puts 28 % of a 1.9 M-ray launch's wave-steps into that tail, at 23 %
+// lane occupancy.  So: a drained wave with at most kTailDonateLanes live walks DONATES them to the block -- it parks their
+// state (40 dwords each) in its own, now unused, staging region and leaves -- and drained waves with idle lanes pick
+// donated walks up through the same path that hands them fresh rays.  A walk continues in another lane with exactly the
+// state it had (slab constants are recomputed from the same origin / direction by the same function), so every ray's own
+// sequence of operations -- and the visit counters -- are untouched.
+// Protocol, all in LDS, no waiting anywhere: `ctrl` = waves of the block still running << 16 | donated walks not yet taken.
+// A donor publishes with ONE compare-and-swap (running - 1, pending + n) that only succeeds while another wave is still
+// running; a wave with nothing left leaves with ONE compare-and-swap (running - 1) that only succeeds while nothing is
+// pending.  Whichever of the two lands first, the other sees it: a donation is never left behind.
+#ifndef ATN_TAIL_MERGE
+#define ATN_TAIL_MERGE 0        /* measured (r03): correct, but the hot loop's allocation goes 80 -> 115 VGPRs (6 -> 4 waves per SIMD) and the
+                                   launch gets 12 % SLOWER; forced back to 80 registers the kernel faults.  DESIGN.md section 7 */
+#endif
+#ifndef ATN_TAIL_DONATE_LANES
+#define ATN_TAIL_DONATE_LANES 16
+#endif
+constexpr uint32_t kTailDonateLanes = ATN_TAIL_DONATE_LANES;
+constexpr uint32_t kTailFields = 42;            // dwords of a parked walk (2 x 13 slab + 6 hit + 8 walk + the COUNT instantiations' two counters)
+struct TraceShared {
+    float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk];    // 18 KB
+    uint32_t ctrl;
+    uint32_t don_count[kTraceWavesPerBlock];    // walks wave d parked in stage[d] (0 = none)
+    uint32_t don_taken[kTraceWavesPerBlock];    // ... of which claimed (may run past don_count: a claim past the end takes nothing)
+};
+static_assert(sizeof(float4) * kFetchChunk * 2 >= kTailFields * kTailDonateLanes * 4, "a wave's staging region holds its donation");
+
+ATN_DEV void trace_shared_init(TraceShared& sh)
+{
+    if (threadIdx.x == 0) {
+        sh.ctrl = (uint32_t)kTraceWavesPerBlock << 16;
+        for (int d = 0; d < kTraceWavesPerBlock; d++) { sh.don_count[d] = 0; sh.don_taken[d] = 0; }
+    }
+    __syncthreads();
+}
+ATN_DEV uint32_t tail_pending(TraceShared& sh) { return __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED) & 0xffffu; }
+// leave the block's census -- only while no donated walk is pending
+ATN_DEV bool tail_try_exit(TraceShared& sh)
+{
+    uint32_t ok = 0;
+    if (__lane_id() == 0) {
+        uint32_t old = __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED);
+        for (;;) {
+            if (old & 0xffffu) break;
+            const uint32_t prev = atomicCAS(&sh.ctrl, old, old - 0x10000u);
+            if (prev == old) { ok = 1; break; }
+            old = prev;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+}
+// publish n parked walks and leave -- only while another wave of the block is still running
+ATN_DEV bool tail_try_publish(TraceShared& sh, uint32_t n)
+{
+    uint32_t ok = 0;
+    if (__lane_id() == 0) {
+        uint32_t old = __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED);
+        for (;;) {
+            if ((old >> 16) <= 1u) break;
+            const uint32_t prev = atomicCAS(&sh.ctrl, old, old - 0x10000u + n);
+            if (prev == old) { ok = 1; break; }
+            old = prev;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+}
+// A parked walk is the Walk's registers, field by field (the slab constants too: recomputing them on the receiving side
+// costs ~35 live registers in the hot loop's allocation -- the kernel went from 80 to 115 VGPRs, 6 -> 4 waves per SIMD).
+template <bool COUNT>
+ATN_DEV void tail_park(float* pool, uint32_t k, const Walk& w, const TravCounters* cnt)
+{
+    uint32_t f = 0;
+    auto put = [&](float v) { pool[f * kTailDonateLanes + k] = v; f++; };
+    auto put_slab = [&](const RaySlab& r) {
+        put(r.org.x); put(r.org.y); put(r.org.z); put(r.dir.x); put(r.dir.y); put(r.dir.z);
+        put(r.invdir.x); put(r.invdir.y); put(r.invdir.z); put(r.oxinvdir.x); put(r.oxinvdir.y); put(r.oxinvdir.z);
+        put(r.finite ? 1.0F : 0.0F);
+    };
+    put_slab(w.wray); put_slab(w.ray);
+    put(w.hit.t); put(__int_as_float(w.hit.objid)); put(__int_as_float(w.hit.tri)); put(w.hit.a); put(w.hit.b);
+    put(__int_as_float(w.hit.meshid)); put(w.t_max); put(w.stop_t); put(__uint_as_float(w.payload));
+    put(__int_as_float(w.node)); put(__int_as_float(w.objid)); put(__int_as_float(w.meshid));
+    put(__int_as_float(w.top_hit)); put(__int_as_float(w.top_miss));
+    if (COUNT) { put(__uint_as_float(cnt->ray_nodes)); put(__uint_as_float(cnt->ray_tris)); }
+}
+// The loads are spelled as in-place `ds_read_b32` with the destination tied to the field's current register: written as plain
+// C++ the conditional redefinition of all 40 fields makes the register allocator keep a second copy of the walk across the
+// hot loop (80 -> 115 VGPRs, 6 -> 4 waves per SIMD) although the receiving lanes' old values are dead.
+#define ATN_LDS_LOAD_INPLACE(field, idx) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(field) : "v"(addr), "n"((idx) * kTailDonateLanes * 4))
+template <bool COUNT>
+ATN_DEV void tail_unpark(const float* pool, uint32_t k, Walk& w, TravCounters* cnt)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(pool + k);     // LDS byte address (the low 32 bits of a __shared__ pointer)
+    float fin_w, fin_r;
+    fin_w = 0.0F; fin_r = 0.0F;
+    ATN_LDS_LOAD_INPLACE(w.wray.org.x, 0); ATN_LDS_LOAD_INPLACE(w.wray.org.y, 1); ATN_LDS_LOAD_INPLACE(w.wray.org.z, 2);
+    ATN_LDS_LOAD_INPLACE(w.wray.dir.x, 3); ATN_LDS_LOAD_INPLACE(w.wray.dir.y, 4); ATN_LDS_LOAD_INPLACE(w.wray.dir.z, 5);
+    ATN_LDS_LOAD_INPLACE(w.wray.invdir.x, 6); ATN_LDS_LOAD_INPLACE(w.wray.invdir.y, 7); ATN_LDS_LOAD_INPLACE(w.wray.invdir.z, 8);
+    ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.x, 9); ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.y, 10); ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.z, 11);
+    ATN_LDS_LOAD_INPLACE(fin_w, 12);
+    ATN_LDS_LOAD_INPLACE(w.ray.org.x, 13); ATN_LDS_LOAD_INPLACE(w.ray.org.y, 14); ATN_LDS_LOAD_INPLACE(w.ray.org.z, 15);
+    ATN_LDS_LOAD_INPLACE(w.ray.dir.x, 16); ATN_LDS_LOAD_INPLACE(w.ray.dir.y, 17); ATN_LDS_LOAD_INPLACE(w.ray.dir.z, 18);
+    ATN_LDS_LOAD_INPLACE(w.ray.invdir.x, 19); ATN_LDS_LOAD_INPLACE(w.ray.invdir.y, 20); ATN_LDS_LOAD_INPLACE(w.ray.invdir.z, 21);
+    ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.x, 22); ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.y, 23); ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.z, 24);
+    ATN_LDS_LOAD_INPLACE(fin_r, 25);
+    ATN_LDS_LOAD_INPLACE(w.hit.t, 26); ATN_LDS_LOAD_INPLACE(w.hit.objid, 27); ATN_LDS_LOAD_INPLACE(w.hit.tri, 28);
+    ATN_LDS_LOAD_INPLACE(w.hit.a, 29); ATN_LDS_LOAD_INPLACE(w.hit.b, 30); ATN_LDS_LOAD_INPLACE(w.hit.meshid, 31);
+    ATN_LDS_LOAD_INPLACE(w.t_max, 32); ATN_LDS_LOAD_INPLACE(w.stop_t, 33); ATN_LDS_LOAD_INPLACE(w.payload, 34);
+    ATN_LDS_LOAD_INPLACE(w.node, 35); ATN_LDS_LOAD_INPLACE(w.objid, 36); ATN_LDS_LOAD_INPLACE(w.meshid, 37);
+    ATN_LDS_LOAD_INPLACE(w.top_hit, 38); ATN_LDS_LOAD_INPLACE(w.top_miss, 39);
+    if (COUNT) { ATN_LDS_LOAD_INPLACE(cnt->ray_nodes, 40); ATN_LDS_LOAD_INPLACE(cnt->ray_tris, 41); }
+    // the tied operands carry the dependence: nothing may read a field before the loads have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w.node), "+v"(w.t_max), "+v"(fin_w), "+v"(fin_r) :: "memory");
+    w.wray.finite = fin_w != 0.0F; w.ray.finite = fin_r != 0.0F;
+}
 
 template <bool COUNT, class Job>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treelet, uint32_t count, uint32_t* fetch_counter,
@@ -550,6 +667,8 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     bool first_chunk = true;            // wave-uniform
+    bool can_donate = true;             // wave-uniform: false once this wave found itself the last one running in its block
+    const int my_wave = (int)(threadIdx.x >> 6);
     bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
 
     Walk w;
@@ -607,8 +726,55 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 c_next += n_idle < avail ? n_idle : avail;
                 all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
             }
+            else if (ATN_TAIL_MERGE) {
+                // queue drained, chunk used up: walks another wave of the block parked, if any, go to the idle lanes (one donor
+                // per pass: with lanes still idle the next pass comes back here)
+                uint32_t idle_left = n_idle;
+                if (__builtin_expect(tail_pending(sh) != 0u, 0)) {
+                    __threadfence_block();
+                    int donor = -1;
+                    uint32_t first = 0, got = 0;
+#pragma unroll 1
+                    for (int d = 0; d < kTraceWavesPerBlock; d++) {
+                        if (d == my_wave) continue;
+                        const uint32_t have = __atomic_load_n(&sh.don_count[d], __ATOMIC_RELAXED);
+                        if (!have) continue;
+                        uint32_t f = 0;
+                        if (lane == 0) f = atomicAdd(&sh.don_taken[d], n_idle);
+                        f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+                        if (f >= have) continue;
+                        donor = d; first = f; got = have - f < n_idle ? have - f : n_idle;
+                        break;
+                    }
+                    if (donor >= 0) {
+                        if (lane == 0) atomicSub(&sh.ctrl, got);
+                        const float* pool = reinterpret_cast<const float*>(sh.stage[donor]);
+                        const uint32_t k = (uint32_t)__popcll(m_idle & lt);          // my rank among the idle lanes
+                        if (w.node == kLinkEnd && k < got) tail_unpark<COUNT>(pool, first + k, w, cnt);
+                        idle_left = n_idle - got;
+                        all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
+                    }
+                }
+                if (idle_left == 64u) {
+                    if (tail_try_exit(sh)) break;       // nothing in flight anywhere we could still be handed
+                    continue;                           // a donation landed in between: take it
+                }
+            }
             else if (n_idle == 64u) {
                 break;          // drained, chunk empty, nothing in flight
+            }
+        }
+        if (ATN_TAIL_MERGE && __builtin_expect(drained && can_donate && c_next >= c_count, 0)) {
+            const unsigned long long m_live = __ballot(w.node != kLinkEnd);
+            const uint32_t n_live = (uint32_t)__popcll(m_live);
+            if (n_live > 0 && n_live <= kTailDonateLanes) {
+                float* pool = reinterpret_cast<float*>(sh.stage[my_wave]);
+                if (w.node != kLinkEnd) tail_park<COUNT>(pool, (uint32_t)__popcll(m_live & lt), w, cnt);
+                if (lane == 0) __atomic_store_n(&sh.don_count[my_wave], n_live, __ATOMIC_RELAXED);
+                __threadfence_block();
+                if (tail_try_publish(sh, n_live)) break;            // the walks live on in other waves of the block
+                if (lane == 0) __atomic_store_n(&sh.don_count[my_wave], 0u, __ATOMIC_RELAXED);      // last wave running: it finishes them itself
+                can_donate = false;
             }
         }
         walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);

@@ -44,6 +44,12 @@ def sponza_disney():
 @pytest.fixture(scope="session")
 def gpu():
     """One PathTracing context on cuda:0; fails (does not skip) when the HIP library or GPU is missing."""
+    # torch (device tensors for the tile / gather tests) bundles its own HIP runtime: when it initialises AFTER
+    # libaten_amd.so has brought up the system one it reports "No HIP GPUs are available" -- so bring it up first, as
+    # bench.py does
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     from aten_amd.renderer import PathTracing
     r = PathTracing(0)
     yield r

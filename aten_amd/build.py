@@ -44,13 +44,14 @@ def _run(cmd):
 
 
 def kernel_sources_sha16():
-    """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over every file under aten_amd/csrc and include/,
-    in path order.  Recorded in profiles/*counters*.json when the PMC passes are collected (tools/pmc_to_json.py) and
+    """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over the sources of libaten_amd.so, in path order.  Recorded in profiles/*counters*.json when the PMC passes are collected (tools/pmc_to_json.py) and
     recomputed by bench.py, which refuses counters taken on other kernels (no .git on the GPU box: a content hash, not a
     commit id)."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(_walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",)))
+    # what aten_amd.hip is made of: the .hip, device/*.hpp, host/*.hpp and the two headers it includes.  (host/*.cpp and
+    # aten_amd_scene.h build libaten_amd_scene.so -- BVH builder, camera, scene ingestion -- and never reach a kernel.)
+    files = sorted(f for f in _walk(CSRC, (".hip", ".h", ".hpp"))) + [os.path.join(ROOT, "include", n) for n in ("aten_amd.h", "aten_layout.h")]
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
@@ -58,7 +59,8 @@ def kernel_sources_sha16():
 
 
 def build_host(force=False):
-    srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp"), os.path.join(CSRC, "host", "camera.cpp")]
+    srcs = [os.path.join(CSRC, "host", "bvh_builder.cpp"), os.path.join(CSRC, "host", "camera.cpp"),
+            os.path.join(CSRC, "host", "obj_ingest.cpp")]
     deps = srcs + _walk(os.path.join(ROOT, "include"), (".h",))
     if force or not _newer(HOST_LIB, deps):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", HOST_LIB] + srcs)

@@ -211,8 +211,14 @@ class SceneBuilder:
         return self.add_texture(tag, out[::-1])
 
     # ---------------------------------------------------------------- geometry
-    def load_obj(self, path, create_mtrl=None, separate_objs=False, normal_on_the_fly=False):
-        """ObjLoader::Load.  Returns the list of created PolygonObject ids."""
+    def load_obj(self, path, create_mtrl=None, separate_objs=False, normal_on_the_fly=False, native=None):
+        """ObjLoader::Load.  Returns the list of created PolygonObject ids.  The parsing and aten::ObjLoader's registration
+        rules run natively (csrc/host/obj_ingest.cpp through include/aten_amd_scene.h); `native=False` (or
+        ATEN_AMD_PY_OBJ=1) takes the Python twin below, kept as the cross-check (tests compare the two byte for byte)."""
+        if native is None:
+            native = os.environ.get("ATEN_AMD_PY_OBJ", "0") != "1"
+        if native:
+            return self._load_obj_native(path, create_mtrl, separate_objs, normal_on_the_fly)
         P, T, N, shapes, mtls = obj_loader.load_obj(path)
         base = os.path.dirname(path)
         objs = []
@@ -274,6 +280,56 @@ class SceneBuilder:
 
         if not separate_objs and cur_obj is not None:
             objs.append(cur_obj)
+        for o in objs:
+            self.blas.setdefault(o, None)
+        return objs
+
+    def _load_obj_native(self, path, create_mtrl, separate_objs, normal_on_the_fly):
+        from . import native_obj
+        f = native_obj.ObjFile(path)
+        try:
+            base = os.path.dirname(path)
+            mtls = [obj_loader.ObjMaterial(m["name"]) for m in f.materials]
+            for o, m in zip(mtls, f.materials):
+                o.diffuse, o.emission = m["diffuse"], m["emission"]
+                o.diffuse_texname, o.bump_texname = m["diffuse_texname"], m["bump_texname"]
+            # pass 1: the groups in creation order (they do not depend on the object partition): materials are created /
+            # found in exactly that order, like ObjLoader's callbacks
+            _, _, _, meshes, _ = f.register(len(self.pos), self.mesh_counter, separate_objs, normal_on_the_fly)
+            mtrl_of = {}
+            for m in meshes:
+                mid = int(m["mtl"])
+                if mid not in mtrl_of:
+                    mtrl_of[mid] = self._resolve_material(mid, mtls, base, create_mtrl)
+            is_em = lambda mid: int(self.materials[mtrl_of[mid]][1]["type"]) == L.MTRL_EMISSIVE
+            em = [1 if (i in mtrl_of and is_em(i)) else 0 for i in range(len(mtls))]
+            # pass 2: the partition into PolygonObjects needs to know which of them are Emissive
+            pos, nml, tris, meshes, objects = f.register(len(self.pos), self.mesh_counter, separate_objs, normal_on_the_fly, em,
+                                                         (-1 in mtrl_of) and is_em(-1))
+            shape_names = f.shape_names
+        finally:
+            f.close()
+        self.pos.extend(map(tuple, pos.tolist()))
+        self.nml.extend(map(tuple, nml.tolist()))
+        self.mesh_counter += len(meshes)
+        first_obj = len(self.objects)
+        for ob in objects:
+            name = shape_names[ob["shape"]] if ob["shape"] >= 0 else ""
+            self.objects.append(dict(type=L.OBJ_POLYGONS, name=name, meshes=[], first_tri=None))
+        first_tri = len(self.tris)
+        mesh_dicts = []
+        for m in meshes:
+            d = dict(tris=list(range(first_tri + int(m["first_triangle"]), first_tri + int(m["first_triangle"]) + int(m["n_triangles"]))),
+                     mtrl=mtrl_of[int(m["mtl"])], mesh_id=int(m["mesh_id"]))
+            mesh_dicts.append(d)
+            if m["object"] >= 0:
+                self.objects[first_obj + int(m["object"])]["meshes"].append(d)
+        for t in tris:
+            d = mesh_dicts[int(t["mesh"])]
+            self.tris.append(dict(idx=(int(t["idx"][0]), int(t["idx"][1]), int(t["idx"][2])), needNormal=int(t["need_normal"]),
+                                  mtrlid=d["mtrl"], mesh_id=d["mesh_id"]))
+        order = sorted((int(ob["return_order"]), first_obj + i) for i, ob in enumerate(objects) if ob["return_order"] >= 0)
+        objs = [i for _, i in order]
         for o in objs:
             self.blas.setdefault(o, None)
         return objs

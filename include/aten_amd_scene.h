@@ -45,6 +45,75 @@ int atns_create_camera(atn_camera_param* out, const float origin[3], const float
  * Returns number of leaves reached by following hit links only, or negative on a bad link. */
 int64_t atns_validate_nodes(const atn_bvh_node* nodes, uint32_t count);
 
+/* ---- scene ingestion: what libatenscene does between a file and aten::context -----------------------
+ * Wavefront OBJ / MTL with the REGISTRATION rules of aten::ObjLoader::Load (src/libatenscene/ObjLoader.cpp:95-461): one
+ * vertex per face corner in file order, uv.z flags, a TriangleGroupMesh per run of equal material ids inside a shape,
+ * needNormal per triangle, PolygonObject partition (one per shape, or one per file with emissive groups split out).
+ * tinyobjloader is absent from the reference snapshot: polygons are triangulated as a plain fan (0,1,2), (0,2,3), ...
+ * Two steps, because ObjLoader's object partition depends on the TYPE of the material its callback created:
+ *   atns_obj_open -> materials (name, Kd, Ke, map_Kd, map_bump) -> the caller creates / finds its materials
+ *   atns_obj_register(..., which of them are emissive) -> vertices, triangles, meshes, objects */
+typedef struct atns_obj atns_obj;
+typedef struct atns_obj_material_info {
+    const char* name;               /* owned by the handle */
+    const char* diffuse_texname;    /* map_Kd, "" if none */
+    const char* bump_texname;       /* map_bump / map_Bump / bump, "" if none */
+    float diffuse[3];               /* Kd (default 1 1 1) */
+    float emission[3];              /* Ke (default 0 0 0) */
+} atns_obj_material_info;
+typedef struct atns_obj_triangle {
+    uint32_t idx[3];                /* TriangleParameter::idx: vertex indices, first_vertex-based */
+    int32_t need_normal;            /* TriangleParameter::needNormal (ObjLoader.cpp:387-393) */
+    int32_t mesh;                   /* index into the mesh array */
+} atns_obj_triangle;
+typedef struct atns_obj_mesh {      /* one aten::TriangleGroupMesh */
+    int32_t mtl;                    /* index into the OBJ's material list, -1 = no usemtl */
+    uint32_t mesh_id;               /* first_mesh_id + creation order */
+    uint32_t first_triangle, n_triangles;
+    int32_t object;                 /* index into the object array */
+    int32_t shape;
+} atns_obj_mesh;
+typedef struct atns_obj_object {    /* one aten::PolygonObject, in creation order */
+    uint32_t first_mesh;            /* unused (an object's meshes are those whose `object` names it, in mesh order) */
+    uint32_t n_meshes;
+    int32_t shape;                  /* the shape that named it (ObjLoader's create_obj_functor) */
+    int32_t is_emissive_split;      /* 1 = split out because its material is emissive (ObjLoader.cpp:262-283,425-437) */
+    int32_t return_order;           /* position in the vector ObjLoader::Load returns (emissive objects as they appear, the
+                                       file's own object last), -1 = created but never returned */
+} atns_obj_object;
+int atns_obj_open(const char* path, atns_obj** out);                    /* 0, or negative: -3 = unreadable / bad indices */
+void atns_obj_close(atns_obj* h);
+uint32_t atns_obj_material_count(const atns_obj* h);
+int atns_obj_material(const atns_obj* h, uint32_t i, atns_obj_material_info* out);
+uint32_t atns_obj_shape_count(const atns_obj* h);
+const char* atns_obj_shape_name(const atns_obj* h, uint32_t i);
+/* first_vertex = ctxt.GetVertexNum() before the load; separate_objs = will_register_shape_as_separate_obj;
+ * normal_on_the_fly = need_compute_normal_on_the_fly; mtl_is_emissive[i] != 0 <=> OBJ material i resolved to an Emissive
+ * material (default_is_emissive: the same for faces without usemtl). */
+int atns_obj_register(atns_obj* h, uint32_t first_vertex, uint32_t first_mesh_id, int32_t separate_objs, int32_t normal_on_the_fly,
+                      const uint8_t* mtl_is_emissive, uint8_t default_is_emissive);
+uint32_t atns_obj_vertex_count(const atns_obj* h);
+uint32_t atns_obj_triangle_count(const atns_obj* h);
+uint32_t atns_obj_mesh_count(const atns_obj* h);
+uint32_t atns_obj_object_count(const atns_obj* h);
+/* copies what atns_obj_register produced into caller arrays sized by the counts above; any pointer may be NULL */
+int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, atns_obj_triangle* tris, atns_obj_mesh* meshes,
+                  atns_obj_object* objects);
+
+/* The material XML aten::MaterialLoader reads (src/libatenscene/MaterialLoader.cpp:82-218):
+ *   <root><material><name>..</name><type>..</type><baseColor>r g b</baseColor><ior>..</ior><albedoMap>file</albedoMap>..
+ * kind: 0 = vec3 (value[0..2]), 1 = texture file name (text), 2 = float (value[0]), -1 = not in MaterialLoader's table
+ * (skipped there).  A repeated name drops the later material; a missing type is "Diffuse". */
+typedef struct atns_mtrlxml atns_mtrlxml;
+typedef struct atns_mtrlxml_param_info { const char* name; const char* text; int32_t kind; float value[3]; } atns_mtrlxml_param_info;
+int atns_mtrlxml_open(const char* path, atns_mtrlxml** out);            /* -3 unreadable, -4 not that format (no <root>, ...) */
+void atns_mtrlxml_close(atns_mtrlxml* h);
+uint32_t atns_mtrlxml_count(const atns_mtrlxml* h);
+const char* atns_mtrlxml_name(const atns_mtrlxml* h, uint32_t i);
+const char* atns_mtrlxml_type(const atns_mtrlxml* h, uint32_t i);
+uint32_t atns_mtrlxml_param_count(const atns_mtrlxml* h, uint32_t i);
+int atns_mtrlxml_param(const atns_mtrlxml* h, uint32_t i, uint32_t k, atns_mtrlxml_param_info* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -554,8 +554,8 @@ def run_workload(args, cfg, ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 200: a timed region of ~0.8 s; 20 for the 4K 8-spp config)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="sponza", choices=["sponza", "cornell", "atrium"])
     ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config shortcuts: c2 = Cornell 1080p 1spp 5-bounce, c3 = Sponza 1080p 1spp 5-bounce "
@@ -590,8 +590,12 @@ def main():
         args.scene = "cornell"
     elif args.config == "c4":
         args.scene, args.width, args.height, args.spp, args.depth, args.all_samples = "atrium", 3840, 2160, 8, 8, True
+        if args.steps is None:
+            args.steps = 20
     elif args.config == "c5":
         args.svgf = True
+    if args.steps is None:
+        args.steps = 200 if args.width * args.height * args.spp <= 4 * 1920 * 1080 else 20
 
     if needs_self_launch(args.gpus, args.mgpu, os.environ):
         # `python bench.py --gpus N` on its own: become the launcher the contract describes (one rank per GPU)

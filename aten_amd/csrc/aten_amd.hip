@@ -121,14 +121,6 @@ public:
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
-    static constexpr int kCounterArrays = 5;    // per batch: q_count, sh_count, fetch_closest, fetch_shadow (round-1 resume cursor of the
-                                                // fused launches), fetch_resume (round-2 cursor); each [max_depth + 2]
-    // walks parked by drained trace waves for the continuation launches (traverse.hpp, ParkArea): two areas per batch
-    DevBuf<float> park_pool;
-    DevBuf<uint32_t> park_counts;
-    uint32_t park_waves = 0;                    // source waves one area holds
-    int env_tail_rounds = 0;                    // continuation launches per refill trace launch (ATEN_AMD_TAIL_ROUNDS: 0, 1 or 2)
-    uint32_t env_resume_div = 2;                // a continuation launch has 1 / this many blocks of the launch that fed it
     DevBuf<unsigned long long> stats;
     DevBuf<uint32_t> cost, cost_film;       // per-slot / per-pixel {node visits, triangle tests} of the last count_stats frame
     int32_t cost_w = 0, cost_h = 0;
@@ -146,9 +138,6 @@ public:
     struct Bank {
         DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
         DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
-        DevBuf<float> park_pool;
-        DevBuf<uint32_t> park_counts;
-        uint32_t park_waves = 0;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
         uint64_t bank_epoch = 0;
@@ -173,7 +162,6 @@ public:
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
         counters.swap(b.counters);
-        park_pool.swap(b.park_pool); park_counts.swap(b.park_counts); std::swap(park_waves, b.park_waves);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
         for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
@@ -445,8 +433,6 @@ public:
         ATN_HIP(hipEventCreateWithFlags(&ev_gather, hipEventDisableTiming));
         // experiment knobs (tools/variants.sh): read once here, never inside a frame
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
-        if (const char* e = std::getenv("ATEN_AMD_TAIL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) env_tail_rounds = v; }
-        if (const char* e = std::getenv("ATEN_AMD_RESUME_DIV")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) env_resume_div = (uint32_t)v; }
         if (const char* e = std::getenv("ATEN_AMD_SVGF_ATROUS4")) env_atrous4 = e[0] != '0';     // 0: the one-pixel-per-thread a-trous kernel
         if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
@@ -890,7 +876,7 @@ public:
             film_w = w; film_h = h;
         }
         if (max_depth + 2 > counters_depth) {
-            ATN_HIP(counters.resize((size_t)kMaxBatches * kCounterArrays * (max_depth + 2)));
+            ATN_HIP(counters.resize((size_t)kMaxBatches * 4 * (max_depth + 2)));
             counters_depth = max_depth + 2;
         }
         if (!stats.p) {
@@ -909,9 +895,9 @@ public:
         pb.isect = isect.p; pb.sh_o = sh_o.p; pb.sh_d = sh_d.p; pb.sh_c = sh_c.p;
         pb.accum = accum.p; pb.done = done.p; pb.queue[0] = queue0.p + slot_begin; pb.queue[1] = queue1.p + slot_begin;
         pb.shadow_q = shadow_q.p + slot_begin;
-        uint32_t* cb = counters.p + (size_t)batch * kCounterArrays * counters_depth;
+        uint32_t* cb = counters.p + (size_t)batch * 4 * counters_depth;
         pb.q_count = cb; pb.sh_count = cb + counters_depth;
-        pb.fetch_closest = cb + 2 * counters_depth; pb.fetch_shadow = cb + 3 * counters_depth; pb.fetch_resume = cb + 4 * counters_depth;
+        pb.fetch_closest = cb + 2 * counters_depth; pb.fetch_shadow = cb + 3 * counters_depth;
         pb.stats = count ? stats.p : nullptr;
         pb.cost = count ? cost.p : nullptr;
         return pb;
@@ -1054,18 +1040,7 @@ public:
         }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
         per = (per + kChunk - 1u) / kChunk * kChunk;        // whole 1024-slot chunks (16 screen tiles)
-        ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * kCounterArrays * counters_depth * 4, stream));
-        if (env_tail_rounds > 0 && use_refill && fuse_traces && !count) {
-            // two park areas per batch, each sized for the largest trace launch of a batch
-            const uint32_t per0 = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
-            const uint32_t waves = trace_grid(2u * per0 + 2u * kChunk) * ((uint32_t)kTraceBlock / 64u);
-            if (waves > park_waves || !park_pool.p) {
-                ATN_HIP(hipDeviceSynchronize());        // (first frame of a bank, or a larger frame: nothing of this bank is in flight, but its batch streams are not `stream`)
-                ATN_HIP(park_pool.resize((size_t)nb * 2u * waves * kParkFields * 64u));
-                ATN_HIP(park_counts.resize((size_t)nb * 2u * waves));
-                park_waves = waves;
-            }
-        }
+        ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * 4 * counters_depth * 4, stream));
         ATN_HIP(hipEventRecord(ev_fork, stream));
         for (int k = 0; k < nb; k++) {
             const uint32_t begin = (uint32_t)k * per;
@@ -1086,7 +1061,7 @@ public:
             const uint32_t g_slots = grid_for(n), g_trace = trace_grid(n), g_all = (n + 255u) / 256u;
             for (int32_t s = 0; s < d->sample; s++) {
                 fp.sample = s;
-                if (s > 0) ATN_HIP(hipMemsetAsync(pb.q_count, 0, (size_t)kCounterArrays * counters_depth * 4, st));
+                if (s > 0) ATN_HIP(hipMemsetAsync(pb.q_count, 0, (size_t)4 * counters_depth * 4, st));
                 prof_begin(prof, ATN_K_GEN, st);
                 hipLaunchKernelGGL(k_gen_path, dim3(g_slots), dim3(256), 0, st, pb, fp, camera, (const uint32_t*)seeds.p);
                 prof_end(prof);
@@ -1116,41 +1091,13 @@ public:
                         prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / simple_block)), tb(refill_now ? (uint32_t)kTraceBlock : simple_block);
                         const uint32_t lds = (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
-                        const ParkArea none{ nullptr, nullptr };
-                        if (refill_now && env_tail_rounds > 0) {
-                            // the launch's waves park what they still walk when the queue runs dry; continuation launches finish
-                            // those walks densely packed (traverse.hpp): round 1 parks again when there is a round 2
-                            const uint32_t wpb = (uint32_t)kTraceBlock / 64u;
-                            const uint32_t n_src0 = gr.x * wpb;
-                            const size_t area = (size_t)park_waves * kParkFields * 64u;
-                            const ParkArea a0{ park_pool.p + (size_t)(2 * k) * area, park_counts.p + (size_t)(2 * k) * park_waves };
-                            const ParkArea a1{ park_pool.p + (size_t)(2 * k + 1) * area, park_counts.p + (size_t)(2 * k + 1) * park_waves };
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b, a0);
-                            else hipLaunchKernelGGL((k_trace_fused<true, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b, a0);
-                            const uint32_t g1 = (gr.x + env_resume_div - 1u) / env_resume_div;
-                            if (env_tail_rounds == 1) {
-                                if (scene.any_alpha) hipLaunchKernelGGL((k_trace_resume<true, false>), dim3(g1), dim3(256), 0, st, pb, scene, bs, bc, a0, n_src0, pb.fetch_shadow + b, none);
-                                else hipLaunchKernelGGL((k_trace_resume<false, false>), dim3(g1), dim3(256), 0, st, pb, scene, bs, bc, a0, n_src0, pb.fetch_shadow + b, none);
-                            }
-                            else {
-                                const uint32_t g2 = (g1 + env_resume_div - 1u) / env_resume_div;
-                                if (scene.any_alpha) {
-                                    hipLaunchKernelGGL((k_trace_resume<true, true>), dim3(g1), dim3(256), 0, st, pb, scene, bs, bc, a0, n_src0, pb.fetch_shadow + b, a1);
-                                    hipLaunchKernelGGL((k_trace_resume<true, false>), dim3(g2), dim3(256), 0, st, pb, scene, bs, bc, a1, g1 * 4u, pb.fetch_resume + b, none);
-                                }
-                                else {
-                                    hipLaunchKernelGGL((k_trace_resume<false, true>), dim3(g1), dim3(256), 0, st, pb, scene, bs, bc, a0, n_src0, pb.fetch_shadow + b, a1);
-                                    hipLaunchKernelGGL((k_trace_resume<false, false>), dim3(g2), dim3(256), 0, st, pb, scene, bs, bc, a1, g1 * 4u, pb.fetch_resume + b, none);
-                                }
-                            }
-                        }
-                        else if (refill_now) {
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b, none);
-                            else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b, none);
+                        if (refill_now) {
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }
                         else {
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, lds, st, pb, scene, bs, bc, b, none);
-                            else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, lds, st, pb, scene, bs, bc, b, none);
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }
                         prof_end(prof);
                         if (b < d->maxDepth) {
@@ -1939,7 +1886,7 @@ int atn_generate_paths(atn_ctx* ctx, int32_t width, int32_t height, int32_t samp
     atn::PathBuffers pb = r.buffers(false);
     atn::DevBuf<atn_ray> out;
     C_HIP(r, out.resize((size_t)width * height));
-    C_HIP(r, hipMemsetAsync(r.counters.p, 0, (size_t)PathTracing::kCounterArrays * r.counters_depth * 4, r.stream));
+    C_HIP(r, hipMemsetAsync(r.counters.p, 0, (size_t)4 * r.counters_depth * 4, r.stream));
     if (sample > 0) C_HIP(r, hipMemsetAsync(r.done.p, 0, (size_t)r.n_slots * 4, r.stream));
     hipLaunchKernelGGL(atn::k_gen_path, dim3(PathTracing::grid_for(r.n_slots)), dim3(256), 0, r.stream, pb, fp, r.camera, (const uint32_t*)r.seeds.p);
     hipLaunchKernelGGL(atn::k_export_rays, dim3((r.n_slots + 255) / 256), dim3(256), 0, r.stream, pb, fp, out.p);

@@ -39,8 +39,7 @@ struct PathBuffers {
     uint32_t* q_count;  // [maxDepth + 1] live count entering bounce b
     uint32_t* sh_count; // [maxDepth]
     uint32_t* fetch_closest;    // [maxDepth] dynamic job-fetch cursors of the trace kernels
-    uint32_t* fetch_shadow;     // [maxDepth]  (fused launches: cursor of the first continuation launch)
-    uint32_t* fetch_resume;     // [maxDepth + 1] cursor of the second continuation launch
+    uint32_t* fetch_shadow;     // [maxDepth]
     uint32_t* cost;     // [2 * slots] node visits / triangle tests of the pixel's walks this sample (count_stats frames; else null)
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
 };
@@ -272,9 +271,8 @@ extern __shared__ float4 atn_dyn_lds[];
 #define ATN_TRACE_ATTR
 #endif
 
-template <bool COUNT, bool REFILL, class Job, bool PARK = false>
-ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc,
-                            const ParkArea& park = ParkArea{ nullptr, nullptr })
+template <bool COUNT, bool REFILL, class Job>
+ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc)
 {
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
@@ -284,7 +282,7 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
             __syncthreads();
         }
         trace_shared_init(sh);
-        trace_refill<COUNT, PARK>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc, park);
+        trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {
         trace_simple<COUNT>(sc, count, job, tc);
@@ -853,25 +851,14 @@ struct FusedJob {
     }
 };
 
-template <bool REFILL, bool ALPHA, bool PARK = false>
-__global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch, ParkArea park)
+template <bool REFILL, bool ALPHA>
+__global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
-    trace_dispatch<false, REFILL, FusedJob<ALPHA>, PARK>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc, park);
-}
-
-// Continuation of a k_trace_fused<true, ., true> launch (or of an earlier round): finishes the walks its waves parked when
-// the job queue ran dry, densely packed (traverse.hpp, trace_resume).  n_src = waves of the producing launch.
-template <bool ALPHA, bool PARK>
-__global__ void ATN_TRACE_ATTR __launch_bounds__(256) k_trace_resume(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, ParkArea src, uint32_t n_src,
-                                                                      uint32_t* cursor, ParkArea dst)
-{
-    const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
-    const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
-    trace_resume<PARK>(sc, src, n_src, cursor, job, dst);
+    trace_dispatch<false, REFILL>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }
 
 // Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,

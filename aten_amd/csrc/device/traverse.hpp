@@ -650,57 +650,9 @@ ATN_DEV void tail_unpark(const float* pool, uint32_t k, Walk& w, TravCounters* c
     w.wray.finite = fin_w != 0.0F; w.ray.finite = fin_r != 0.0F;
 }
 
-// CONTINUATION LAUNCHES (r03).  When a persistent wave finds the job queue empty it still holds up to 48 walks that end at
-// very different times; finishing them in place is what puts 28 % of a launch's wave-steps into a tail at 23 % lane occupancy
-// (tools/tail_sim.py) -- and a wave load costs the L1 the same whether 3 or 60 lanes take part.  Instead the wave PARKS its
-// live walks in HBM (26 dwords each: both rays, the hit so far, the links) and leaves; a follow-up launch (k_trace_resume)
-// picks the parked walks up densely packed -- its refill source is the array of parked walks instead of the job queue --
-// and may park again; the last round runs to the end.  A walk continues with exactly the state it had (the slab constants
-// are recomputed from the same origin / direction by the same function), so every ray's own sequence of operations is
-// untouched.  Unlike a hand-over INSIDE the kernel (ATN_TAIL_MERGE, measured 12 % slower: 80 -> 115 VGPRs) the receiving
-// side is another kernel with its own register allocation.
-constexpr uint32_t kParkFields = 26;
-struct ParkArea {
-    float* pool;            // [(source wave * kParkFields + field) * 64 + k], k = rank among the wave's live lanes
-    uint32_t* counts;       // [source wave]: walks parked (every wave of the producing launch writes its count, 0 included)
-};
-ATN_DEV void park_walk(const ParkArea& a, uint32_t wave, uint32_t k, const Walk& w)
-{
-    float* p = a.pool + (size_t)wave * (kParkFields * 64u) + k;
-    uint32_t f = 0;
-    auto put = [&](float v) { p[f * 64u] = v; f++; };
-    put(w.wray.org.x); put(w.wray.org.y); put(w.wray.org.z); put(w.wray.dir.x); put(w.wray.dir.y); put(w.wray.dir.z);
-    put(w.ray.org.x); put(w.ray.org.y); put(w.ray.org.z); put(w.ray.dir.x); put(w.ray.dir.y); put(w.ray.dir.z);
-    put(w.hit.t); put(__int_as_float(w.hit.objid)); put(__int_as_float(w.hit.tri)); put(w.hit.a); put(w.hit.b);
-    put(__int_as_float(w.hit.meshid)); put(w.t_max); put(w.stop_t); put(__uint_as_float(w.payload));
-    put(__int_as_float(w.node)); put(__int_as_float(w.objid)); put(__int_as_float(w.meshid));
-    put(__int_as_float(w.top_hit)); put(__int_as_float(w.top_miss));
-}
-ATN_DEV void unpark_walk(const ParkArea& a, uint32_t wave, uint32_t k, Walk& w)
-{
-    const float* p = a.pool + (size_t)wave * (kParkFields * 64u) + k;
-    float v[kParkFields];
-#pragma unroll
-    for (uint32_t f = 0; f < kParkFields; f++) v[f] = p[f * 64u];
-    slab_setup(w.wray, mk3(v[0], v[1], v[2]), mk3(v[3], v[4], v[5]));
-    slab_setup(w.ray, mk3(v[6], v[7], v[8]), mk3(v[9], v[10], v[11]));
-    w.hit.t = v[12]; w.hit.objid = __float_as_int(v[13]); w.hit.tri = __float_as_int(v[14]); w.hit.a = v[15]; w.hit.b = v[16];
-    w.hit.meshid = __float_as_int(v[17]); w.t_max = v[18]; w.stop_t = v[19]; w.payload = __float_as_uint(v[20]);
-    w.node = __float_as_int(v[21]); w.objid = __float_as_int(v[22]); w.meshid = __float_as_int(v[23]);
-    w.top_hit = __float_as_int(v[24]); w.top_miss = __float_as_int(v[25]);
-}
-// a drained wave parks whatever it still walks; returns after the stores are issued (the wave then leaves its loop)
-ATN_DEV void park_wave(const ParkArea& a, uint32_t wave_id, const Walk& w)
-{
-    const unsigned long long m_live = __ballot(w.node != kLinkEnd);
-    const uint32_t lane = __lane_id();
-    if (w.node != kLinkEnd) park_walk(a, wave_id, (uint32_t)__popcll(m_live & ((1ull << lane) - 1ull)), w);
-    if (lane == 0) a.counts[wave_id] = (uint32_t)__popcll(m_live);
-}
-
-template <bool COUNT, bool PARK, class Job>
+template <bool COUNT, class Job>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treelet, uint32_t count, uint32_t* fetch_counter,
-                          const Job& job, TravCounters* cnt, const ParkArea& park)
+                          const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
@@ -812,11 +764,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        if (PARK && drained && c_next >= c_count) {
-            // the queue is empty: what this wave still walks is finished by the continuation launch
-            park_wave(park, wave_id, w);
-            break;
-        }
         if (ATN_TAIL_MERGE && __builtin_expect(drained && can_donate && c_next >= c_count, 0)) {
             const unsigned long long m_live = __ballot(w.node != kLinkEnd);
             const uint32_t n_live = (uint32_t)__popcll(m_live);
@@ -831,71 +778,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
             }
         }
         walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
-    }
-}
-
-// The continuation launch's loop: trace_refill with the array of parked walks as its source.  A "chunk" is what ONE wave of
-// the producing launch parked (0 .. 64 walks); the first chunk of a wave is pre-assigned, the rest come off a shared cursor.
-// PARK: park again at the end of the source (all but the last round).
-template <bool PARK, class Job>
-ATN_DEV void trace_resume(const DevScene& sc, const ParkArea& src, uint32_t n_src, uint32_t* cursor, const Job& job, const ParkArea& dst)
-{
-    const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
-    const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
-    const uint32_t lane = __lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t c_src = 0, c_count = 0, c_next = 0;    // wave-uniform: source chunk, its size, next unassigned entry
-    bool drained = false, first_chunk = true, all_finite = true;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
-
-    Walk w;
-    slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
-    w.ray = w.wray;
-    w.node = kLinkEnd;
-    w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
-    w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
-    w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
-#if ATN_LEAF_STASH
-    w.stash = kLinkEnd; w.sq0 = make_float4(0, 0, 0, 0); w.sq1 = w.sq0;
-#endif
-
-    for (;;) {
-        const unsigned long long m_idle = __ballot(w.node == kLinkEnd);
-        const uint32_t n_idle = (uint32_t)__popcll(m_idle);
-        if (n_idle >= kRefillLanes) {
-            // (a chunk may be empty: keep asking until one has walks or the source ends)
-            while (c_next >= c_count && !drained) {
-                uint32_t c = 0;
-                if (first_chunk) { c = wave_id; first_chunk = false; }
-                else { if (lane == 0) c = atomicAdd(cursor, 1u) + n_waves; }
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if (c >= n_src) { drained = true; c_count = 0; c_next = 0; }
-                else {
-                    c_src = c; c_next = 0;
-                    c_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)src.counts[c]);
-                }
-            }
-            if (c_next < c_count) {
-                const uint32_t avail = c_count - c_next;
-                if (w.node == kLinkEnd) {
-                    const uint32_t k = (uint32_t)__popcll(m_idle & lt);
-                    if (k < avail) unpark_walk(src, c_src, c_next + k, w);
-                }
-                c_next += n_idle < avail ? n_idle : avail;
-                all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
-            }
-            else if (n_idle == 64u) {
-                if (PARK && lane == 0) dst.counts[wave_id] = 0u;
-                break;          // source used up, nothing in flight
-            }
-        }
-        if (PARK && drained && c_next >= c_count) {
-            park_wave(dst, wave_id, w);
-            break;
-        }
-        walk_iteration<false, false, kInnerBurst>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, &tc);
     }
 }
 

@@ -78,9 +78,6 @@ public:
 
     // scene (HBM-resident after UpdateSceneData)
     DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint, shade_tris;
-    DevBuf<uint4> cnodes;           // quantised twins of the inner records (scene_dev.hpp); static scenes only, see drop_cnodes
-    DevBuf<float4> cframes;
-    bool env_cnodes = true;         // ATEN_AMD_CNODES=0: exact records only
     DevBuf<atn_triangle_param> tris;
     DevBuf<atn_object_param> objects;
     DevBuf<DevMaterial> materials;
@@ -441,7 +438,6 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
-        if (const char* e = std::getenv("ATEN_AMD_CNODES")) env_cnodes = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -495,8 +491,6 @@ public:
         std::string err;
         if (!build_host_image(img, s, err)) return fail(ATN_ERR_UNSUPPORTED, err);
         ATN_HIP(nodes.upload(img.nodes, stream));
-        ATN_HIP(cnodes.upload(img.cnodes, stream));
-        ATN_HIP(cframes.upload(img.cframes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));
         ATN_HIP(vtx_nml.upload(img.vtx_nml, stream));
@@ -522,7 +516,6 @@ public:
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
         scene.toon = toon.p; scene.npr_lights = npr_lights.p; scene.screen_shadow = img.screen_shadow.empty() ? nullptr : screen_shadow.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
-        scene.cnodes = env_cnodes ? cnodes.p : nullptr; scene.cframes = cframes.p;
         has_scene = true;
         env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;
         {
@@ -650,7 +643,6 @@ public:
             if (n_objs > objects.n) ATN_HIP(objects.resize(n_objs));
             if (mv.size() > matrices.n) ATN_HIP(matrices.resize(mv.size()));
         }
-        scene.cnodes = nullptr;         // the quantised twins describe the uploaded tree (experiment: static scenes only)
         { int r = begin_scene_update(top_bytes + obj_bytes + mtx_bytes + 512); if (r) return r; }
         { int r = stage_copy(reinterpret_cast<char*>(nodes.p) + top_base, rec.data(), top_bytes); if (r) return r; log_range(SB_NODES, top_base, top_bytes); }
         { int r = stage_copy(objects.p, objs, obj_bytes); if (r) return r; log_range(SB_OBJECTS, 0, obj_bytes); }
@@ -804,7 +796,6 @@ public:
         if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
-        scene.cnodes = nullptr;         // the quantised twins describe the uploaded tree (experiment: static scenes only)
         { int r = begin_scene_update(0); if (r) return r; }
         // a caller may have written the scene arrays in place (atn_scene_device_arrays): refresh this mesh's shading records
         { int r = repack_shade_tris(tri_offset, n); if (r) return r; }

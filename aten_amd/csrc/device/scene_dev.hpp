@@ -8,7 +8,7 @@ namespace atn {
 
 // BVH records.  All node lists live in ONE byte image (DevScene::nodes); a link is the BYTE offset of the target
 // record (a multiple of 16) with the target's type in the low bits: kLinkLeafBit = triangle leaf, kLinkTlasBit = TLAS
-// leaf with a nested tree, 0 = inner node; kLinkEnd (both type bits set) = leave this list.  Links are explicit,
+// leaf with a nested tree, 0 = inner node; kLinkEnd (-1, both type bits set) = leave this list.  Links are explicit,
 // so the walk order -- and therefore every hit/miss decision -- is exactly the reference's
 // (threaded_bvh_traverser.h:98-304) whatever the storage order is; records are stored in walk (pre-)order for locality.
 //
@@ -24,7 +24,7 @@ namespace atn {
 //
 // The image starts with the TREELET: the inner records nearest the roots of the bottom-level trees (at most
 // kTreeletMaxBytes), which the persistent trace kernel copies into LDS; [0, treelet_bytes) is that address range.
-constexpr int32_t kLinkEnd = -13;          // 0xFFFFFFF3: both type bits set, bits 2-3 clear (a compressed inner record keeps its hit child's type there)
+constexpr int32_t kLinkEnd = -1;
 constexpr int32_t kLinkLeafBit = 1;
 constexpr int32_t kLinkTlasBit = 2;
 constexpr int32_t kLinkTypeMask = 3;
@@ -103,21 +103,6 @@ struct DevTexture {
     int32_t format;     // 0 = float4, 1 = RGBA8 decoded as k / 255.0f, 2 = RGBA8 decoded as k * (1.0f / 255)
 };
 
-// COMPRESSED INNER RECORDS (r03).  The trace kernels are bound by the per-CU L1 (TCP), which charges a 16-byte wave load
-// 16 clocks + ~0.5 per distinct 64-byte chunk WHATEVER the exec mask (profiles/r03_calibration.json), and an inner step
-// needs 32 bytes = two loads.  aabb::hit's decision must be the reference's bit for bit, so the boxes cannot simply be
-// stored with fewer bits -- but a 16-bit FILTER can decide almost every test: the record below holds the box quantised
-// to 16 bits per coordinate in its list's frame (x ~ b + q * s), the walk evaluates the slab test on it with per-ray
-// constants folded in (one fma per plane), and because every float operation involved is within a KNOWN distance of the
-// reference's (|t' - t| <= E, E from the quantum and the rounding bounds, traverse.hpp: cslab_setup) the quantised result
-// equals the exact one whenever |t1' - t0'| >= 2E.  Only the ambiguous lanes (~1 % of the steps) load the exact record.
-//   cnode (16 B, at the inner record's byte offset in `cnodes`):
-//     x = qmin.x | qmin.y << 16   y = qmin.z | qmax.x << 16   z = qmax.y | qmax.z << 16
-//     w = typed miss link | hit child's type << 2    (type 3 = irregular record: always take the exact one)
-//   the hit link is implicit: records are stored in walk (pre-)order, an inner record's hit child is the next record.
-constexpr uint32_t kCFrameQuads = 3;        // {b.xyz, 0} {s.xyz, 0} {h.xyz, 0}: h = 0.5 s + (|b| + 65535 s) 2^-21 (error budget per unit |1/dir|)
-constexpr uint32_t kCNodeIrregular = 3u;
-
 struct DevScene {
     const float4* nodes;                // byte image of the BVH records (see above)
     const atn_triangle_param* tris;     // 32 B each (ids / needNormal / mtrlid / mesh_id)
@@ -156,10 +141,6 @@ struct DevScene {
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
-    // 16-byte QUANTISED twins of the inner records (see "compressed inner records" above CNode): same byte offsets as in
-    // `nodes`; null = not available (after an in-place change of the tree) -> the walks use the exact records only
-    const uint4* cnodes;
-    const float4* cframes;              // kCFrameQuads float4 per BVH list: the list's quantisation frame
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

@@ -139,10 +139,6 @@ struct Walk {
     float t_max, stop_t;
     uint32_t payload;
     int32_t node, objid, meshid, top_hit, top_miss;
-    // compressed inner records (scene_dev.hpp): the slab test on a quantised box, folded with the frame of the list being
-    // walked: plane value t' = fma(q, csinv, cc); cthr = 2E (cslab_setup); only kept current when the kernel uses them
-    f3 csinv, cc;
-    float cthr;
 #if ATN_LEAF_STASH
     // first two quarters of the leaf / TLAS-leaf record the lane stands on, fetched by the burst's load instructions
     // (see inner_burst); `stash` = the typed link they belong to
@@ -242,71 +238,6 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treel
     }
 }
 
-// ---- compressed inner records (scene_dev.hpp "COMPRESSED INNER RECORDS") ------------------------------------------------
-// Per (ray, list) constants.  A stored coordinate q stands for x' = b + q s with |x' - x| <= s / 2 (checked at upload,
-// scene_upload.hpp: compress_list).  The reference evaluates, per plane, f = fl(fl(x * inv) + oxi); the walk evaluates
-// f' = fma(q, csinv, cc) with csinv = fl(s * inv), cc = fl(fl(b * inv) + oxi).  Distance between the two:
-//   quantisation  |x' - x| |inv|                                   <= 0.5 s |inv|
-//   rounding      ours: 2^-24 |inv| (3|b| + 3|org| + 2 * 65535 s); the reference's: 2^-24 |inv| (2|x| + |org|)
-//                 together                                         <= 5 * 2^-24 |inv| (|b| + 65535 s + |org|)  <  2^-21 |inv| (...)
-// so |f' - f| <= e_axis = |inv| (h + 2^-21 |org|) with h = 0.5 s + 2^-21 (|b| + 65535 s) from the frame.  min / max keep
-// bounds: |t0' - t0| <= E and |t1' - t1| <= E with E = max over the axes (t_min / t_max enter both sides exactly), hence
-// t1' - t0' >= 2E  =>  t0 <= t1  and  t1' - t0' <= -2E  =>  t0 > t1.  cthr = 2.2 E (10 % on top for the float evaluation of
-// E and of the difference); a non-finite or huge budget (|1/dir| ~ 1e30: the products may overflow) turns the filter off
-// for this ray: cthr = NaN compares false, every step reads the exact record.
-ATN_DEV void cslab_setup(Walk& w, const float4* __restrict__ fr)
-{
-    const float4 fb = fr[0], fs = fr[1], fh = fr[2];
-    const RaySlab& r = w.ray;
-    w.csinv = mk3(fs) * r.invdir;
-    w.cc = mk3(fb) * r.invdir + r.oxinvdir;
-    const float k = 4.76837158203125e-7F;       // 2^-21
-    const float ex = fabsf(r.invdir.x) * (fh.x + fabsf(r.org.x) * k);
-    const float ey = fabsf(r.invdir.y) * (fh.y + fabsf(r.org.y) * k);
-    const float ez = fabsf(r.invdir.z) * (fh.z + fabsf(r.org.z) * k);
-    const float e = smax(smax(ex, ey), ez);
-    const bool ok = (ex <= 1e30F) && (ey <= 1e30F) && (ez <= 1e30F);      // false for NaN too
-    w.cthr = ok ? 2.2F * e : __int_as_float(0x7fc00000);
-}
-
-// The burst of inner-node steps on the quantised records: ONE 16-byte load per step.  Only used while every live lane's
-// slab constants are finite (the caller's wave-uniform flag), so the exact test of the ambiguous lanes takes the
-// hardware min / max form.
-template <bool COUNT, int BURST>
-ATN_DEV void inner_burst_c(Walk& w, const char* __restrict__ nb, const char* __restrict__ cb, float t_min, TravCounters* cnt)
-{
-#pragma unroll 1
-    for (int k = 0; k < BURST; k++) {
-        if (!(w.node & kLinkTypeMask)) {
-            const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
-            const uint4 q = *reinterpret_cast<const uint4*>(cb + off);
-            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-            const float nx = __builtin_fmaf((float)(q.x & 0xffffu), w.csinv.x, w.cc.x);
-            const float ny = __builtin_fmaf((float)(q.x >> 16), w.csinv.y, w.cc.y);
-            const float nz = __builtin_fmaf((float)(q.y & 0xffffu), w.csinv.z, w.cc.z);
-            const float fx = __builtin_fmaf((float)(q.y >> 16), w.csinv.x, w.cc.x);
-            const float fy = __builtin_fmaf((float)(q.z & 0xffffu), w.csinv.y, w.cc.y);
-            const float fz = __builtin_fmaf((float)(q.z >> 16), w.csinv.z, w.cc.z);
-            const float t1 = hw_min3(hw_min(hw_max(fx, nx), hw_max(fy, ny)), hw_max(fz, nz), w.t_max);
-            const float t0 = hw_max3(hw_max(hw_min(fx, nx), hw_min(fy, ny)), hw_min(fz, nz), t_min);
-            const uint32_t ht = (q.w >> 2) & 3u;
-            bool box = t0 <= t1;
-            int32_t hit = (int32_t)(off + kInnerBytes + ht);
-            int32_t miss = (int32_t)(q.w & ~12u);
-            if (!(fabsf(t1 - t0) >= w.cthr) || ht == kCNodeIrregular) {
-#ifdef ATN_CNODE_STATS      /* experiment: the COUNT kernels' triangle counter counts ambiguous lane-steps (1) / wave-steps with any (2) */
-                if (COUNT) { if (ATN_CNODE_STATS == 1 || __lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt->tris += 1000u; }
-#endif
-                float4 q0, q1;
-                ld32(nb, off, q0, q1);
-                box = slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                hit = __float_as_int(q0.w); miss = __float_as_int(q1.w);
-            }
-            w.node = box ? hit : miss;
-        }
-    }
-}
-
 // One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
 // 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
 // leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.
@@ -320,8 +251,8 @@ ATN_DEV void inner_burst_c(Walk& w, const char* __restrict__ nb, const char* __r
 // -- otherwise.  TREELET: records below sc.treelet_bytes are read from the block's LDS copy (`treelet`).
 // A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
 template <bool COUNT, bool TREELET, int BURST, class Job>
-ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* __restrict__ cb,
-                            const char* treelet, uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
+ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* treelet,
+                            uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
 {
     // ---- burst of inner-node steps.  kLinkEnd has both type bits set, so `(node & 3) == 0` alone selects the live
     // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
@@ -330,10 +261,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     // the slab form is wave-uniform: chosen ONCE per burst, outside the step loop (inside it the choice costs ~8 scalar
     // instructions and two branches on every step)
 #if ATN_BURST_HOIST
-    if (all_finite) {
-        if (cb) inner_burst_c<COUNT, BURST>(w, nb, cb, t_min, cnt);
-        else inner_burst<COUNT, TREELET, BURST, true>(w, nb, treelet, treelet_bytes, t_min, cnt);
-    }
+    if (all_finite) inner_burst<COUNT, TREELET, BURST, true>(w, nb, treelet, treelet_bytes, t_min, cnt);
     else inner_burst<COUNT, TREELET, BURST, false>(w, nb, treelet, treelet_bytes, t_min, cnt);
 #else
 #pragma unroll 1
@@ -433,7 +361,6 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             else {
                 w.ray = w.wray;
             }
-            if (cb) cslab_setup(w, sc.cframes + kCFrameQuads * (uint32_t)__float_as_int(q0.w));
             is_hit = true;
             w.node = __float_as_int(q0.z);      // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
             ended = false;
@@ -451,7 +378,6 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
             if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start(w, sc, ra, rb, rstop);
         }
-        if (cb && w.node != kLinkEnd) cslab_setup(w, sc.cframes);       // back in (or restarted in) the top layer: list 0's frame
     }
     // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
     if (__any(ended || at_tlas) || !all_finite) all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
@@ -729,7 +655,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                           const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
-    const char* __restrict__ cb = reinterpret_cast<const char*>(sc.cnodes);     // null: exact records only
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
     const uint32_t treelet_bytes = sc.treelet_bytes;
     const uint32_t lane = __lane_id();
@@ -753,7 +678,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
     w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
     w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
     w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
-    w.csinv = mk3(0.0F); w.cc = mk3(0.0F); w.cthr = 0.0F;
 #if ATN_LEAF_STASH
     w.stash = kLinkEnd; w.sq0 = make_float4(0, 0, 0, 0); w.sq1 = w.sq0;
 #endif
@@ -797,10 +721,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 const uint32_t avail = c_count - c_next;
                 if (w.node == kLinkEnd) {
                     const uint32_t k = (uint32_t)__popcll(m_idle & lt);
-                    if (k < avail) {
-                        walk_start(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
-                        if (cb) cslab_setup(w, sc.cframes);
-                    }
+                    if (k < avail) walk_start(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
                 }
                 c_next += n_idle < avail ? n_idle : avail;
                 all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
@@ -856,7 +777,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 can_donate = false;
             }
         }
-        walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, cb, treelet, treelet_bytes, t_min, job, cnt);
+        walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
     }
 }
 

@@ -1,7 +1,6 @@
 // Host-side conversion of the caller's flat scene (include/aten_layout.h) into the device layout
 // of device/scene_dev.hpp.  Pure host C++ (no HIP calls) so that it can be unit-tested on CPU.
 #pragma once
-#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -13,8 +12,6 @@ namespace atn {
 
 struct HostSceneImage {
     std::vector<float4> nodes;          // the byte image of all records (16-byte units)
-    std::vector<uint4> cnodes;          // quantised twins of the inner records, same offsets (scene_dev.hpp: CNode)
-    std::vector<float4> cframes;        // kCFrameQuads per list
     uint64_t n_nodes = 0;
     std::vector<uint32_t> list_root;    // byte offset of each list's first non-treelet record
     std::vector<int32_t> list_root_link; // typed link of each list's root
@@ -164,7 +161,7 @@ inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, c
                 if ((uint32_t)obj.mtx_id + 1 >= c.n_matrices) { err = "object matrix index out of range"; return false; }
                 w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
             }
-            q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), i2f(exid));      // .w: the nested list = its quantisation frame (cframes)
+            q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), 0.0F);
             q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), 0.0F);
             counts[2]++;
             break;
@@ -190,72 +187,6 @@ inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, c
         }
     }
     return true;
-}
-
-// Quantised twins of one emitted list's inner records (scene_dev.hpp "compressed inner records"): reads the exact records
-// back from `img`, writes the 16-byte twins at the same offsets of `cimg` and the list's frame into frame[0..2].
-// Everything the device relies on is CHECKED here in double precision -- |b + q s - x| <= s / 2 for every stored
-// coordinate -- and a record that fails (non-finite box, dead leaf, hit child not the next record) is marked irregular:
-// the walk then reads its exact record.
-inline void compress_list(const ListLayout& L, const char* img, uint4* cimg, float4 frame[kCFrameQuads], uint32_t write_bias = 0)
-{
-    const uint32_t n = (uint32_t)L.order.size();
-    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
-    auto rec = [&](uint32_t j) { return reinterpret_cast<const float4*>(img + (L.offset[j] - write_bias)); };
-    auto finite_box = [&](const float4* q) {
-        const float v[6] = { q[0].x, q[0].y, q[0].z, q[1].x, q[1].y, q[1].z };
-        for (float f : v) if (!(std::fabs(f) <= 3.0e38F)) return false;
-        return true;
-    };
-    for (uint32_t j = 0; j < n; j++) {
-        if (L.kind[j] != KIND_INNER) continue;
-        const float4* q = rec(j);
-        if (!finite_box(q)) continue;
-        const float mn[3] = { q[0].x, q[0].y, q[0].z }, mx[3] = { q[1].x, q[1].y, q[1].z };
-        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)std::min(mn[a], mx[a])); hi[a] = std::max(hi[a], (double)std::max(mn[a], mx[a])); }
-    }
-    float b[3], s[3], h[3];
-    for (int a = 0; a < 3; a++) {
-        if (!(lo[a] <= hi[a])) { lo[a] = 0; hi[a] = 0; }
-        b[a] = (float)lo[a];
-        if ((double)b[a] > lo[a]) b[a] = std::nextafter(b[a], -3.0e38F);
-        double step = (hi[a] - (double)b[a]) / 65535.0 * (1.0 + 1e-6);
-        const double floor_step = std::max(std::fabs((double)b[a]), std::fabs(hi[a])) * 1e-7 + 1e-30;   // flat axis: any positive step
-        if (step < floor_step) step = floor_step;
-        s[a] = (float)step;
-        if ((double)s[a] < step) s[a] = std::nextafter(s[a], 3.0e38F);
-        const double hh = 0.5 * (double)s[a] + (std::fabs((double)b[a]) + 65535.0 * (double)s[a]) * (1.0 / 2097152.0);
-        h[a] = (float)hh;
-        if ((double)h[a] < hh) h[a] = std::nextafter(h[a], 3.0e38F);
-    }
-    frame[0] = make_float4(b[0], b[1], b[2], 0.0F);
-    frame[1] = make_float4(s[0], s[1], s[2], 0.0F);
-    frame[2] = make_float4(h[0], h[1], h[2], 0.0F);
-    for (uint32_t j = 0; j < n; j++) {
-        if (L.kind[j] != KIND_INNER && L.kind[j] != KIND_DEAD) continue;
-        const float4* q = rec(j);
-        const uint32_t hit = f2u(q[0].w), miss = f2u(q[1].w);
-        uint32_t ht = kCNodeIrregular;
-        uint32_t qc[6] = { 0, 0, 0, 0, 0, 0 };
-        // regular: an inner record with a finite box whose hit child is the record right behind it
-        if (L.kind[j] == KIND_INNER && finite_box(q) && (hit & ~3u) == L.offset[j] + kInnerBytes && (hit & 3u) != 3u) {
-            const float v[6] = { q[0].x, q[0].y, q[0].z, q[1].x, q[1].y, q[1].z };
-            bool ok = true;
-            for (int i = 0; i < 6 && ok; i++) {
-                const int a = i % 3;
-                const double t = ((double)v[i] - (double)b[a]) / (double)s[a];
-                const double r = std::floor(t + 0.5);
-                if (!(r >= 0.0 && r <= 65535.0)) { ok = false; break; }
-                qc[i] = (uint32_t)r;
-                ok = std::fabs((double)b[a] + r * (double)s[a] - (double)v[i]) <= 0.5 * (double)s[a] * (1.0 + 1e-9);
-            }
-            if (ok) ht = hit & 3u;
-        }
-        uint4 c;
-        c.x = qc[0] | (qc[1] << 16); c.y = qc[2] | (qc[3] << 16); c.z = qc[4] | (qc[5] << 16);
-        c.w = miss | (ht << 2);
-        cimg[(L.offset[j] - write_bias) / 16] = c;
-    }
 }
 
 // Range checks of every id the kernels index with (a bad id is a device out-of-bounds read, not an error code).
@@ -362,13 +293,6 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         img.list_root_link[k] = root;
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
-    {
-        uint4 z; z.x = z.y = z.z = z.w = 0;
-        img.cnodes.assign(img.nodes.size(), z);
-        img.cframes.assign((size_t)nl * kCFrameQuads, make_float4(0, 0, 0, 0));
-        for (uint32_t k = 0; k < nl; k++)
-            compress_list(lay[k], reinterpret_cast<const char*>(img.nodes.data()), img.cnodes.data(), &img.cframes[(size_t)k * kCFrameQuads]);
-    }
     img.params.treelet_bytes = (uint32_t)treelet_bytes;
 
     // ---- plain copies

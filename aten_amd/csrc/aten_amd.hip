@@ -71,6 +71,7 @@ public:
     int n_batches = 3;
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
+    bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
     int env_shade_items = 0, env_flavour = -1, env_first_simple = 1;
@@ -438,6 +439,7 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -650,6 +652,7 @@ public:
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
         scene.root_link = root;
+        scene.node_bytes = (uint32_t)(top_base + top_bytes);
         point_scene_at_current_set();
         tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;
         if (!flavour_forced) use_refill = tree_is_deep;
@@ -1089,9 +1092,17 @@ public:
                         // (timed under "trace_closest" when it is a different kernel from the other launches: the roofline of
                         // k_trace_fused<true, .> is about those)
                         prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
-                        const dim3 gr(refill_now ? g_fused : g_fused * (256u / simple_block)), tb(refill_now ? (uint32_t)kTraceBlock : simple_block);
-                        const uint32_t lds = (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
-                        if (refill_now) {
+                        // a node image of a few KB is walked from an LDS copy (trace_simple<., ., true>); above 8 KB per copy the blocks get
+                        // four waves to share it
+                        const bool lds_nodes = !refill_now && env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
+                        const uint32_t sb = (lds_nodes && scene.node_bytes > 8192u) ? 256u : simple_block;
+                        const dim3 gr(refill_now ? g_fused : g_fused * (256u / sb)), tb(refill_now ? (uint32_t)kTraceBlock : sb);
+                        const uint32_t lds = lds_nodes ? scene.node_bytes : (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
+                        if (lds_nodes) {
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<false, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                        }
+                        else if (refill_now) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }

@@ -264,14 +264,13 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
 // REFILL selects the persistent, lane-refilling walk (large trees) or the plain walk (small trees and small launches,
 // where the refill bookkeeping costs more than the idle lanes it removes).  The persistent kernels keep the treelet
 // -- the first sc.treelet_bytes of the node image -- in dynamic LDS (the launch passes that many bytes).
-extern __shared__ float4 atn_dyn_lds[];
 #ifdef ATN_TRACE_WPE
 #define ATN_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(ATN_TRACE_WPE, ATN_TRACE_WPE)))
 #else
 #define ATN_TRACE_ATTR
 #endif
 
-template <bool COUNT, bool REFILL, class Job>
+template <bool COUNT, bool REFILL, class Job, bool LDSN = false>
 ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_counter, const Job& job, TravCounters* tc)
 {
     if constexpr (REFILL) {
@@ -285,7 +284,7 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
         trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {
-        trace_simple<COUNT>(sc, count, job, tc);
+        trace_simple<COUNT, Job, LDSN>(sc, count, job, tc);
     }
 }
 
@@ -851,14 +850,16 @@ struct FusedJob {
     }
 };
 
-template <bool REFILL, bool ALPHA>
+// LDSN: the plain walk over an LDS copy of the whole node image (small scenes, trace_simple)
+template <bool REFILL, bool ALPHA, bool LDSN = false>
 __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
+    static_assert(!(REFILL && LDSN), "the LDS copy of the node image belongs to the plain walk");
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
-    trace_dispatch<false, REFILL>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
+    trace_dispatch<false, REFILL, FusedJob<ALPHA>, LDSN>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }
 
 // Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,

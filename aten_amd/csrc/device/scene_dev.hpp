@@ -44,6 +44,9 @@ constexpr int kMsToon = 4;        // + Toon / StylizedBrdf (inline visibility wa
 #define ATN_TREELET_BYTES 0      /* measured on MI355X: the LDS copy loses to the L1; > 0 re-enables it */
 #endif
 constexpr uint32_t kTreeletMaxBytes = ATN_TREELET_BYTES;
+// A node image of at most this many bytes (Cornell box: 71 nodes = 2.9 KB; instanced props) is copied into LDS by every
+// block of the plain walk and ALL its records are read from there (one source: none of the treelet's per-lane selection).
+constexpr uint32_t kLdsNodesMaxBytes = 32u * 1024u;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
 constexpr uint32_t kAttrIdealRefraction = 0x10000u;   // MaterialParameter::isIdealRefraction, folded into attrib at upload
@@ -141,6 +144,7 @@ struct DevScene {
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
+    uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

@@ -93,6 +93,17 @@ ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
     return *reinterpret_cast<const float4*>(base + byte_off);
 }
 
+// The block's dynamic LDS: the treelet of the persistent kernels, or the WHOLE node image of a small scene (LDSN).
+extern __shared__ float4 atn_dyn_lds[];
+// a 16-byte quarter of a node record: from global memory, or -- LDSN -- from the block's LDS copy of the node image
+// (indexing the __shared__ array keeps the access in the LDS address space: ds_read_b128, not a flat load)
+template <bool LDSN>
+ATN_DEV float4 ldn(const char* base, uint32_t byte_off)
+{
+    if constexpr (LDSN) return atn_dyn_lds[byte_off >> 4];
+    else return ld16(base, byte_off);
+}
+
 // One Moeller-Trumbore test against a triangle-leaf record (q0, q1, q2) -- intersectTriangle (math/intersect.h:45-90) +
 // triangle::hit (geometry/triangle.h:40-67) + the traverser's acceptance (threaded_bvh_traverser.h:236-262).
 // Returns triangle::hit's result; `accept` = the hit became the ray's closest one.
@@ -446,10 +457,19 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
 // walk, and making lanes wait at leaves for the end of a burst (walk_iteration) only lengthens it: measured on MI355X
 // with the burst form, Cornell 1080p 1.85 -> 2.08 ms per frame and sponza_lod forced onto this flavour 6.24 -> 7.17 ms.
 // Used for small trees and small launches, where the refill bookkeeping costs more than the idle lanes it removes.
-template <bool COUNT, class Job>
+// LDSN (scenes whose node image is at most kLdsNodesMaxBytes: the Cornell box is 2.9 KB): every block first copies the image
+// into its dynamic LDS and the walk reads ALL records from there -- one source, so none of the per-lane selection that
+// sank the LDS treelet of the deep trees; a walk step waits for the LDS (~100 clocks) instead of the
+// L1 behind a queue of other waves' gathers, and the plain walk is latency-bound by construction.
+template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
+    if constexpr (LDSN) {
+        const uint32_t n16 = sc.node_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
+        __syncthreads();
+    }
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
@@ -462,8 +482,8 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
         // (the loop of walk_run, spelled out: as a call the compiler lays the kernel out 4 % slower on Cornell 1080p)
         while (w.node != kLinkEnd) {
             const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
-            const float4 q0 = ld16(nb, off);
-            const float4 q1 = ld16(nb, off + 16u);
+            const float4 q0 = ldn<LDSN>(nb, off);
+            const float4 q1 = ldn<LDSN>(nb, off + 16u);
             if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             bool is_hit;
             if (!(w.node & kLinkTypeMask)) {
@@ -475,7 +495,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                 is_hit = false;
             }
             else if (w.node & kLinkLeafBit) {
-                const float4 q2 = ld16(nb, off + 32u);
+                const float4 q2 = ldn<LDSN>(nb, off + 32u);
                 if (COUNT) { cnt->tris++; cnt->ray_tris++; }
                 bool accept; float t;
                 is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);

@@ -294,6 +294,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
     img.params.treelet_bytes = (uint32_t)treelet_bytes;
+    img.params.node_bytes = (uint32_t)off;
 
     // ---- plain copies
     img.tris.assign(s->triangles, s->triangles + s->n_triangles);

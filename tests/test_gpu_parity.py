@@ -687,3 +687,41 @@ def test_headline_config_full_size_vs_oracle(gpu, orc, sponza):
         frac, mean_err = frame_tolerance_report(got, want)
         assert frac >= 0.998, (frame, frac)
         assert mean_err <= 2e-3, (frame, mean_err)
+
+
+# ---- small node images are walked from an LDS copy (trace_simple<., ., true>): same records, same arithmetic ---------
+@pytest.mark.parametrize("which", ["cornell", "room_with_small_mesh"])
+def test_node_image_in_lds_equals_global_memory_walk(orc, cornell, which):
+    """Node images up to kLdsNodesMaxBytes (32 KB) are copied into LDS by every block of the plain walk (one wave per
+    block below 8 KB, four above).  The walk is the same code on another address space: films byte-equal to the
+    global-memory walk (ATEN_AMD_LDS_NODES=0), and inside the stated tolerance of the oracle."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    w, h = 160, 120
+    if which == "cornell":
+        fs, cam = cornell
+    else:
+        b, _, cam = scenedefs.deformable_room(0.7, nu=12, nv=8)       # + 192 triangles: ~18 KB of records
+        fs = b.build()
+    n_nodes = sum(len(l) for l in fs.arrays["bvh_lists"])      # a record is 32 or 48 bytes
+    if which == "cornell": assert n_nodes * 48 <= 8192          # one wave per block
+    else: assert n_nodes * 32 > 8192 and n_nodes * 48 <= 32768  # four waves share the copy
+    c = make_camera(orc, cam, w, h)
+    films = {}
+    old = os.environ.get("ATEN_AMD_LDS_NODES")
+    try:
+        for mode in ("0", "1"):
+            os.environ["ATEN_AMD_LDS_NODES"] = mode
+            r = PathTracing(0)
+            try:
+                r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+                films[mode] = r.render(w, h, frame=0).copy()
+            finally:
+                r.close()
+    finally:
+        if old is None: os.environ.pop("ATEN_AMD_LDS_NODES", None)
+        else: os.environ["ATEN_AMD_LDS_NODES"] = old
+    assert films["0"].tobytes() == films["1"].tobytes()
+    seeds = orc.init_sampler(w, h, 0)
+    inside, mean_err = frame_tolerance_report(films["1"], orc.render(fs, c, seeds, w, h, frame=0))
+    assert inside >= 0.995 and mean_err <= 2e-3

@@ -1038,7 +1038,9 @@ public:
             // the refill walk wants the machine to itself; the plain walk gains from a second batch down to ~0.8 M paths
             // (with frames in flight the next frame fills the gaps a second batch was for: measured r02_e on Cornell, 3 in
             // flight, 1.04 M paths: 1 batch 0.82 ms, 2 batches 0.96; 2.07 M paths: 1.66 vs 1.63)
-            nb = use_refill ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
+            // (r03, node image in LDS, 3 in flight, Cornell 2.07 M paths: 1 batch 1.52 ms, 2 batches 1.58 -- one batch whenever frames overlap)
+            const bool lds_nodes = env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
+            nb = use_refill ? 1 : (lds_nodes && frames_in_flight > 1) ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
             if (nb > n_batches) nb = n_batches;
         }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
@@ -1094,11 +1096,15 @@ public:
                         prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
                         // a node image of a few KB is walked from an LDS copy (trace_simple<., ., true>); above 8 KB per copy the blocks get
                         // four waves to share it
-                        const bool lds_nodes = !refill_now && env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
+                        const bool lds_nodes = env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
                         const uint32_t sb = (lds_nodes && scene.node_bytes > 8192u) ? 256u : simple_block;
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / sb)), tb(refill_now ? (uint32_t)kTraceBlock : sb);
                         const uint32_t lds = lds_nodes ? scene.node_bytes : (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
-                        if (lds_nodes) {
+                        if (lds_nodes && refill_now) {
+                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                            else hipLaunchKernelGGL((k_trace_fused<true, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
+                        }
+                        else if (lds_nodes) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<false, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }

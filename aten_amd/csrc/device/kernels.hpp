@@ -275,13 +275,18 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
 {
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
-        if (ATN_TREELET_LDS) {
+        if (LDSN) {         // the whole node image (small scenes)
+            const uint32_t n16 = sc.node_bytes >> 4;
+            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
+            __syncthreads();
+        }
+        else if (ATN_TREELET_LDS) {
             const uint32_t n16 = sc.treelet_bytes / 16u;
             for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
             __syncthreads();
         }
         trace_shared_init(sh);
-        trace_refill<COUNT>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
+        trace_refill<COUNT, Job, LDSN>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
     }
     else {
         trace_simple<COUNT, Job, LDSN>(sc, count, job, tc);
@@ -850,11 +855,10 @@ struct FusedJob {
     }
 };
 
-// LDSN: the plain walk over an LDS copy of the whole node image (small scenes, trace_simple)
+// LDSN: the walk over an LDS copy of the whole node image (small scenes)
 template <bool REFILL, bool ALPHA, bool LDSN = false>
 __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
-    static_assert(!(REFILL && LDSN), "the LDS copy of the node image belongs to the plain walk");
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };

@@ -195,7 +195,7 @@ ATN_DEV void ld32(const char* base, uint32_t byte_off, float4& a, float4& b)
 
 // A burst of inner-node steps with ONE form of the slab test (FAST: hardware min/max, valid when every live lane's slab
 // constants are finite; else the select form, valid for all inputs).  See walk_iteration.
-template <bool COUNT, bool TREELET, int BURST, bool FAST>
+template <bool COUNT, bool TREELET, int BURST, bool FAST, bool LDSN = false>
 ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treelet, uint32_t treelet_bytes, float t_min, TravCounters* cnt)
 {
 #pragma unroll 1
@@ -237,6 +237,9 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treel
                 q0 = make_float4(in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w);
                 q1 = make_float4(in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w);
             }
+            else if (LDSN) {
+                q0 = ldn<true>(nb, off); q1 = ldn<true>(nb, off + 16u);
+            }
             else {
                 ld32(nb, off, q0, q1);
             }
@@ -261,7 +264,7 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treel
 // are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form -- valid for all inputs
 // -- otherwise.  TREELET: records below sc.treelet_bytes are read from the block's LDS copy (`treelet`).
 // A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
-template <bool COUNT, bool TREELET, int BURST, class Job>
+template <bool COUNT, bool TREELET, int BURST, class Job, bool LDSN = false>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* treelet,
                             uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
 {
@@ -272,8 +275,8 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     // the slab form is wave-uniform: chosen ONCE per burst, outside the step loop (inside it the choice costs ~8 scalar
     // instructions and two branches on every step)
 #if ATN_BURST_HOIST
-    if (all_finite) inner_burst<COUNT, TREELET, BURST, true>(w, nb, treelet, treelet_bytes, t_min, cnt);
-    else inner_burst<COUNT, TREELET, BURST, false>(w, nb, treelet, treelet_bytes, t_min, cnt);
+    if (all_finite) inner_burst<COUNT, TREELET, BURST, true, LDSN>(w, nb, treelet, treelet_bytes, t_min, cnt);
+    else inner_burst<COUNT, TREELET, BURST, false, LDSN>(w, nb, treelet, treelet_bytes, t_min, cnt);
 #else
 #pragma unroll 1
     for (int k = 0; k < BURST; k++) {
@@ -341,12 +344,12 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
     if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
-        const float4 q0 = ld16(nb, off);
-        const float4 q1 = ld16(nb, off + 16u);
+        const float4 q0 = ldn<LDSN>(nb, off);
+        const float4 q1 = ldn<LDSN>(nb, off + 16u);
 #endif
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         if (w.node & kLinkLeafBit) {
-            const float4 q2 = ld16(nb, off + 32u);
+            const float4 q2 = ldn<LDSN>(nb, off + 32u);
             if (COUNT) { cnt->tris++; cnt->ray_tris++; }
             bool accept; float t;
             is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
@@ -670,7 +673,7 @@ ATN_DEV void tail_unpark(const float* pool, uint32_t k, Walk& w, TravCounters* c
     w.wray.finite = fin_w != 0.0F; w.ray.finite = fin_r != 0.0F;
 }
 
-template <bool COUNT, class Job>
+template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treelet, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)
 {
@@ -797,7 +800,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 can_donate = false;
             }
         }
-        walk_iteration<COUNT, (kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
+        walk_iteration<COUNT, (!LDSN && kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
     }
 }
 

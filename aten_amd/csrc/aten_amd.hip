@@ -518,6 +518,7 @@ public:
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
         scene.toon = toon.p; scene.npr_lights = npr_lights.p; scene.screen_shadow = img.screen_shadow.empty() ? nullptr : screen_shadow.p;
         scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
+        scene.mtx_quads = (uint32_t)img.matrices.size();
         has_scene = true;
         env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;
         {
@@ -653,6 +654,7 @@ public:
         list_root_link[0] = root;
         scene.root_link = root;
         scene.node_bytes = (uint32_t)(top_base + top_bytes);
+        if (n_mtxs) scene.mtx_quads = (uint32_t)mv.size();
         point_scene_at_current_set();
         tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;
         if (!flavour_forced) use_refill = tree_is_deep;
@@ -944,6 +946,13 @@ public:
     // 1.9 M paths is gone, deep trees take the refill walk at every size that fills the machine at all
     static constexpr uint32_t kRefillMinPaths = 128u * 1000u;
 
+    // bytes of the LDS copy a small scene is walked from (node image + matrix rows), 0 = the scene is walked from global memory
+    uint32_t lds_scene_bytes() const
+    {
+        const uint64_t b = (uint64_t)scene.node_bytes + (uint64_t)scene.mtx_quads * 16u;
+        return (env_lds_nodes && b <= kLdsNodesMaxBytes) ? (uint32_t)b : 0u;
+    }
+
     uint32_t trace_grid(uint32_t n_jobs) const
     {
         if (use_refill) {
@@ -1039,7 +1048,7 @@ public:
             // (with frames in flight the next frame fills the gaps a second batch was for: measured r02_e on Cornell, 3 in
             // flight, 1.04 M paths: 1 batch 0.82 ms, 2 batches 0.96; 2.07 M paths: 1.66 vs 1.63)
             // (r03, node image in LDS, 3 in flight, Cornell 2.07 M paths: 1 batch 1.52 ms, 2 batches 1.58 -- one batch whenever frames overlap)
-            const bool lds_nodes = env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
+            const bool lds_nodes = lds_scene_bytes() != 0u;
             nb = use_refill ? 1 : (lds_nodes && frames_in_flight > 1) ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
             if (nb > n_batches) nb = n_batches;
         }
@@ -1096,10 +1105,10 @@ public:
                         prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
                         // a node image of a few KB is walked from an LDS copy (trace_simple<., ., true>); above 8 KB per copy the blocks get
                         // four waves to share it
-                        const bool lds_nodes = env_lds_nodes && scene.node_bytes <= kLdsNodesMaxBytes;
-                        const uint32_t sb = (lds_nodes && scene.node_bytes > 8192u) ? 256u : simple_block;
+                        const bool lds_nodes = lds_scene_bytes() != 0u;
+                        const uint32_t sb = (lds_nodes && lds_scene_bytes() > 8192u) ? 256u : simple_block;
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / sb)), tb(refill_now ? (uint32_t)kTraceBlock : sb);
-                        const uint32_t lds = lds_nodes ? scene.node_bytes : (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
+                        const uint32_t lds = lds_nodes ? lds_scene_bytes() : (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
                         if (lds_nodes && refill_now) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<true, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);

@@ -275,11 +275,7 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
 {
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
-        if (LDSN) {         // the whole node image (small scenes)
-            const uint32_t n16 = sc.node_bytes >> 4;
-            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
-            __syncthreads();
-        }
+        if (LDSN) lds_scene_copy(sc);       // the whole node image + the matrices (small scenes)
         else if (ATN_TREELET_LDS) {
             const uint32_t n16 = sc.treelet_bytes / 16u;
             for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];

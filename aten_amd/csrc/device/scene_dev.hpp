@@ -145,6 +145,7 @@ struct DevScene {
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
     uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
+    uint32_t mtx_quads;                 // float4 rows in `matrices` (the LDS copy holds them behind the node image)
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

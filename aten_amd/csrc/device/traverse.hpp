@@ -104,6 +104,21 @@ ATN_DEV float4 ldn(const char* base, uint32_t byte_off)
     else return ld16(base, byte_off);
 }
 
+// the block's LDS copy of a small scene's walk data: the node image, then the matrix rows (LDSN)
+ATN_DEV void lds_scene_copy(const DevScene& sc)
+{
+    const uint32_t n16 = sc.node_bytes >> 4;
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.mtx_quads; i += blockDim.x) atn_dyn_lds[n16 + i] = sc.matrices[i];
+    __syncthreads();
+}
+template <bool LDSN>
+ATN_DEV float4 ldm(const DevScene& sc, int32_t row)
+{
+    if constexpr (LDSN) return atn_dyn_lds[(sc.node_bytes >> 4) + (uint32_t)row];
+    else return sc.matrices[row];
+}
+
 // One Moeller-Trumbore test against a triangle-leaf record (q0, q1, q2) -- intersectTriangle (math/intersect.h:45-90) +
 // triangle::hit (geometry/triangle.h:40-67) + the traverser's acceptance (threaded_bvh_traverser.h:236-262).
 // Returns triangle::hit's result; `accept` = the hit became the ray's closest one.
@@ -182,6 +197,10 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
 constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
 
 
+#ifndef ATN_SIMPLE_BURST_LDS
+#define ATN_SIMPLE_BURST_LDS 2  /* the plain walk over an LDS copy of the scene steps in bursts of this many inner-node steps (0 = every kind every step) */
+#endif
+constexpr int kSimpleBurstLds = ATN_SIMPLE_BURST_LDS;
 #ifndef ATN_BURST_HOIST
 #define ATN_BURST_HOIST 1
 #endif
@@ -366,8 +385,8 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             if (w2l >= 0) {
                 // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
                 m4 m;
-                m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
-                m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                m.r0 = ldm<LDSN>(sc, w2l + 0); m.r1 = ldm<LDSN>(sc, w2l + 1);
+                m.r2 = ldm<LDSN>(sc, w2l + 2); m.r3 = ldm<LDSN>(sc, w2l + 3);
                 const f3 o = m4_apply(m, w.wray.org);
                 const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
                 slab_setup(w.ray, o, d);
@@ -468,11 +487,7 @@ template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
-    if constexpr (LDSN) {
-        const uint32_t n16 = sc.node_bytes >> 4;
-        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
-        __syncthreads();
-    }
+    if constexpr (LDSN) lds_scene_copy(sc);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
@@ -480,6 +495,19 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
         float4 a, b;
         float stop_t;
         job.fetch(j, a, b, stop_t);
+        if constexpr (LDSN && kSimpleBurstLds > 0) {
+            // Over an LDS copy a step waits ~100 clocks, not for the L1 behind other waves' gathers, so what the plain walk pays
+            // for is issue: every iteration of the loop below offers every node kind, and the ~75-instruction triangle block
+            // and the ~110-instruction TLAS-leaf block (two matrix products, normalize, three IEEE divides) run each time
+            // for a handful of lanes.  The burst form of the step (walk_iteration: kSimpleBurstLds inner-node steps, then ONE
+            // step for the lanes on a leaf) issues them once per burst: Cornell 1080p trace 1.11 -> 1.00 ms per frame.
+            // (From global memory the same form LOSES -- 1.85 -> 2.08 ms, r02 -- there the waiting lanes cost more.)
+            walk_start(w, sc, a, b, stop_t);
+            bool all_finite = __all(w.ray.finite) != 0;
+            while (__any(w.node != kLinkEnd))
+                walk_iteration<COUNT, false, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
+            continue;
+        }
       restart:
         walk_start(w, sc, a, b, stop_t);
         // (the loop of walk_run, spelled out: as a call the compiler lays the kernel out 4 % slower on Cornell 1080p)
@@ -515,8 +543,8 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                 if (w2l >= 0) {
                     // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
                     m4 m;
-                    m.r0 = sc.matrices[w2l + 0]; m.r1 = sc.matrices[w2l + 1];
-                    m.r2 = sc.matrices[w2l + 2]; m.r3 = sc.matrices[w2l + 3];
+                    m.r0 = ldm<LDSN>(sc, w2l + 0); m.r1 = ldm<LDSN>(sc, w2l + 1);
+                    m.r2 = ldm<LDSN>(sc, w2l + 2); m.r3 = ldm<LDSN>(sc, w2l + 3);
                     const f3 o = m4_apply(m, w.wray.org);
                     const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
                     slab_setup(w.ray, o, d);

@@ -201,6 +201,13 @@ constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
 #define ATN_SIMPLE_BURST_LDS 2  /* the plain walk over an LDS copy of the scene steps in bursts of this many inner-node steps (0 = every kind every step) */
 #endif
 constexpr int kSimpleBurstLds = ATN_SIMPLE_BURST_LDS;
+#ifndef ATN_SIMPLE_BURST_GLOBAL
+#define ATN_SIMPLE_BURST_GLOBAL 0
+#endif
+constexpr int kSimpleBurstGlobal = ATN_SIMPLE_BURST_GLOBAL;
+#ifndef ATN_TREELET_PHASES
+#define ATN_TREELET_PHASES 0    /* > 0 (with ATN_TREELET_BYTES > 0): phased treelet walk, see inner_burst */
+#endif
 #ifndef ATN_BURST_HOIST
 #define ATN_BURST_HOIST 1
 #endif
@@ -241,6 +248,34 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treel
             }
         }
 #else
+#if ATN_TREELET_PHASES
+        if (TREELET) {
+            // PHASED treelet walk: the lanes whose inner node lies in the treelet (the block's LDS copy of the records nearest
+            // the roots) take up to ATN_TREELET_PHASES steps from LDS -- no L1 involved -- then the lanes on inner nodes
+            // outside take ONE step from global memory.  Two plain blocks, one source each: none of the per-lane selection
+            // between sources that made the earlier treelet forms issue BOTH loads on every step.
+#pragma unroll 1
+            for (int m = 0; m < ATN_TREELET_PHASES; m++) {
+                if (!(w.node & kLinkTypeMask) && (uint32_t)w.node < treelet_bytes) {
+                    const uint32_t i16 = (uint32_t)w.node >> 4;
+                    const float4 q0 = atn_dyn_lds[i16], q1 = atn_dyn_lds[i16 + 1u];
+                    if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+                    const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                          : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+                    w.node = __float_as_int(box ? q0.w : q1.w);
+                }
+            }
+            if (!(w.node & kLinkTypeMask) && (uint32_t)w.node >= treelet_bytes) {
+                float4 q0, q1;
+                ld32(nb, (uint32_t)w.node, q0, q1);
+                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+                w.node = __float_as_int(box ? q0.w : q1.w);
+            }
+            continue;
+        }
+#endif
         if (!(w.node & kLinkTypeMask)) {
             const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
             float4 q0, q1;
@@ -495,7 +530,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
         float4 a, b;
         float stop_t;
         job.fetch(j, a, b, stop_t);
-        if constexpr (LDSN && kSimpleBurstLds > 0) {
+        if constexpr ((LDSN && kSimpleBurstLds > 0) || (!LDSN && kSimpleBurstGlobal > 0)) {
             // Over an LDS copy a step waits ~100 clocks, not for the L1 behind other waves' gathers, so what the plain walk pays
             // for is issue: every iteration of the loop below offers every node kind, and the ~75-instruction triangle block
             // and the ~110-instruction TLAS-leaf block (two matrix products, normalize, three IEEE divides) run each time
@@ -505,7 +540,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             walk_start(w, sc, a, b, stop_t);
             bool all_finite = __all(w.ray.finite) != 0;
             while (__any(w.node != kLinkEnd))
-                walk_iteration<COUNT, false, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
+                walk_iteration<COUNT, false, (LDSN ? kSimpleBurstLds : kSimpleBurstGlobal), Job, LDSN>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
             continue;
         }
       restart:

@@ -16,7 +16,7 @@ K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sam
 SYMBOLS = [
     "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera", "atn_update_tlas",
     "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset", "atn_set_path_batches",
-    "atn_set_frames_in_flight", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
+    "atn_set_frames_in_flight", "atn_bank_streams", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
     "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
     "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
@@ -72,6 +72,7 @@ def lib():
         l.atn_reset.argtypes = [vp]
         l.atn_set_path_batches.argtypes = [vp, C.c_int32]
         l.atn_set_frames_in_flight.argtypes = [vp, C.c_int32]
+        l.atn_bank_streams.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.atn_set_sampling_options.argtypes = [vp, C.c_int32, C.c_int32]
         l.atn_sample_texture.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp]
         l.atn_mgpu_set_frames_in_flight.argtypes = [vp, C.c_int32]

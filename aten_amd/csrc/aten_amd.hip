@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <random>
 #include <string>
@@ -53,6 +54,36 @@ struct DevBuf {
     }
 };
 
+// ---- which streams really run side by side ---------------------------------------------------------------------------
+// HIP streams are multiplexed onto a few hardware queues (4 by default; under RCCL that number holds whatever
+// GPU_MAX_HW_QUEUES says), chosen by the runtime when a stream is created, and two streams that share a queue execute
+// strictly one after the other.  Frames in flight live on one stream per bank: measured with rocprofv3 (tools/trace_queues.py)
+// under torch.distributed two of the three bank streams shared a queue -- two frames in flight instead of three, 4.20 ->
+// 4.46 ms per frame at full size, and on an 8-way shard the 2-in-flight figure (0.83 instead of 0.67 ms).
+// The API does not tell which queue a stream got, so it is MEASURED: two spin kernels of kSpinTicks, one per stream; side by
+// side they take one spin, on one queue two.
+__global__ void k_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();      // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) { }
+}
+constexpr unsigned long long kSpinTicks = 12000;        // 120 us
+inline bool streams_run_side_by_side(hipStream_t a, hipStream_t b, bool& ok)
+{
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {                 // the first round also loads the kernel; keep the fastest
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { ok = false; return false; }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, a, kSpinTicks);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, b, kSpinTicks);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { ok = false; return false; }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < best) best = us;
+    }
+    ok = true;
+    return best < 1.6 * 120.0;
+}
+
 class PathTracing {
 public:
     std::string last_error;
@@ -71,6 +102,7 @@ public:
     int n_batches = 3;
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
+    bool env_probe_streams = true;  // ATEN_AMD_PROBE_STREAMS=0: take the bank streams as the runtime hands them out
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
@@ -189,6 +221,44 @@ public:
         // flight) is not logged, so sets kept across N -> 1 -> N would come back stale.  Re-clone at the next flip.
         if (n != frames_in_flight) drop_alt_set();
         frames_in_flight = n;
+        if (n > 1 && env_probe_streams) { int rc2 = separate_bank_streams(n); if (rc2) return rc2; }
+        return ATN_OK;
+    }
+
+    // Every bank's main stream on a hardware queue of its own (see streams_run_side_by_side): a bank stream that shares its
+    // queue with an earlier bank's is replaced by a newly created one, up to kStreamTries times (the rejected ones stay
+    // alive until the end, so that the runtime's next choice differs).  Best effort: with fewer queues than banks the last
+    // candidates are kept as they are.
+    static constexpr int kStreamTries = 12;
+    int bank_streams_checked = 0;       // banks 0 .. n-1 are known to be pairwise concurrent
+    int n_stream_swaps = 0;             // (diagnostics: atn_get_stream_swaps)
+    int separate_bank_streams(int n)
+    {
+        if (n <= bank_streams_checked) return ATN_OK;
+        hipStream_t* st[kMaxInFlight];
+        st[0] = &stream;
+        for (int i = 1; i < n; i++) st[i] = &spare[i - 1].stream;
+        std::vector<hipStream_t> rejected;
+        for (int i = (bank_streams_checked > 1 ? bank_streams_checked : 1); i < n; i++) {
+            for (int t = 0; t < kStreamTries; t++) {
+                bool clash = false;
+                for (int j = 0; j < i && !clash; j++) {
+                    bool ok = true;
+                    const bool par = streams_run_side_by_side(*st[j], *st[i], ok);
+                    if (!ok) { for (auto r : rejected) (void)hipStreamDestroy(r); return fail(ATN_ERR_HIP, "stream probe failed"); }
+                    clash = !par;
+                }
+                if (!clash) break;
+                if (t == kStreamTries - 1) break;        // out of tries: keep it
+                hipStream_t fresh = nullptr;
+                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+                rejected.push_back(*st[i]);
+                *st[i] = fresh;
+                n_stream_swaps++;
+            }
+        }
+        for (auto r : rejected) (void)hipStreamDestroy(r);
+        bank_streams_checked = n;
         return ATN_OK;
     }
 
@@ -440,6 +510,7 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ATEN_AMD_PROBE_STREAMS")) env_probe_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -1643,6 +1714,30 @@ int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n)
 {
     CTX_OR_FAIL(ctx);
     return guarded(ctx, [&] { return ctx->r.set_frames_in_flight(n); });
+}
+
+int atn_bank_streams(atn_ctx* ctx, int32_t* swaps, int32_t* concurrent)
+{
+    CTX_OR_FAIL(ctx);
+    return guarded(ctx, [&] {
+        atn::PathTracing& r = ctx->r;
+        C_HIP(r, hipSetDevice(r.device));
+        { int q = r.quiesce(); if (q) return q; }
+        if (swaps) *swaps = r.n_stream_swaps;
+        if (concurrent) {
+            *concurrent = 1;
+            hipStream_t st[atn::PathTracing::kMaxInFlight];
+            st[0] = r.stream;
+            for (int i = 1; i < r.frames_in_flight; i++) st[i] = r.spare[i - 1].stream;
+            for (int i = 0; i < r.frames_in_flight; i++)
+                for (int j = 0; j < i; j++) {
+                    bool ok = true;
+                    if (!atn::streams_run_side_by_side(st[j], st[i], ok)) *concurrent = 0;
+                    if (!ok) return r.fail(ATN_ERR_HIP, "stream probe failed");
+                }
+        }
+        return (int)ATN_OK;
+    });
 }
 
 int atn_svgf_render(atn_ctx* ctx, const atn_destination* dst, int32_t compute_motion, atn_vec4* out_host, atn_vec4* stages_host)

@@ -129,6 +129,12 @@ class PathTracing:
     def set_frames_in_flight(self, n):
         self._check(self._l.atn_set_frames_in_flight(self._ctx, n))
 
+    def bank_streams(self):
+        """(streams replaced by the queue probe so far, every pair of bank streams measured to run side by side)"""
+        sw, cc = C.c_int32(0), C.c_int32(0)
+        self._check(self._l.atn_bank_streams(self._ctx, C.byref(sw), C.byref(cc)))
+        return sw.value, bool(cc.value)
+
     def set_sampling_options(self, ibl_importance=False, tex_bilinear=False):
         self._check(self._l.atn_set_sampling_options(self._ctx, int(ibl_importance), int(tex_bilinear)))
 

@@ -211,6 +211,9 @@ def run_workload(args, cfg, ctx):
     # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
     # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
     ext_streams = {}        # the renderer's stream of the frame just enqueued (one per bank of frames in flight)
+    # (HIP streams share a handful of hardware queues -- 4 under RCCL -- and two streams on one queue run one after the
+    # other.  The renderer makes sure its BANK streams have queues of their own: atn_set_frames_in_flight measures it.  This
+    # stream may share a queue with one bank; its operations are short.  DESIGN.md section 8.)
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
     full = [None]
@@ -253,11 +256,14 @@ def run_workload(args, cfg, ctx):
             dist.barrier()
             torch.cuda.synchronize()
 
+    host_enqueue = [0.0]
+
     def timed(n):
         sync_all()
         t0 = time.perf_counter()
         for i in range(n):
             step(i, False)      # the timed region carries no instrumentation: no event records, no counters
+        host_enqueue[0] = time.perf_counter() - t0      # the host's share: when it returns from the last enqueue
         sync_all()
         e = time.perf_counter() - t0
         if use_dist:
@@ -270,6 +276,7 @@ def run_workload(args, cfg, ctx):
         step(i, False)
     r.reset()
     elapsed = timed(steps)
+    host_enqueue_ms = 1e3 * host_enqueue[0] / steps
     final_img = None
     if cfg.get("dump") and rank == 0:
         final_img = full[0].cpu().numpy() if use_dist else r.download_film()
@@ -533,6 +540,7 @@ def run_workload(args, cfg, ctx):
                                 "one frame's launch tails overlap the next frame's bulk); ms_per_frame_latency is the same K frames with one frame "
                                 "in flight, i.e. what a caller that waits for each frame sees" % in_flight) if in_flight > 1 else "one frame in flight: throughput = latency",
             "ms_per_step_with_events": round(1e3 * elapsed_events / steps, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,

@@ -185,6 +185,11 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n);
  * section 8).  Only the film orders the frames.  atn_stream / atn_tile_device then refer to the LAST rendered frame;
  * every other entry point first waits for all frames in flight. */
 int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n);
+/* Diagnostics of the above: HIP streams share a few hardware queues and two streams on one queue run one after the other, so
+ * atn_set_frames_in_flight MEASURES which of its bank streams run side by side and replaces the ones that do not (DESIGN.md
+ * section 8).  *swaps = streams replaced so far; *concurrent = 1 when every pair of the current bank streams was measured
+ * to overlap (re-measured by this call), 0 otherwise (fewer hardware queues than frames in flight).  Either may be NULL. */
+int atn_bank_streams(atn_ctx* ctx, int32_t* swaps, int32_t* concurrent);
 
 /* Optional samplers, both off by default: they change the sample stream, i.e. they leave the parity path of
  * aten::PathTracing (every default-mode result still matches the CPU renderer).

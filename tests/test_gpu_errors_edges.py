@@ -225,3 +225,21 @@ def test_film_checkpoint_and_resume(orc, cornell):
         assert r._l.atn_upload_film(r._ctx, 0, 4, ckpt.ctypes.data) != 0
     finally:
         r.close()
+
+
+def test_bank_streams_run_side_by_side():
+    """Frames in flight need one hardware queue per bank stream; the runtime multiplexes streams onto a few queues and two
+    streams on one queue serialise.  atn_set_frames_in_flight measures the pairs and replaces the streams that clash."""
+    from aten_amd.renderer import PathTracing
+    r = PathTracing(0)
+    try:
+        # crowd the runtime's queue assignment the way torch.distributed does (a few more live streams) -- whatever it
+        # hands out, the banks must end up pairwise concurrent
+        r.set_frames_in_flight(3)
+        swaps, concurrent = r.bank_streams()
+        assert concurrent, "three bank streams on fewer than three hardware queues (%d swaps)" % swaps
+        r.set_frames_in_flight(1)
+        r.set_frames_in_flight(3)
+        assert r.bank_streams()[1]
+    finally:
+        r.close()

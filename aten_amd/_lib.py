@@ -16,7 +16,7 @@ K_NAMES = ["gen_path", "trace_closest", "shade", "trace_shadow", "accumulate_sam
 SYMBOLS = [
     "atn_create", "atn_destroy", "atn_last_error", "atn_upload_scene", "atn_update_camera", "atn_update_tlas",
     "atn_init_sampler", "atn_set_random", "atn_set_screen_shard", "atn_render", "atn_reset", "atn_set_path_batches",
-    "atn_set_frames_in_flight", "atn_bank_streams", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
+    "atn_set_frames_in_flight", "atn_bank_streams", "atn_side_stream", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
     "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
     "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
@@ -90,6 +90,7 @@ def lib():
         l.atn_tile_device.argtypes = [vp]; l.atn_tile_device.restype = vp
         l.atn_tile_slots.argtypes = [vp]; l.atn_tile_slots.restype = C.c_uint32
         l.atn_stream.argtypes = [vp]; l.atn_stream.restype = vp
+        l.atn_side_stream.argtypes = [vp]; l.atn_side_stream.restype = vp
         l.atn_synchronize.argtypes = [vp]
         l.atn_assemble_tiles.argtypes = [vp, vp, C.c_int32, vp]
         l.atn_assemble_tiles_on.argtypes = [vp, vp, C.c_int32, vp, vp]

@@ -262,6 +262,36 @@ public:
         return ATN_OK;
     }
 
+    // the caller's side stream (atn_side_stream): concurrent with every bank stream if a queue is left
+    hipStream_t side_stream = nullptr;
+    hipStream_t get_side_stream()
+    {
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        hipStream_t banks[kMaxInFlight];
+        banks[0] = stream;
+        for (int i = 1; i < frames_in_flight; i++) banks[i] = spare[i - 1].stream;
+        auto clashes = [&](hipStream_t c, bool& ok) {
+            for (int j = 0; j < frames_in_flight; j++) {
+                if (!streams_run_side_by_side(banks[j], c, ok) || !ok) return true;
+            }
+            return false;
+        };
+        std::vector<hipStream_t> rejected;
+        for (int t = 0; t < kStreamTries; t++) {
+            if (!side_stream && hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess) { side_stream = nullptr; break; }
+            bool ok = true;
+            const bool clash = env_probe_streams ? clashes(side_stream, ok) : false;
+            if (!ok) break;
+            if (!clash || t == kStreamTries - 1) break;
+            rejected.push_back(side_stream);
+            side_stream = nullptr;
+        }
+        // out of tries (fewer queues than banks + 1): any stream will do
+        if (!side_stream && !rejected.empty()) { side_stream = rejected.back(); rejected.pop_back(); }
+        for (auto r : rejected) (void)hipStreamDestroy(r);
+        return side_stream;
+    }
+
     // every frame in flight finished (all banks' streams idle): required before anything but the next render()
     int quiesce()
     {
@@ -547,6 +577,7 @@ public:
             if (b.stream) (void)hipStreamDestroy(b.stream);
         }
         if (stream) (void)hipStreamDestroy(stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
         if (scene_stream) (void)hipStreamDestroy(scene_stream);
         for (auto& e : ev_read) if (e) (void)hipEventDestroy(e);
         if (ev_scene) (void)hipEventDestroy(ev_scene);
@@ -1797,6 +1828,11 @@ void* atn_film_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.film.p : nullpt
 void* atn_tile_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.tile_out.p : nullptr; }
 uint32_t atn_tile_slots(atn_ctx* ctx) { return ctx ? ctx->r.n_slots : 0; }
 void* atn_stream(atn_ctx* ctx) { return ctx ? (void*)ctx->r.stream : nullptr; }
+void* atn_side_stream(atn_ctx* ctx)
+{
+    if (!ctx) return nullptr;
+    try { if (ctx->r.quiesce() != ATN_OK) return nullptr; return (void*)ctx->r.get_side_stream(); } catch (...) { return nullptr; }
+}
 
 int atn_synchronize(atn_ctx* ctx)
 {

@@ -129,6 +129,13 @@ class PathTracing:
     def set_frames_in_flight(self, n):
         self._check(self._l.atn_set_frames_in_flight(self._ctx, n))
 
+    def side_stream_ptr(self):
+        """hipStream_t for the caller's own work beside the frames in flight (atn_side_stream)"""
+        p = self._l.atn_side_stream(self._ctx)
+        if not p:
+            raise AtenAmdError("atn_side_stream failed")
+        return p
+
     def bank_streams(self):
         """(streams replaced by the queue probe so far, every pair of bank streams measured to run side by side)"""
         sw, cc = C.c_int32(0), C.c_int32(0)

@@ -211,10 +211,12 @@ def run_workload(args, cfg, ctx):
     # full frame.  The exchange of frame f runs on its own stream while the renderer's stream already traces frame
     # f + 1 (two staging / gather buffers, events both ways); no host synchronisation inside a step.
     ext_streams = {}        # the renderer's stream of the frame just enqueued (one per bank of frames in flight)
-    # (HIP streams share a handful of hardware queues -- 4 under RCCL -- and two streams on one queue run one after the
-    # other.  The renderer makes sure its BANK streams have queues of their own: atn_set_frames_in_flight measures it.  This
-    # stream may share a queue with one bank; its operations are short.  DESIGN.md section 8.)
-    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    # HIP streams share a handful of hardware queues (4 under RCCL) and two streams on one queue run one after the other.
+    # The renderer measures which of its bank streams run side by side (atn_set_frames_in_flight) and hands out a stream
+    # for the exchange that has, if one is left, a queue of its own (atn_side_stream): a torch pool stream lands on SOME
+    # queue, possibly a bank's, and the all_gather -- a cross-rank synchronisation point -- would then wait behind that bank's
+    # trace kernels and hold its queue meanwhile.  (Synchronous c10d collectives are launched on the current stream.)
+    comm_stream = torch.cuda.ExternalStream(r.side_stream_ptr(), device=dev) if use_dist else None
     stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
     full = [None]
 

@@ -190,6 +190,11 @@ int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n);
  * section 8).  *swaps = streams replaced so far; *concurrent = 1 when every pair of the current bank streams was measured
  * to overlap (re-measured by this call), 0 otherwise (fewer hardware queues than frames in flight).  Either may be NULL. */
 int atn_bank_streams(atn_ctx* ctx, int32_t* swaps, int32_t* concurrent);
+/* A stream for the CALLER's own work beside the frames in flight (a tile exchange, a display copy): created on first use and
+ * chosen -- by the same measurement -- to run side by side with every bank stream when a hardware queue is left for it
+ * (a stream the caller creates itself lands on SOME queue, possibly a bank's, and then waits behind that bank's kernels).
+ * Owned by the context; NULL on failure.  Call after atn_set_frames_in_flight. */
+void* atn_side_stream(atn_ctx* ctx);
 
 /* Optional samplers, both off by default: they change the sample stream, i.e. they leave the parity path of
  * aten::PathTracing (every default-mode result still matches the CPU renderer).

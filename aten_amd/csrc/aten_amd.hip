@@ -232,14 +232,11 @@ public:
     static constexpr int kStreamTries = 12;
     int bank_streams_checked = 0;       // banks 0 .. n-1 are known to be pairwise concurrent
     int n_stream_swaps = 0;             // (diagnostics: atn_get_stream_swaps)
-    int separate_bank_streams(int n)
+    // st[first .. n-1] each made concurrent with every stream before it in the list (replaced in place when they clash)
+    int separate_streams(hipStream_t** st, int n, int first)
     {
-        if (n <= bank_streams_checked) return ATN_OK;
-        hipStream_t* st[kMaxInFlight];
-        st[0] = &stream;
-        for (int i = 1; i < n; i++) st[i] = &spare[i - 1].stream;
         std::vector<hipStream_t> rejected;
-        for (int i = (bank_streams_checked > 1 ? bank_streams_checked : 1); i < n; i++) {
+        for (int i = (first > 1 ? first : 1); i < n; i++) {
             for (int t = 0; t < kStreamTries; t++) {
                 bool clash = false;
                 for (int j = 0; j < i && !clash; j++) {
@@ -258,8 +255,26 @@ public:
             }
         }
         for (auto r : rejected) (void)hipStreamDestroy(r);
+        return ATN_OK;
+    }
+    int separate_bank_streams(int n)
+    {
+        if (n <= bank_streams_checked) return ATN_OK;
+        hipStream_t* st[kMaxInFlight];
+        st[0] = &stream;
+        for (int i = 1; i < n; i++) st[i] = &spare[i - 1].stream;
+        const int rc = separate_streams(st, n, bank_streams_checked);
+        if (rc) return rc;
         bank_streams_checked = n;
         return ATN_OK;
+    }
+    // the batch streams a frame forks into when it is rendered in several batches (one frame in flight: run_paths)
+    int separate_batch_streams()
+    {
+        hipStream_t* st[kMaxBatches];
+        const int n = n_batches < 3 ? n_batches : 3;        // the size policy never uses more than two; three when forced
+        for (int i = 0; i < n; i++) st[i] = &bstream[i];
+        return n > 1 ? separate_streams(st, n, 1) : (int)ATN_OK;
     }
 
     // the caller's side stream (atn_side_stream): concurrent with every bank stream if a queue is left
@@ -550,6 +565,8 @@ public:
             if (n_batches < 1) n_batches = 1;
             if (n_batches > kMaxBatches) n_batches = kMaxBatches;
         }
+        // the streams a frame's batches run on must not share a hardware queue (see streams_run_side_by_side)
+        if (env_probe_streams) { int rc = separate_batch_streams(); if (rc) return rc; }
         return ATN_OK;
     }
 

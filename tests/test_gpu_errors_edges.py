@@ -238,6 +238,8 @@ def test_bank_streams_run_side_by_side():
         r.set_frames_in_flight(3)
         swaps, concurrent = r.bank_streams()
         assert concurrent, "three bank streams on fewer than three hardware queues (%d swaps)" % swaps
+        side = r.side_stream_ptr()
+        assert side and side != r.stream_ptr() and side == r.side_stream_ptr()      # owned by the context, handed out again
         r.set_frames_in_flight(1)
         r.set_frames_in_flight(3)
         assert r.bank_streams()[1]

@@ -389,7 +389,10 @@ inline bool isCloseUlps(float A, float B, int32_t maxUlps)
     if (aInt < 0) aInt = (int32_t)(0x80000000u - (uint32_t)aInt);
     int32_t bInt = float_as_int(B);
     if (bInt < 0) bInt = (int32_t)(0x80000000u - (uint32_t)bInt);
-    int32_t intDiff = std::abs(aInt - bInt);
+    // (the reference's `abs(aInt - bInt)` overflows a signed int for operands of opposite huge magnitude -- +-inf against a
+    // large value of the other sign; its compilers wrap, and so does this, spelled out: found by tools/sanitize_cpu.sh)
+    const int32_t d = (int32_t)((uint32_t)aInt - (uint32_t)bInt);
+    const int32_t intDiff = d < 0 ? (int32_t)(0u - (uint32_t)d) : d;
     return intDiff <= maxUlps;
 }
 

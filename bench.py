@@ -593,6 +593,9 @@ def main():
                     help="one process, every GPU behind the C-ABI (atn_mgpu_*: worker thread per GPU, peer-copy gather into "
                          "GPU 0) instead of one process per GPU + RCCL all_gather")
     ap.add_argument("--shards", type=int, default=0, help="with --mgpu: shard count when it differs from --gpus (shards then share GPUs)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the one-rank-per-GPU mode; nccl (= RCCL) is what is measured, gloo lets "
+                         "several ranks SHARE a GPU (RCCL refuses that), which is how the tests run a world of two on a 1-GPU box")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -625,8 +628,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            local_rank = local_rank % torch.cuda.device_count()     # ranks may share a GPU (tests)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
 
     ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}

@@ -61,24 +61,25 @@ def test_default_line_carries_roofline_companion_and_cpu_baseline():
 
 
 @pytest.mark.gpu
-def test_two_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path):
-    """The N > 1 bench path with a world of TWO on the hardware there is: the launcher command the driver uses
+@pytest.mark.parametrize("world", [2, 7])
+def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
+    """The N > 1 bench path with a world of two (and of seven: a tile count that does not divide) on the hardware there is: the launcher command the driver uses
     (torch.distributed.run, one process per rank, rendezvous on 127.0.0.1), each rank renders its tiles (tile t -> rank
-    t % 2) with frames in flight, exchanges them every frame and assembles the frame -- with the gloo backend, because RCCL
+    t % world) with frames in flight, exchanges them every frame and assembles the frame -- with the gloo backend, because RCCL
     refuses two ranks on one device.  Rank 0's assembled film equals the single-rank film byte for byte."""
     _, film_plain = run_bench([], tmp_path, "plain1")
     dump = str(tmp_path / "two.npy")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29573 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline", "--dump", dump]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
     d = json.loads(lines[-1])
     assert len(lines) == 1, "only rank 0 prints the JSON line"
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     film_two = np.load(dump)
     assert film_two.tobytes() == film_plain.tobytes()

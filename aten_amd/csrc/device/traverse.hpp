@@ -208,6 +208,9 @@ constexpr int kSimpleBurstGlobal = ATN_SIMPLE_BURST_GLOBAL;
 #ifndef ATN_TREELET_PHASES
 #define ATN_TREELET_PHASES 0    /* > 0 (with ATN_TREELET_BYTES > 0): phased treelet walk, see inner_burst */
 #endif
+#ifndef ATN_BURST_UNROLL
+#define ATN_BURST_UNROLL 1      /* the burst's steps unrolled: no loop counter / branch per step (r03: fused trace -1.2 %, atrium -2 %, Cornell -2 %) */
+#endif
 #ifndef ATN_BURST_HOIST
 #define ATN_BURST_HOIST 1
 #endif
@@ -224,7 +227,11 @@ ATN_DEV void ld32(const char* base, uint32_t byte_off, float4& a, float4& b)
 template <bool COUNT, bool TREELET, int BURST, bool FAST, bool LDSN = false>
 ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treelet, uint32_t treelet_bytes, float t_min, TravCounters* cnt)
 {
+#if ATN_BURST_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int k = 0; k < BURST; k++) {
 #if ATN_LEAF_STASH
         // What the per-CU L1 (TCP) charges for a 16-byte wave load is 16 cycles + ~0.5 per distinct 64-byte chunk beyond

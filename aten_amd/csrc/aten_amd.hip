@@ -917,7 +917,6 @@ public:
         if (n < 2) return fail(ATN_ERR_INVALID_ARG, "an LBVH needs at least two triangles");
         if (n > kLbvhMaxTris) return fail(ATN_ERR_UNSUPPORTED, "too many triangles: node indices are stored as floats");
         if ((uint64_t)tri_offset + n > n_scene_tris) return fail(ATN_ERR_INVALID_ARG, "triangle range outside the uploaded scene");
-        if (scene.treelet_bytes) return fail(ATN_ERR_UNSUPPORTED, "the node image has a treelet region (ATN_TREELET_BYTES > 0): lists cannot be rebuilt in place");
         if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
@@ -1086,12 +1085,12 @@ public:
         return grid_for(n_jobs);
     }
 
-    // the persistent kernels run kTraceBlock threads per block and keep the treelet in dynamic LDS
+    // the persistent kernels run kTraceBlock threads per block
     template <bool SHADOW>
     void launch_trace(const PathBuffers& pb, uint32_t grid, bool count, int32_t b, hipStream_t stream)
     {
         const dim3 g(grid), t(use_refill ? (uint32_t)kTraceBlock : 256u);
-        const uint32_t lds = (use_refill && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
+        const uint32_t lds = 0u;
         if (SHADOW) {
             if (count) { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, t, lds, stream, pb, scene, b); }
             else { if (use_refill) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, t, lds, stream, pb, scene, b); else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, t, lds, stream, pb, scene, b); }
@@ -1228,7 +1227,7 @@ public:
                         const bool lds_nodes = lds_scene_bytes() != 0u;
                         const uint32_t sb = (lds_nodes && lds_scene_bytes() > 8192u) ? 256u : simple_block;
                         const dim3 gr(refill_now ? g_fused : g_fused * (256u / sb)), tb(refill_now ? (uint32_t)kTraceBlock : sb);
-                        const uint32_t lds = lds_nodes ? lds_scene_bytes() : (refill_now && ATN_TREELET_LDS) ? scene.treelet_bytes : 0u;
+                        const uint32_t lds = lds_nodes ? lds_scene_bytes() : 0u;
                         if (lds_nodes && refill_now) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<true, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
@@ -2089,7 +2088,7 @@ int atn_trace_closest(atn_ctx* ctx, const atn_ray* rays_host, uint32_t n, float 
         const bool probe_refill = r.flavour_forced ? r.use_refill : r.tree_is_deep;
         r.use_refill = probe_refill;        // trace_grid sizes the launch for it
         const dim3 g(r.trace_grid(n)), t(probe_refill ? (uint32_t)atn::kTraceBlock : 256u);
-        const uint32_t lds = (probe_refill && ATN_TREELET_LDS) ? r.scene.treelet_bytes : 0u;
+        const uint32_t lds = 0u;
         const atn_ray* rp = rays.p;
         if (stats_out) {
             if (probe_refill) hipLaunchKernelGGL((atn::k_trace_batch<true, true>), g, t, lds, r.stream, r.scene, rp, n, t_min, t_max, out.p, st.p);
@@ -2172,12 +2171,6 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
 int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
                  int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
 {
-    return atn_compact3(ctx, flags_a_host, flags_b_host, n, grid_blocks, 0, out_a_host, out_count_a, out_b_host, out_count_b);
-}
-
-int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks, int32_t binned,
-                 int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
-{
     CTX_QUIET_OR_FAIL(ctx);
     PathTracing& r = ctx->r;
     if (!flags_a_host || !out_a_host || !out_count_a) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
@@ -2197,7 +2190,7 @@ int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags
         C_HIP(r, hipMemsetAsync(c.p, 0, 8, r.stream));
         uint32_t grid = grid_blocks ? grid_blocks : PathTracing::grid_for((n + (uint32_t)atn::kChunkItems - 1u) / (uint32_t)atn::kChunkItems);
         hipLaunchKernelGGL(atn::k_compact_append, dim3(grid), dim3(256), 0, r.stream, (const int32_t*)fa.p, (const int32_t*)fb.p, n,
-                           oa.p, c.p, ob.p, c.p + 1, binned);
+                           oa.p, c.p, ob.p, c.p + 1);
         C_HIP(r, hipGetLastError());
         uint32_t hc[2] = { 0, 0 };
         C_HIP(r, hipMemcpyAsync(hc, c.p, 8, hipMemcpyDeviceToHost, r.stream));

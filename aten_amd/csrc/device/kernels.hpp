@@ -125,83 +125,6 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
     __syncthreads();    // sh is reused by the next chunk
 }
 
-// The same append with the chunk's entries written in BIN-major order inside the range the chunk reserves (still one
-// atomicAdd per queue and chunk).  k_shade bins next-bounce and shadow rays by direction octant: a trace wave reads 64
-// consecutive queue entries, i.e. a slice of one chunk's output, so its rays then come from one 16-tile screen region
-// AND point into the same octant -- they walk the tree through neighbouring records instead of 64 unrelated paths.
-// Queue order is free (all per-path state is indexed by slot, section 8 a26), so results are unchanged.
-// binsA/binsB: 3 bits per item (item k's bin at bits 3k..3k+2).  Positions inside a bin come from LDS atomics on 8
-// cursors -- a few hundred cycles per chunk against the ~30 K cycles the chunk's shading takes.
-#ifndef ATN_RAY_BINS
-#define ATN_RAY_BINS 1      /* measured: octant binning costs more in scattered path-state gathers than the walk gains */
-#endif
-constexpr uint32_t kRayBins = ATN_RAY_BINS;        // 1 = no binning (the plain append)
-struct BlockBinShared { uint32_t hist[2][8]; uint32_t start[2][8]; uint32_t base[2]; };
-
-template <class EntryFn>
-ATN_DEV void block_append2_binned(BlockBinShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA, uint32_t binsA,
-                                  uint32_t* qB, uint32_t* cntB, uint32_t flagsB, uint32_t binsB, EntryFn entry)
-{
-    if (threadIdx.x < 16u) sh.hist[threadIdx.x >> 3][threadIdx.x & 7u] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kChunkItems; k++) {
-        if ((flagsA >> k) & 1u) atomicAdd(&sh.hist[0][(binsA >> (3 * k)) & 7u], 1u);
-        if ((flagsB >> k) & 1u) atomicAdd(&sh.hist[1][(binsB >> (3 * k)) & 7u], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2u) {
-        // exclusive prefix over the 8 bins of queue threadIdx.x, one global atomic for the whole chunk; the histogram
-        // cells become the bins' write cursors
-        const uint32_t q = threadIdx.x;
-        uint32_t run = 0;
-        for (int b = 0; b < 8; b++) { const uint32_t c = sh.hist[q][b]; sh.start[q][b] = run; run += c; sh.hist[q][b] = 0u; }
-        uint32_t* cnt = q ? cntB : cntA;
-        sh.base[q] = (run && cnt) ? atomicAdd(cnt, run) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kChunkItems; k++) {
-        if ((flagsA >> k) & 1u) {
-            const uint32_t b = (binsA >> (3 * k)) & 7u;
-            qA[sh.base[0] + sh.start[0][b] + atomicAdd(&sh.hist[0][b], 1u)] = entry(k);
-        }
-        if ((flagsB >> k) & 1u) {
-            const uint32_t b = (binsB >> (3 * k)) & 7u;
-            qB[sh.base[1] + sh.start[1][b] + atomicAdd(&sh.hist[1][b], 1u)] = entry(k);
-        }
-    }
-    __syncthreads();    // sh is reused by the next chunk
-}
-
-ATN_DEV uint32_t dir_octant(const f3& d) { return (d.x < 0.0F ? 1u : 0u) | (d.y < 0.0F ? 2u : 0u) | (d.z < 0.0F ? 4u : 0u); }
-
-// Streamed path state in k_shade: ATN_SHADE_NT = 1 reads it with the non-temporal hint (each record is read once per
-// bounce and should not push the scene's triangles / materials / texels out of the 4 MiB per-XCD L2), 2 also writes the
-// records k_shade produces that way.  Experiment knob: see DESIGN.md section 7 for what was measured.
-#ifndef ATN_SHADE_NT
-#define ATN_SHADE_NT 0
-#endif
-typedef float atn_v4f __attribute__((ext_vector_type(4)));
-ATN_DEV float4 ld_state(const float4* p)
-{
-#if ATN_SHADE_NT >= 1
-    const atn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const atn_v4f*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-ATN_DEV void st_state(float4* p, const float4& v)
-{
-#if ATN_SHADE_NT >= 2
-    atn_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<atn_v4f*>(p));
-#else
-    *p = v;
-#endif
-}
-
 ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
 {
     // wave reduction, one atomic per wave
@@ -262,8 +185,7 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
 }
 
 // REFILL selects the persistent, lane-refilling walk (large trees) or the plain walk (small trees and small launches,
-// where the refill bookkeeping costs more than the idle lanes it removes).  The persistent kernels keep the treelet
-// -- the first sc.treelet_bytes of the node image -- in dynamic LDS (the launch passes that many bytes).
+// where the refill bookkeeping costs more than the idle lanes it removes).
 #ifdef ATN_TRACE_WPE
 #define ATN_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(ATN_TRACE_WPE, ATN_TRACE_WPE)))
 #else
@@ -276,13 +198,7 @@ ATN_DEV void trace_dispatch(const DevScene& sc, uint32_t count, uint32_t* fetch_
     if constexpr (REFILL) {
         __shared__ TraceShared sh;
         if (LDSN) lds_scene_copy(sc);       // the whole node image + the matrices (small scenes)
-        else if (ATN_TREELET_LDS) {
-            const uint32_t n16 = sc.treelet_bytes / 16u;
-            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) atn_dyn_lds[i] = sc.nodes[i];
-            __syncthreads();
-        }
-        trace_shared_init(sh);
-        trace_refill<COUNT, Job, LDSN>(sc, sh, reinterpret_cast<const char*>(atn_dyn_lds), count, fetch_counter, job, tc);
+        trace_refill<COUNT, Job, LDSN>(sc, sh, count, fetch_counter, job, tc);
     }
     else {
         trace_simple<COUNT, Job, LDSN>(sc, count, job, tc);
@@ -359,7 +275,6 @@ template <bool SVGF, int MS>
 ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FrameParams& fp, const atn_camera_param& cam, int32_t bounce, const SvgfShade& sv)
 {
     __shared__ BlockAppendShared sh;
-    __shared__ BlockBinShared shb;
 #if ATN_SHADE_PARTITION
     __shared__ ShadePartShared part;
 #endif
@@ -371,7 +286,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
     const int items = fp.chunk_items;
     const uint32_t chunk_size = 256u * (uint32_t)items;
     for (uint32_t chunk = blockIdx.x * chunk_size; chunk < count; chunk += gridDim.x * chunk_size) {
-      uint32_t flags_next = 0, flags_shadow = 0, bins_next = 0, bins_shadow = 0;
+      uint32_t flags_next = 0, flags_shadow = 0;
 #if ATN_SHADE_PARTITION
       const uint32_t n_valid = count - chunk < chunk_size ? count - chunk : chunk_size;
       {
@@ -418,7 +333,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
         const bool valid = j < count;
 #endif
         bool push_next = false, push_shadow = false;
-        uint32_t bin_next = 0, bin_shadow = 0;
         uint32_t slot = 0;
 
         if (valid) {
@@ -427,13 +341,13 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
 #else
             slot = q[j];
 #endif
-            const float4 ro4 = ld_state(&pb.ray_o[slot]), rd4 = ld_state(&pb.ray_d[slot]);
+            const float4 ro4 = pb.ray_o[slot], rd4 = pb.ray_d[slot];
             const f3 ray_org = mk3(ro4), ray_dir = mk3(rd4);
             float pdfb = ro4.w;
             uint32_t flags = __float_as_uint(rd4.w);
-            const float4 is4 = ld_state(&pb.isect[slot]);
+            const float4 is4 = pb.isect[slot];
             const int32_t hit_objid = __float_as_int(is4.x);
-            const float4 thr4 = ld_state(&pb.thr[slot]);
+            const float4 thr4 = pb.thr[slot];
             f3 throughput = mk3(thr4);
             bool wrote_ray = false;
             f3 contrib_add = mk3(0.0F);         // contrib is read-modify-written only by the paths that add to it
@@ -601,7 +515,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         sh_d4 = make_float4(dirToLight.x, dirToLight.y, dirToLight.z,
                                             __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)));
                         sh_c4 = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, sh_d4.w);     // (the light bits again: all finish() needs)
-                        bin_shadow = dir_octant(dirToLight);
                     }
 
                     // ---- ComputeRussianProbability, pathtracing_impl.h:680-698
@@ -636,40 +549,36 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         }
                         const f3 no = ray_offset(rec.p, ray_along_normal);
                         const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
-                        st_state(&pb.ray_o[slot], make_float4(no.x, no.y, no.z, pdfb));
-                        st_state(&pb.ray_d[slot], make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags)));
+                        pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
+                        pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
                         wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
-                        bin_next = dir_octant(nd);
                     }
                     // HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     push_shadow = shadow_active && !(flags & F_TERMINATED);
-                    if (push_shadow) { st_state(&pb.sh_o[slot], sh_o4); st_state(&pb.sh_d[slot], sh_d4); st_state(&pb.sh_c[slot], sh_c4); }
+                    if (push_shadow) { pb.sh_o[slot] = sh_o4; pb.sh_d[slot] = sh_d4; pb.sh_c[slot] = sh_c4; }
                 }
             }
             if (!push_next && !wrote_ray) {
                 // path ends here (terminated; a path that merely ran out of depth stored its flags with its last ray):
                 // keep the flags for the sample epilogue
-                st_state(&pb.ray_d[slot], make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags)));
+                pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
             }
-            st_state(&pb.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim)));
+            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
             if (contrib_changed) {
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             }
         }
-        if (push_next) { flags_next |= 1u << k; bins_next |= bin_next << (3 * k); }
-        if (push_shadow) { flags_shadow |= 1u << k; bins_shadow |= bin_shadow << (3 * k); }
+        if (push_next) flags_next |= 1u << k;
+        if (push_shadow) flags_shadow |= 1u << k;
       }
 #if ATN_SHADE_PARTITION
       auto entry_of = [&](int k) { return part.perm[(uint32_t)k * 256u + threadIdx.x]; };
 #else
       auto entry_of = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
 #endif
-      if (kRayBins > 1)
-          block_append2_binned(shb, qn, &pb.q_count[bounce + 1], flags_next, bins_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, bins_shadow, entry_of);
-      else
-          block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, entry_of);
+      block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, entry_of);
     }
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
 }
@@ -1043,27 +952,21 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
 // its next-bounce and shadow queues, same chunking (kChunkItems x 256 entries per block and atomic), grid-stride.
 // The queues come out UNORDERED (slot order is irrelevant to the renderer); atn_compact sorts them on the host
 // to present the stable contract of idaten::StreamCompaction::compact (StreamCompaction.cu:175-316).
-// binned != 0: the bin-major variant k_shade uses, entry i's bin = (flag - 1) & 7.
 __global__ void __launch_bounds__(256) k_compact_append(const int32_t* __restrict__ flags_a, const int32_t* __restrict__ flags_b, uint32_t n,
-                                                        uint32_t* out_a, uint32_t* cnt_a, uint32_t* out_b, uint32_t* cnt_b, int32_t binned)
+                                                        uint32_t* out_a, uint32_t* cnt_a, uint32_t* out_b, uint32_t* cnt_b)
 {
     __shared__ BlockAppendShared sh;
-    __shared__ BlockBinShared shb;
     for (uint32_t chunk = blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
-        uint32_t fa = 0, fb = 0, ba = 0, bb = 0;
+        uint32_t fa = 0, fb = 0;
 #pragma unroll
         for (int k = 0; k < kChunkItems; k++) {
             const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
             if (i < n) {
-                if (flags_a[i] > 0) { fa |= 1u << k; ba |= ((uint32_t)(flags_a[i] - 1) & 7u) << (3 * k); }
-                if (flags_b && flags_b[i] > 0) { fb |= 1u << k; bb |= ((uint32_t)(flags_b[i] - 1) & 7u) << (3 * k); }
+                if (flags_a[i] > 0) fa |= 1u << k;
+                if (flags_b && flags_b[i] > 0) fb |= 1u << k;
             }
         }
-        if (binned)
-            block_append2_binned(shb, out_a, cnt_a, fa, ba, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb, bb,
-                                 [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
-        else
-            block_append2(sh, out_a, cnt_a, fa, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb,
+        block_append2(sh, out_a, cnt_a, fa, out_b, flags_b ? cnt_b : (uint32_t*)nullptr, fb,
                           [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
     }
 }

@@ -21,9 +21,6 @@ namespace atn {
 //                     q1 = {meshid, top hit link, top miss link, 0}
 //   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
 //              path); an inner record whose hit link IS its miss link.
-//
-// The image starts with the TREELET: the inner records nearest the roots of the bottom-level trees (at most
-// kTreeletMaxBytes), which the persistent trace kernel copies into LDS; [0, treelet_bytes) is that address range.
 constexpr int32_t kLinkEnd = -1;
 constexpr int32_t kLinkLeafBit = 1;
 constexpr int32_t kLinkTlasBit = 2;
@@ -40,12 +37,9 @@ constexpr int kMsDisney = 1;      // + Disney
 constexpr int kMsAnalytic = 2;    // + Refraction, Beckman, Oren-Nayar, Velvet, MicrofacetRefraction, Retroreflective
 constexpr int kMsCarPaint = 3;    // + CarPaint (flake normals, shared random number)
 constexpr int kMsToon = 4;        // + Toon / StylizedBrdf (inline visibility walk)
-#ifndef ATN_TREELET_BYTES
-#define ATN_TREELET_BYTES 0      /* measured on MI355X: the LDS copy loses to the L1; > 0 re-enables it */
-#endif
-constexpr uint32_t kTreeletMaxBytes = ATN_TREELET_BYTES;
 // A node image of at most this many bytes (Cornell box: 71 nodes = 2.9 KB; instanced props) is copied into LDS by every
-// block of the plain walk and ALL its records are read from there (one source: none of the treelet's per-lane selection).
+// block of the plain walk and ALL its records are read from there (one source, no per-lane selection between sources; an
+// LDS copy of only the top of a deep tree -- a "treelet" -- lost to the L1 in every form tried).
 constexpr uint32_t kLdsNodesMaxBytes = 32u * 1024u;
 
 // MaterialParameter reduced to what this path reads (96 B instead of 248 B AoS).
@@ -73,33 +67,7 @@ static_assert(sizeof(DevMaterial) == 80, "DevMaterial");
 // (image/image.cpp:76-80) -- for an integer k in 0..255, i.e. an 8-bit image the caller converted with one IEEE operation,
 // is stored as packed RGBA8 and converted back with the same operation on fetch -- bit-identical values at a quarter of the bytes (sponza_lod: 50 MB of float4 texels -> 12.5 MB, 32 texels
 // per 128-byte line instead of 8).  Anything else (HDR environment maps, filtered images) stays float4.
-// Texel order (ATN_TEX_TILED): 64-byte SECTORS of 4 x 4 RGBA8 texels / 2 x 2 float4 texels, sectors row-major over the image
-// (width and height padded to whole sectors), so a 128-byte line is an 8 x 4 / 4 x 2 block instead of a 32 x 1 / 8 x 1 strip:
-// neighbouring pixels' point lookups share sectors in both directions.  Values are untouched (same texel, other address).
-#ifndef ATN_TEX_TILED
-#define ATN_TEX_TILED 0        /* measured (r03, profiles/r03_shade_texture_tiling.txt): k_shade FETCH_SIZE -0.4 % / -0.5 %: the lookups are incoherent, row-major stays */
-#endif
-__host__ __device__ inline uint32_t tex_log2_tile(int32_t format) { return format ? 2u : 1u; }      // RGBA8: 4 x 4, float4: 2 x 2
-__host__ __device__ inline size_t tex_storage_texels(int32_t width, int32_t height, int32_t format)
-{
-#if ATN_TEX_TILED
-    const uint32_t l = tex_log2_tile(format), m = (1u << l) - 1u;
-    return (size_t)(((uint32_t)width + m) >> l) * (((uint32_t)height + m) >> l) << (2 * l);
-#else
-    return (size_t)width * height;
-#endif
-}
-__host__ __device__ inline uint32_t tex_texel_index(int32_t width, int32_t format, int32_t x, int32_t y)
-{
-#if ATN_TEX_TILED
-    const uint32_t l = tex_log2_tile(format), m = (1u << l) - 1u;
-    const uint32_t per_row = ((uint32_t)width + m) >> l;
-    return ((((uint32_t)y >> l) * per_row + ((uint32_t)x >> l)) << (2 * l)) + (((uint32_t)y & m) << l) + ((uint32_t)x & m);
-#else
-    return (uint32_t)(y * width + x);
-#endif
-}
-
+// Texels are row-major (64-byte sector tiling was measured in r03: k_shade FETCH_SIZE -0.4 %, the lookups are incoherent).
 struct DevTexture {
     uint32_t offset;    // first texel in `texels` (format 0) or `texels8` (format 1)
     int32_t width, height;
@@ -143,7 +111,6 @@ struct DevScene {
     int32_t material_set;               // kMsCore .. kMsToon: which k_shade is launched
     int32_t root_link;                  // typed link of TLAS node 0
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
-    uint32_t treelet_bytes;             // [0, treelet_bytes) of `nodes`: the records a trace kernel may keep in LDS
     uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
     uint32_t mtx_quads;                 // float4 rows in `matrices` (the LDS copy holds them behind the node image)
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):

@@ -77,7 +77,7 @@ ATN_DEV int32_t wrap_repeat(int32_t value, int32_t wrap_size)
 }
 ATN_DEV float4 fetch_texel(const DevScene& sc, const DevTexture& t, int32_t x, int32_t y)
 {
-    const uint32_t idx = t.offset + tex_texel_index(t.width, t.format, x, y);
+    const uint32_t idx = t.offset + (uint32_t)(y * t.width + x);
     if (t.format) {
         // the same IEEE operation the caller's 8-bit -> float conversion made (which one: checked per texel at upload)
         const uint32_t p = sc.texels8[idx];

@@ -19,10 +19,6 @@
 
 namespace atn {
 
-#ifndef ATN_LEAF_STASH
-#define ATN_LEAF_STASH 0        /* measured negative: VMEM instructions -18 %, VALU +48 %, time +7 % */
-#endif
-
 struct Hit {
     float t;
     int32_t objid;      // instance object id (TLAS leaf), -1 = miss
@@ -93,7 +89,7 @@ ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
     return *reinterpret_cast<const float4*>(base + byte_off);
 }
 
-// The block's dynamic LDS: the treelet of the persistent kernels, or the WHOLE node image of a small scene (LDSN).
+// The block's dynamic LDS: the WHOLE node image of a small scene (LDSN).
 extern __shared__ float4 atn_dyn_lds[];
 // a 16-byte quarter of a node record: from global memory, or -- LDSN -- from the block's LDS copy of the node image
 // (indexing the __shared__ array keeps the access in the LDS address space: ds_read_b128, not a flat load)
@@ -165,12 +161,6 @@ struct Walk {
     float t_max, stop_t;
     uint32_t payload;
     int32_t node, objid, meshid, top_hit, top_miss;
-#if ATN_LEAF_STASH
-    // first two quarters of the leaf / TLAS-leaf record the lane stands on, fetched by the burst's load instructions
-    // (see inner_burst); `stash` = the typed link they belong to
-    float4 sq0, sq1;
-    int32_t stash;
-#endif
 };
 
 ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t)
@@ -182,232 +172,78 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
     slab_setup(w.wray, mk3(a), mk3(b));
     w.ray = w.wray;
     w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
-    // (w.stash is left alone: a stale stash still holds the bytes of the record its link names)
 }
 
-#ifndef ATN_TREELET_LDS
-#define ATN_TREELET_LDS 1       /* 0: keep the treelet REGION (hot records contiguous at the head of the image) but read it from global memory */
-#endif
-#ifndef ATN_PAIR_FETCH
-#define ATN_PAIR_FETCH 0        /* 1: a burst step fetches 64 B (the record and the one behind it) and may take two steps */
-#endif
 #ifndef ATN_INNER_BURST
 #define ATN_INNER_BURST 5
 #endif
-constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk
-
-
+constexpr int kInnerBurst = ATN_INNER_BURST;       // persistent (refill) walk: 3 / 4 / 5 / 6 steps measured, DESIGN.md section 7
 #ifndef ATN_SIMPLE_BURST_LDS
-#define ATN_SIMPLE_BURST_LDS 2  /* the plain walk over an LDS copy of the scene steps in bursts of this many inner-node steps (0 = every kind every step) */
+#define ATN_SIMPLE_BURST_LDS 2  /* the plain walk over an LDS copy of the scene steps in bursts of this many inner-node steps */
 #endif
 constexpr int kSimpleBurstLds = ATN_SIMPLE_BURST_LDS;
-#ifndef ATN_SIMPLE_BURST_GLOBAL
-#define ATN_SIMPLE_BURST_GLOBAL 0
-#endif
-constexpr int kSimpleBurstGlobal = ATN_SIMPLE_BURST_GLOBAL;
-#ifndef ATN_TREELET_PHASES
-#define ATN_TREELET_PHASES 0    /* > 0 (with ATN_TREELET_BYTES > 0): phased treelet walk, see inner_burst */
-#endif
-#ifndef ATN_BURST_UNROLL
-#define ATN_BURST_UNROLL 1      /* the burst's steps unrolled: no loop counter / branch per step (r03: fused trace -1.2 %, atrium -2 %, Cornell -2 %) */
-#endif
-#ifndef ATN_BURST_HOIST
-#define ATN_BURST_HOIST 1
-#endif
 
 // both 16-byte halves of a record through ONE address computation (the second load takes an immediate offset)
+template <bool LDSN>
 ATN_DEV void ld32(const char* base, uint32_t byte_off, float4& a, float4& b)
 {
-    const float4* p = reinterpret_cast<const float4*>(base + byte_off);
-    a = p[0]; b = p[1];
+    if constexpr (LDSN) { a = atn_dyn_lds[byte_off >> 4]; b = atn_dyn_lds[(byte_off >> 4) + 1u]; }
+    else {
+        const float4* p = reinterpret_cast<const float4*>(base + byte_off);
+        a = p[0]; b = p[1];
+    }
 }
 
-// A burst of inner-node steps with ONE form of the slab test (FAST: hardware min/max, valid when every live lane's slab
-// constants are finite; else the select form, valid for all inputs).  See walk_iteration.
-template <bool COUNT, bool TREELET, int BURST, bool FAST, bool LDSN = false>
-ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, const char* treelet, uint32_t treelet_bytes, float t_min, TravCounters* cnt)
+// A burst of inner-node steps, spelled out (no loop counter, compare and branch per step), with ONE form of the slab test
+// (FAST: hardware min/max, valid when every live lane's slab constants are finite; else the select form, valid for all
+// inputs).  See walk_iteration.
+template <bool COUNT, int BURST, bool FAST, bool LDSN>
+ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, float t_min, TravCounters* cnt)
 {
-#if ATN_BURST_UNROLL
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int k = 0; k < BURST; k++) {
-#if ATN_LEAF_STASH
-        // What the per-CU L1 (TCP) charges for a 16-byte wave load is 16 cycles + ~0.5 per distinct 64-byte chunk beyond
-        // one per quad of lanes -- WHATEVER the exec mask (profiles/r03_calibration.json: 16 active lanes cost 16.8
-        // cycles, 64 cost 39).  The trace kernels are bound by exactly that unit, so a load instruction should carry as
-        // many lanes as it can: the lanes that reached a triangle leaf or a TLAS leaf ride along with the next burst
-        // step's two loads (their record's first two quarters are what they need), park the data, and the leaf step
-        // below issues ONE load (the third quarter) instead of three for a handful of lanes.
-        if (w.node != kLinkEnd && w.node != w.stash) {
-            const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
-            float4 q0, q1;
-            ld32(nb, off, q0, q1);
-            if (!(w.node & kLinkTypeMask)) {
-                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
-                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                w.node = __float_as_int(box ? q0.w : q1.w);
-            }
-            else {
-                w.sq0 = q0; w.sq1 = q1; w.stash = w.node;
-            }
-        }
-#else
-#if ATN_TREELET_PHASES
-        if (TREELET) {
-            // PHASED treelet walk: the lanes whose inner node lies in the treelet (the block's LDS copy of the records nearest
-            // the roots) take up to ATN_TREELET_PHASES steps from LDS -- no L1 involved -- then the lanes on inner nodes
-            // outside take ONE step from global memory.  Two plain blocks, one source each: none of the per-lane selection
-            // between sources that made the earlier treelet forms issue BOTH loads on every step.
-#pragma unroll 1
-            for (int m = 0; m < ATN_TREELET_PHASES; m++) {
-                if (!(w.node & kLinkTypeMask) && (uint32_t)w.node < treelet_bytes) {
-                    const uint32_t i16 = (uint32_t)w.node >> 4;
-                    const float4 q0 = atn_dyn_lds[i16], q1 = atn_dyn_lds[i16 + 1u];
-                    if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-                    const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
-                                          : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                    w.node = __float_as_int(box ? q0.w : q1.w);
-                }
-            }
-            if (!(w.node & kLinkTypeMask) && (uint32_t)w.node >= treelet_bytes) {
-                float4 q0, q1;
-                ld32(nb, (uint32_t)w.node, q0, q1);
-                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
-                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                w.node = __float_as_int(box ? q0.w : q1.w);
-            }
-            continue;
-        }
-#endif
         if (!(w.node & kLinkTypeMask)) {
-            const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
             float4 q0, q1;
-            if (TREELET) {
-                const bool in_lds = off < treelet_bytes;
-                float4 g0, g1;      // deliberately not initialised: only the lanes that load them select them
-                if (!in_lds) ld32(nb, off, g0, g1);
-                const uint32_t loff = in_lds ? off : 0u;
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v4f l0 = *reinterpret_cast<const v4f*>(treelet + loff);
-                v4f l1 = *reinterpret_cast<const v4f*>(treelet + loff + 16u);
-                asm volatile("" : "+v"(l0), "+v"(l1));
-                q0 = make_float4(in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w);
-                q1 = make_float4(in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w);
-            }
-            else if (LDSN) {
-                q0 = ldn<true>(nb, off); q1 = ldn<true>(nb, off + 16u);
-            }
-            else {
-                ld32(nb, off, q0, q1);
-            }
+            ld32<LDSN>(nb, (uint32_t)w.node, q0, q1);       // type bits are 0: the link is the byte offset
             if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
                                   : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
             w.node = __float_as_int(box ? q0.w : q1.w);
         }
-#endif
     }
 }
 
-// One wave iteration of the walk, for every live lane: a BURST of kInnerBurst inner-node steps in a tight loop (two
-// 16-byte loads, the slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle
-// leaf or a TLAS leaf, then the lanes whose list ended leave the bottom layer or finish.
+// One wave iteration of the walk, for every live lane: a BURST of inner-node steps in a tight loop (two 16-byte loads, the
+// slab test, the link select -- nothing else), then ONE step for the lanes that stand on a triangle leaf or a TLAS leaf,
+// then the lanes whose list ended leave the bottom layer or finish.
 // Why: at any moment only ~7 of 64 lanes stand on a leaf (one visit in nine), so a loop that offers every node kind on
 // every iteration issues the ~75-instruction triangle block each time for a handful of lanes, and drags the leave /
 // finish (and refill) bookkeeping -- ~60 scalar instructions -- through every inner-node step.  Here a lane that
 // reaches a leaf waits, masked off, for the end of the burst, the triangle block runs once per burst with several
 // times the lanes, and the inner-node step is ~30 VALU + ~15 SALU.
-// The slab test takes ONE of its two forms per wave: the hardware min/max form when every live lane's slab constants
-// are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form -- valid for all inputs
-// -- otherwise.  TREELET: records below sc.treelet_bytes are read from the block's LDS copy (`treelet`).
+// The slab test takes ONE of its two forms per wave, chosen once per burst: the hardware min/max form when every live
+// lane's slab constants are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form --
+// valid for all inputs -- otherwise.
 // A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
-template <bool COUNT, bool TREELET, int BURST, class Job, bool LDSN = false>
-ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, const char* treelet,
-                            uint32_t treelet_bytes, float t_min, const Job& job, TravCounters* cnt)
+template <bool COUNT, int BURST, class Job, bool LDSN = false>
+ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, float t_min,
+                            const Job& job, TravCounters* cnt)
 {
     // ---- burst of inner-node steps.  kLinkEnd has both type bits set, so `(node & 3) == 0` alone selects the live
     // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
     // link is its miss link): a list that ends here ended on a MISS.
     const bool live = w.node != kLinkEnd;
-    // the slab form is wave-uniform: chosen ONCE per burst, outside the step loop (inside it the choice costs ~8 scalar
-    // instructions and two branches on every step)
-#if ATN_BURST_HOIST
-    if (all_finite) inner_burst<COUNT, TREELET, BURST, true, LDSN>(w, nb, treelet, treelet_bytes, t_min, cnt);
-    else inner_burst<COUNT, TREELET, BURST, false, LDSN>(w, nb, treelet, treelet_bytes, t_min, cnt);
-#else
-#pragma unroll 1
-    for (int k = 0; k < BURST; k++) {
-        if (!(w.node & kLinkTypeMask)) {
-            const uint32_t off = (uint32_t)w.node;          // type bits are 0: the link is the byte offset
-            float4 q0, q1;
-            if (TREELET) {
-                // The L1 (TCP) counts one access per ACTIVE lane and load, so the global loads are issued for the
-                // lanes outside the treelet only (exec-masked); the lanes inside read the block's LDS copy.  The two
-                // sides must land in DIFFERENT registers: with a shared destination the compiler completes one side
-                // before it issues the other (it cannot see that the lanes are disjoint) and the latencies add up.
-                // The empty asm keeps the LDS values live in their own registers while the global loads are in flight.
-                const bool in_lds = off < treelet_bytes;
-                float4 g0, g1;      // deliberately not initialised: only the lanes that load them select them
-                if (!in_lds) { g0 = ld16(nb, off); g1 = ld16(nb, off + 16u); }
-                const uint32_t loff = in_lds ? off : 0u;
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v4f l0 = *reinterpret_cast<const v4f*>(treelet + loff);
-                v4f l1 = *reinterpret_cast<const v4f*>(treelet + loff + 16u);
-                asm volatile("" : "+v"(l0), "+v"(l1));
-                q0 = make_float4(in_lds ? l0.x : g0.x, in_lds ? l0.y : g0.y, in_lds ? l0.z : g0.z, in_lds ? l0.w : g0.w);
-                q1 = make_float4(in_lds ? l1.x : g1.x, in_lds ? l1.y : g1.y, in_lds ? l1.z : g1.z, in_lds ? l1.w : g1.w);
-            }
-            else {
-                q0 = ld16(nb, off);
-                q1 = ld16(nb, off + 16u);
-            }
-#if ATN_PAIR_FETCH
-            // the record that FOLLOWS this one in the image: in walk (pre-)order that is the hit-link target of an inner
-            // node more often than not, so one memory round trip can serve two tree levels (same decisions, same order)
-            const float4 s0 = ld16(nb, off + 32u);
-            const float4 s1 = ld16(nb, off + 48u);
-#endif
-            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-            bool box;
-            if (all_finite) box = slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-            else box = slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-            w.node = __float_as_int(box ? q0.w : q1.w);
-#if ATN_PAIR_FETCH
-            if (w.node == (int32_t)(off + 32u)) {       // an inner record (type bits 0) right behind this one: already here
-                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-                bool box2;
-                if (all_finite) box2 = slab_hit_fast(w.ray, mk3(s0), mk3(s1), t_min, w.t_max);
-                else box2 = slab_hit_exact(w.ray, mk3(s0), mk3(s1), t_min, w.t_max);
-                w.node = __float_as_int(box2 ? s0.w : s1.w);
-            }
-#endif
-        }
-    }
-#endif
+    if (all_finite) inner_burst<COUNT, BURST, true, LDSN>(w, nb, t_min, cnt);
+    else inner_burst<COUNT, BURST, false, LDSN>(w, nb, t_min, cnt);
     bool ended = live && w.node == kLinkEnd;    // this lane's walk left a list in this iteration ...
     bool is_hit = false;                        // ... and this was the result of its last step
 
     // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
-#if ATN_LEAF_STASH && ATN_BURST_HOIST
-    // only the lanes whose record head was fetched by the burst (a lane that stepped onto a leaf in the burst's last step
-    // gets it in the next burst's first step and is served by the next leaf step)
-    const bool staged = w.node != kLinkEnd && (w.node & kLinkTypeMask) && w.node == w.stash;
-    const bool at_tlas = staged && (w.node & kLinkTypeMask) == kLinkTlasBit;
-    if (staged) {
-        const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
-        const float4 q0 = w.sq0;
-        const float4 q1 = w.sq1;
-#else
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
     if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ldn<LDSN>(nb, off);
         const float4 q1 = ldn<LDSN>(nb, off + 16u);
-#endif
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         if (w.node & kLinkLeafBit) {
             const float4 q2 = ldn<LDSN>(nb, off + 32u);
@@ -537,7 +373,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
         float4 a, b;
         float stop_t;
         job.fetch(j, a, b, stop_t);
-        if constexpr ((LDSN && kSimpleBurstLds > 0) || (!LDSN && kSimpleBurstGlobal > 0)) {
+        if constexpr (LDSN && kSimpleBurstLds > 0) {
             // Over an LDS copy a step waits ~100 clocks, not for the L1 behind other waves' gathers, so what the plain walk pays
             // for is issue: every iteration of the loop below offers every node kind, and the ~75-instruction triangle block
             // and the ~110-instruction TLAS-leaf block (two matrix products, normalize, three IEEE divides) run each time
@@ -547,7 +383,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             walk_start(w, sc, a, b, stop_t);
             bool all_finite = __all(w.ray.finite) != 0;
             while (__any(w.node != kLinkEnd))
-                walk_iteration<COUNT, false, (LDSN ? kSimpleBurstLds : kSimpleBurstGlobal), Job, LDSN>(w, all_finite, sc, nb, nullptr, 0u, t_min, job, cnt);
+                walk_iteration<COUNT, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
             continue;
         }
       restart:
@@ -624,132 +460,18 @@ constexpr uint32_t kRefillLanes = ATN_REFILL_LANES;
 #endif
 constexpr uint32_t kFetchChunk = ATN_FETCH_CHUNK;
 constexpr int kTraceWavesPerBlock = kTraceBlock / 64;
-// TAIL MERGING (r03).  When the job queue is drained every wave still holds up to 64 walks that end at very different times
-// (sponza_lod: median 56 node visits, 1 % above 164), so a launch ends with thousands of waves that each keep a few lanes
-// alive -- and a wave load costs the per-CU L1 its 16 clocks whether 3 or 60 lanes take part (profiles/r03_calibration.json).
-// A CPU replay of the refill schedule puts 28 % of a 1.9 M-ray launch's wave-steps into that tail, at 23 %
-// lane occupancy.  So: a drained wave with at most kTailDonateLanes live walks DONATES them to the block -- it parks their
-// state (40 dwords each) in its own, now unused, staging region and leaves -- and drained waves with idle lanes pick
-// donated walks up through the same path that hands them fresh rays.  A walk continues in another lane with exactly the
-// state it had (slab constants are recomputed from the same origin / direction by the same function), so every ray's own
-// sequence of operations -- and the visit counters -- are untouched.
-// Protocol, all in LDS, no waiting anywhere: `ctrl` = waves of the block still running << 16 | donated walks not yet taken.
-// A donor publishes with ONE compare-and-swap (running - 1, pending + n) that only succeeds while another wave is still
-// running; a wave with nothing left leaves with ONE compare-and-swap (running - 1) that only succeeds while nothing is
-// pending.  Whichever of the two lands first, the other sees it: a donation is never left behind.
-#ifndef ATN_TAIL_MERGE
-#define ATN_TAIL_MERGE 0        /* measured (r03): correct, but the hot loop's allocation goes 80 -> 115 VGPRs (6 -> 4 waves per SIMD) and the
-                                   launch gets 12 % SLOWER; forced back to 80 registers the kernel faults.  DESIGN.md section 7 */
-#endif
-#ifndef ATN_TAIL_DONATE_LANES
-#define ATN_TAIL_DONATE_LANES 16
-#endif
-constexpr uint32_t kTailDonateLanes = ATN_TAIL_DONATE_LANES;
-constexpr uint32_t kTailFields = 42;            // dwords of a parked walk (2 x 13 slab + 6 hit + 8 walk + the COUNT instantiations' two counters)
+// (Merging the launch tail's half-empty waves -- within a block through LDS, or through a continuation launch -- was
+// built and measured in r03: correct, 12 % / 20 % slower.  DESIGN.md section 7, profiles/r03_variants_tail_merge.txt.)
 struct TraceShared {
     float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk];    // 18 KB
-    uint32_t ctrl;
-    uint32_t don_count[kTraceWavesPerBlock];    // walks wave d parked in stage[d] (0 = none)
-    uint32_t don_taken[kTraceWavesPerBlock];    // ... of which claimed (may run past don_count: a claim past the end takes nothing)
 };
-static_assert(sizeof(float4) * kFetchChunk * 2 >= kTailFields * kTailDonateLanes * 4, "a wave's staging region holds its donation");
-
-ATN_DEV void trace_shared_init(TraceShared& sh)
-{
-    if (threadIdx.x == 0) {
-        sh.ctrl = (uint32_t)kTraceWavesPerBlock << 16;
-        for (int d = 0; d < kTraceWavesPerBlock; d++) { sh.don_count[d] = 0; sh.don_taken[d] = 0; }
-    }
-    __syncthreads();
-}
-ATN_DEV uint32_t tail_pending(TraceShared& sh) { return __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED) & 0xffffu; }
-// leave the block's census -- only while no donated walk is pending
-ATN_DEV bool tail_try_exit(TraceShared& sh)
-{
-    uint32_t ok = 0;
-    if (__lane_id() == 0) {
-        uint32_t old = __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED);
-        for (;;) {
-            if (old & 0xffffu) break;
-            const uint32_t prev = atomicCAS(&sh.ctrl, old, old - 0x10000u);
-            if (prev == old) { ok = 1; break; }
-            old = prev;
-        }
-    }
-    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
-}
-// publish n parked walks and leave -- only while another wave of the block is still running
-ATN_DEV bool tail_try_publish(TraceShared& sh, uint32_t n)
-{
-    uint32_t ok = 0;
-    if (__lane_id() == 0) {
-        uint32_t old = __atomic_load_n(&sh.ctrl, __ATOMIC_RELAXED);
-        for (;;) {
-            if ((old >> 16) <= 1u) break;
-            const uint32_t prev = atomicCAS(&sh.ctrl, old, old - 0x10000u + n);
-            if (prev == old) { ok = 1; break; }
-            old = prev;
-        }
-    }
-    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
-}
-// A parked walk is the Walk's registers, field by field (the slab constants too: recomputing them on the receiving side
-// costs ~35 live registers in the hot loop's allocation -- the kernel went from 80 to 115 VGPRs, 6 -> 4 waves per SIMD).
-template <bool COUNT>
-ATN_DEV void tail_park(float* pool, uint32_t k, const Walk& w, const TravCounters* cnt)
-{
-    uint32_t f = 0;
-    auto put = [&](float v) { pool[f * kTailDonateLanes + k] = v; f++; };
-    auto put_slab = [&](const RaySlab& r) {
-        put(r.org.x); put(r.org.y); put(r.org.z); put(r.dir.x); put(r.dir.y); put(r.dir.z);
-        put(r.invdir.x); put(r.invdir.y); put(r.invdir.z); put(r.oxinvdir.x); put(r.oxinvdir.y); put(r.oxinvdir.z);
-        put(r.finite ? 1.0F : 0.0F);
-    };
-    put_slab(w.wray); put_slab(w.ray);
-    put(w.hit.t); put(__int_as_float(w.hit.objid)); put(__int_as_float(w.hit.tri)); put(w.hit.a); put(w.hit.b);
-    put(__int_as_float(w.hit.meshid)); put(w.t_max); put(w.stop_t); put(__uint_as_float(w.payload));
-    put(__int_as_float(w.node)); put(__int_as_float(w.objid)); put(__int_as_float(w.meshid));
-    put(__int_as_float(w.top_hit)); put(__int_as_float(w.top_miss));
-    if (COUNT) { put(__uint_as_float(cnt->ray_nodes)); put(__uint_as_float(cnt->ray_tris)); }
-}
-// The loads are spelled as in-place `ds_read_b32` with the destination tied to the field's current register: written as plain
-// C++ the conditional redefinition of all 40 fields makes the register allocator keep a second copy of the walk across the
-// hot loop (80 -> 115 VGPRs, 6 -> 4 waves per SIMD) although the receiving lanes' old values are dead.
-#define ATN_LDS_LOAD_INPLACE(field, idx) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(field) : "v"(addr), "n"((idx) * kTailDonateLanes * 4))
-template <bool COUNT>
-ATN_DEV void tail_unpark(const float* pool, uint32_t k, Walk& w, TravCounters* cnt)
-{
-    const uint32_t addr = (uint32_t)(uintptr_t)(pool + k);     // LDS byte address (the low 32 bits of a __shared__ pointer)
-    float fin_w, fin_r;
-    fin_w = 0.0F; fin_r = 0.0F;
-    ATN_LDS_LOAD_INPLACE(w.wray.org.x, 0); ATN_LDS_LOAD_INPLACE(w.wray.org.y, 1); ATN_LDS_LOAD_INPLACE(w.wray.org.z, 2);
-    ATN_LDS_LOAD_INPLACE(w.wray.dir.x, 3); ATN_LDS_LOAD_INPLACE(w.wray.dir.y, 4); ATN_LDS_LOAD_INPLACE(w.wray.dir.z, 5);
-    ATN_LDS_LOAD_INPLACE(w.wray.invdir.x, 6); ATN_LDS_LOAD_INPLACE(w.wray.invdir.y, 7); ATN_LDS_LOAD_INPLACE(w.wray.invdir.z, 8);
-    ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.x, 9); ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.y, 10); ATN_LDS_LOAD_INPLACE(w.wray.oxinvdir.z, 11);
-    ATN_LDS_LOAD_INPLACE(fin_w, 12);
-    ATN_LDS_LOAD_INPLACE(w.ray.org.x, 13); ATN_LDS_LOAD_INPLACE(w.ray.org.y, 14); ATN_LDS_LOAD_INPLACE(w.ray.org.z, 15);
-    ATN_LDS_LOAD_INPLACE(w.ray.dir.x, 16); ATN_LDS_LOAD_INPLACE(w.ray.dir.y, 17); ATN_LDS_LOAD_INPLACE(w.ray.dir.z, 18);
-    ATN_LDS_LOAD_INPLACE(w.ray.invdir.x, 19); ATN_LDS_LOAD_INPLACE(w.ray.invdir.y, 20); ATN_LDS_LOAD_INPLACE(w.ray.invdir.z, 21);
-    ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.x, 22); ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.y, 23); ATN_LDS_LOAD_INPLACE(w.ray.oxinvdir.z, 24);
-    ATN_LDS_LOAD_INPLACE(fin_r, 25);
-    ATN_LDS_LOAD_INPLACE(w.hit.t, 26); ATN_LDS_LOAD_INPLACE(w.hit.objid, 27); ATN_LDS_LOAD_INPLACE(w.hit.tri, 28);
-    ATN_LDS_LOAD_INPLACE(w.hit.a, 29); ATN_LDS_LOAD_INPLACE(w.hit.b, 30); ATN_LDS_LOAD_INPLACE(w.hit.meshid, 31);
-    ATN_LDS_LOAD_INPLACE(w.t_max, 32); ATN_LDS_LOAD_INPLACE(w.stop_t, 33); ATN_LDS_LOAD_INPLACE(w.payload, 34);
-    ATN_LDS_LOAD_INPLACE(w.node, 35); ATN_LDS_LOAD_INPLACE(w.objid, 36); ATN_LDS_LOAD_INPLACE(w.meshid, 37);
-    ATN_LDS_LOAD_INPLACE(w.top_hit, 38); ATN_LDS_LOAD_INPLACE(w.top_miss, 39);
-    if (COUNT) { ATN_LDS_LOAD_INPLACE(cnt->ray_nodes, 40); ATN_LDS_LOAD_INPLACE(cnt->ray_tris, 41); }
-    // the tied operands carry the dependence: nothing may read a field before the loads have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w.node), "+v"(w.t_max), "+v"(fin_w), "+v"(fin_r) :: "memory");
-    w.wray.finite = fin_w != 0.0F; w.ray.finite = fin_r != 0.0F;
-}
 
 template <bool COUNT, class Job, bool LDSN = false>
-ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treelet, uint32_t count, uint32_t* fetch_counter,
+ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)
 {
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
-    const uint32_t treelet_bytes = sc.treelet_bytes;
     const uint32_t lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     float4 (*stage)[2] = sh.stage[threadIdx.x >> 6];
@@ -760,8 +482,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     bool first_chunk = true;            // wave-uniform
-    bool can_donate = true;             // wave-uniform: false once this wave found itself the last one running in its block
-    const int my_wave = (int)(threadIdx.x >> 6);
     bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
 
     Walk w;
@@ -771,9 +491,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
     w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
     w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
     w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
-#if ATN_LEAF_STASH
-    w.stash = kLinkEnd; w.sq0 = make_float4(0, 0, 0, 0); w.sq1 = w.sq0;
-#endif
 
     for (;;) {
         // ---- refill
@@ -819,58 +536,11 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, const char* treel
                 c_next += n_idle < avail ? n_idle : avail;
                 all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
             }
-            else if (ATN_TAIL_MERGE) {
-                // queue drained, chunk used up: walks another wave of the block parked, if any, go to the idle lanes (one donor
-                // per pass: with lanes still idle the next pass comes back here)
-                uint32_t idle_left = n_idle;
-                if (__builtin_expect(tail_pending(sh) != 0u, 0)) {
-                    __threadfence_block();
-                    int donor = -1;
-                    uint32_t first = 0, got = 0;
-#pragma unroll 1
-                    for (int d = 0; d < kTraceWavesPerBlock; d++) {
-                        if (d == my_wave) continue;
-                        const uint32_t have = __atomic_load_n(&sh.don_count[d], __ATOMIC_RELAXED);
-                        if (!have) continue;
-                        uint32_t f = 0;
-                        if (lane == 0) f = atomicAdd(&sh.don_taken[d], n_idle);
-                        f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-                        if (f >= have) continue;
-                        donor = d; first = f; got = have - f < n_idle ? have - f : n_idle;
-                        break;
-                    }
-                    if (donor >= 0) {
-                        if (lane == 0) atomicSub(&sh.ctrl, got);
-                        const float* pool = reinterpret_cast<const float*>(sh.stage[donor]);
-                        const uint32_t k = (uint32_t)__popcll(m_idle & lt);          // my rank among the idle lanes
-                        if (w.node == kLinkEnd && k < got) tail_unpark<COUNT>(pool, first + k, w, cnt);
-                        idle_left = n_idle - got;
-                        all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
-                    }
-                }
-                if (idle_left == 64u) {
-                    if (tail_try_exit(sh)) break;       // nothing in flight anywhere we could still be handed
-                    continue;                           // a donation landed in between: take it
-                }
-            }
             else if (n_idle == 64u) {
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        if (ATN_TAIL_MERGE && __builtin_expect(drained && can_donate && c_next >= c_count, 0)) {
-            const unsigned long long m_live = __ballot(w.node != kLinkEnd);
-            const uint32_t n_live = (uint32_t)__popcll(m_live);
-            if (n_live > 0 && n_live <= kTailDonateLanes) {
-                float* pool = reinterpret_cast<float*>(sh.stage[my_wave]);
-                if (w.node != kLinkEnd) tail_park<COUNT>(pool, (uint32_t)__popcll(m_live & lt), w, cnt);
-                if (lane == 0) __atomic_store_n(&sh.don_count[my_wave], n_live, __ATOMIC_RELAXED);
-                __threadfence_block();
-                if (tail_try_publish(sh, n_live)) break;            // the walks live on in other waves of the block
-                if (lane == 0) __atomic_store_n(&sh.don_count[my_wave], 0u, __ATOMIC_RELAXED);      // last wave running: it finishes them itself
-                can_donate = false;
-            }
-        }
-        walk_iteration<COUNT, (!LDSN && kTreeletMaxBytes > 0 && ATN_TREELET_LDS != 0), kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, treelet, treelet_bytes, t_min, job, cnt);
+        walk_iteration<COUNT, kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
     }
 }
 

@@ -13,9 +13,9 @@ namespace atn {
 struct HostSceneImage {
     std::vector<float4> nodes;          // the byte image of all records (16-byte units)
     uint64_t n_nodes = 0;
-    std::vector<uint32_t> list_root;    // byte offset of each list's first non-treelet record
+    std::vector<uint32_t> list_root;    // byte offset of each list's first record
     std::vector<int32_t> list_root_link; // typed link of each list's root
-    std::vector<uint32_t> list_bytes;   // bytes of each list's contiguous region starting at list_root (treelet records excluded)
+    std::vector<uint32_t> list_bytes;   // bytes of each list's contiguous region starting at list_root
     std::vector<uint32_t> list_tri_leaves, list_inner;  // record counts of each list
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
@@ -67,7 +67,6 @@ struct ListLayout {
     std::vector<uint8_t> kind;          // by walk position
     std::vector<int32_t> depth;         // by walk position
     std::vector<uint32_t> offset;       // by walk position: byte offset of the record in the device image
-    std::vector<uint8_t> in_treelet;    // by walk position
 };
 
 // Validates a list (reachability, forward links, the structural rules the walk relies on) and fills order/kind/depth.
@@ -75,7 +74,7 @@ inline bool analyse_list(ListLayout& L, const atn_bvh_node* src, uint32_t count,
 {
     if (!walk_order(src, count, L.new_index, L.order, err)) return false;
     const uint32_t n = (uint32_t)L.order.size();
-    L.kind.assign(n, KIND_INNER); L.depth.assign(n, 0); L.offset.assign(n, 0); L.in_treelet.assign(n, 0);
+    L.kind.assign(n, KIND_INNER); L.depth.assign(n, 0); L.offset.assign(n, 0);
     std::vector<uint32_t> open_end;     // walk positions at which the open subtrees end (a stack)
     for (uint32_t j = 0; j < n; j++) {
         const atn_bvh_node& nd = src[L.order[j]];
@@ -216,11 +215,7 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
     return true;
 }
 
-// Node image (bytes): [treelet | BLAS list 1 | BLAS list 2 | ... | top layer (list 0)].
-//  * treelet = the inner nodes nearest the roots of the bottom-level trees, level by level over all of them, at most
-//    kTreeletMaxBytes: the region the persistent trace kernel keeps in LDS (on sponza_lod the top 10 levels, 1023
-//    nodes = 32 KB, receive 65-78 % of all node visits).  Because it is an address range, any kernel can equally
-//    read it from global memory: there is one set of links.
+// Node image (bytes): [BLAS list 1 | BLAS list 2 | ... | top layer (list 0)].
 //  * every list in walk order (locality; the links are explicit, so correctness does not depend on it)
 //  * the top layer comes last so that update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it
 //    without moving the others; top-layer records are all kInnerBytes long.
@@ -237,27 +232,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         if (!analyse_list(lay[k], s->bvh_lists[k].nodes, s->bvh_lists[k].count, k == 0, err)) return false;
         total_nodes += lay[k].order.size();
     }
-    // treelet: bottom-level inner nodes by depth, whole levels first, then the walk-order head of the next level
-    uint32_t treelet_nodes = 0;
-    {
-        const uint32_t budget = kTreeletMaxBytes / kInnerBytes;
-        for (int32_t d = 0; treelet_nodes < budget; d++) {
-            bool any_deeper = false;
-            for (uint32_t k = 1; k < nl && treelet_nodes < budget; k++) {
-                ListLayout& L = lay[k];
-                for (uint32_t j = 0; j < L.order.size() && treelet_nodes < budget; j++) {
-                    if (L.depth[j] >= d && L.kind[j] == KIND_INNER) any_deeper = true;
-                    if (L.depth[j] == d && L.kind[j] == KIND_INNER) { L.in_treelet[j] = 1; treelet_nodes++; }
-                }
-            }
-            if (!any_deeper) break;
-        }
-    }
     uint64_t off = 0;
-    for (uint32_t k = 1; k < nl; k++)
-        for (uint32_t j = 0; j < lay[k].order.size(); j++)
-            if (lay[k].in_treelet[j]) { lay[k].offset[j] = (uint32_t)off; off += kInnerBytes; }
-    const uint64_t treelet_bytes = off;
     img.list_root.assign(nl, 0);
     img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0);
     for (uint32_t kk = 1; kk <= nl; kk++) {
@@ -268,7 +243,6 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             else if (lay[k].kind[j] == KIND_INNER) img.list_inner[k]++;
         }
         for (uint32_t j = 0; j < lay[k].order.size(); j++) {
-            if (lay[k].in_treelet[j]) continue;
             if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
             lay[k].offset[j] = (uint32_t)off;
             off += record_bytes(lay[k].kind[j]);
@@ -293,7 +267,6 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         img.list_root_link[k] = root;
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
-    img.params.treelet_bytes = (uint32_t)treelet_bytes;
     img.params.node_bytes = (uint32_t)off;
 
     // ---- plain copies
@@ -371,24 +344,15 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         }
         const bool unorm8 = fmt != 0;
         img.textures[i].width = t.width; img.textures[i].height = t.height;
-        // texel (x, y) goes to tex_texel_index(): 64-byte sectors of 4 x 4 / 2 x 2 texels (scene_dev.hpp); padding texels are 0
-        const size_t ns = tex_storage_texels(t.width, t.height, fmt);
         if (unorm8) {
             img.textures[i].offset = (uint32_t)at8; img.textures[i].format = fmt;
-            img.texels8.resize(at8 + ns, 0u);
-            for (int32_t y = 0; y < t.height; y++)
-                for (int32_t x = 0; x < t.width; x++)
-                    img.texels8[at8 + tex_texel_index(t.width, fmt, x, y)] = packed[(size_t)y * t.width + x];
+            img.texels8.insert(img.texels8.end(), packed.begin(), packed.end());
         }
         else {
             const size_t at = img.texels.size();
             img.textures[i].offset = (uint32_t)at; img.textures[i].format = 0;
-            img.texels.resize(at + ns, make_float4(0, 0, 0, 0));
-            for (int32_t y = 0; y < t.height; y++)
-                for (int32_t x = 0; x < t.width; x++) {
-                    const atn_vec4& c = t.texels[(size_t)y * t.width + x];
-                    img.texels[at + tex_texel_index(t.width, 0, x, y)] = make_float4(c.x, c.y, c.z, c.w);
-                }
+            img.texels.resize(at + n);
+            for (size_t j = 0; j < n; j++) img.texels[at + j] = make_float4(t.texels[j].x, t.texels[j].y, t.texels[j].z, t.texels[j].w);
         }
     }
 

@@ -303,15 +303,15 @@ class PathTracing:
         self._check(self._l.atn_compact(self._ctx, flags.ctypes.data, len(flags), out.ctypes.data, C.byref(cnt)))
         return out[:cnt.value]
 
-    def compact2(self, flags_a, flags_b=None, grid_blocks=0, binned=False):
+    def compact2(self, flags_a, flags_b=None, grid_blocks=0):
         """The renderer's two-queue block append over caller flags; returns the queues in device order."""
         fa = np.ascontiguousarray(flags_a, np.int32)
         fb = np.ascontiguousarray(flags_b, np.int32) if flags_b is not None else None
         n = len(fa)
         oa = np.zeros(max(1, n), np.int32); ob = np.zeros(max(1, n), np.int32)
         ca = C.c_uint32(); cb = C.c_uint32()
-        self._check(self._l.atn_compact3(self._ctx, fa.ctypes.data, fb.ctypes.data if fb is not None else None, n, grid_blocks,
-                                         1 if binned else 0, oa.ctypes.data, C.byref(ca), ob.ctypes.data if fb is not None else None,
+        self._check(self._l.atn_compact2(self._ctx, fa.ctypes.data, fb.ctypes.data if fb is not None else None, n, grid_blocks,
+                                         oa.ctypes.data, C.byref(ca), ob.ctypes.data if fb is not None else None,
                                          C.byref(cb) if fb is not None else None))
         return oa[:ca.value], (ob[:cb.value] if fb is not None else None)
 

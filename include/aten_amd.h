@@ -318,10 +318,6 @@ int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* ou
  * picks the renderer's launch geometry; any other value forces that many 256-thread blocks (grid-stride path). */
 int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
                  int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b);
-/* Same; binned != 0 selects the bin-major form of the append k_shade uses for its ray queues (entry i's bin =
- * (flag - 1) & 7: inside the range a 1024-entry chunk reserves, entries are grouped by bin). */
-int atn_compact3(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks, int32_t binned,
-                 int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b);
 
 /* ABI self-description for binding checks. */
 uint32_t atn_sizeof_scene_desc(void);

@@ -2168,6 +2168,31 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
     return ATN_OK;
 }
 
+int atn_material_eval(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi, const float* wo, const float* uv, float* out_eval)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+    if (mtrl_id < 0 || mtrl_id >= r.scene.n_materials || n == 0) return r.fail(ATN_ERR_INVALID_ARG, "bad material id / count");
+    if (!nrm || !wi || !wo || !uv || !out_eval) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
+    return guarded(ctx, [&]() -> int {
+        C_HIP(r, hipSetDevice(r.device));
+        atn::DevBuf<float> dn, dw, dwo, duv, de;
+        C_HIP(r, dn.resize(3 * (size_t)n)); C_HIP(r, dw.resize(3 * (size_t)n)); C_HIP(r, dwo.resize(3 * (size_t)n));
+        C_HIP(r, duv.resize(2 * (size_t)n)); C_HIP(r, de.resize(5 * (size_t)n));
+        C_HIP(r, hipMemcpyAsync(dn.p, nrm, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        C_HIP(r, hipMemcpyAsync(dw.p, wi, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        C_HIP(r, hipMemcpyAsync(dwo.p, wo, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        C_HIP(r, hipMemcpyAsync(duv.p, uv, 8 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+        hipLaunchKernelGGL(atn::k_material_eval, dim3((n + 255) / 256), dim3(256), 0, r.stream, r.scene, mtrl_id, n,
+                           (const float*)dn.p, (const float*)dw.p, (const float*)dwo.p, (const float*)duv.p, de.p);
+        C_HIP(r, hipGetLastError());
+        C_HIP(r, hipMemcpyAsync(out_eval, de.p, 20 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+        C_HIP(r, hipStreamSynchronize(r.stream));
+        return ATN_OK;
+    });
+}
+
 int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags_b_host, uint32_t n, uint32_t grid_blocks,
                  int32_t* out_a_host, uint32_t* out_count_a, int32_t* out_b_host, uint32_t* out_count_b)
 {

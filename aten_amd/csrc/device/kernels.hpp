@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
 {
     const uint32_t count = pb.q_count[bounce];
     const ClosestJob job{ pb, pb.queue[bounce & 1], kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
+    TravCounters tc{};
     trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_closest[bounce], job, &tc);
     if (COUNT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[0], (unsigned long long)count);
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
 {
     const uint32_t count = pb.sh_count[bounce];
     const ShadowJob<true> job{ pb, sc, kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
+    TravCounters tc{};
     trace_dispatch<COUNT, REFILL>(sc, count, &pb.fetch_shadow[bounce], job, &tc);
     if (COUNT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.stats[1], (unsigned long long)count);
@@ -767,7 +767,7 @@ __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
+    TravCounters tc{};
     trace_dispatch<false, REFILL, FusedJob<ALPHA>, LDSN>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }
 
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
                                                      unsigned long long* stats)
 {
     const BatchJob job{ sc, rays, out, t_min, t_max };
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.ray_nodes = 0; tc.ray_tris = 0;
+    TravCounters tc{};
     trace_dispatch<COUNT, REFILL>(sc, n, reinterpret_cast<uint32_t*>(&stats[7]), job, &tc);     // stats[7]: zeroed fetch cursor
     if (COUNT) { wave_add_stat(&stats[3], tc.nodes); wave_add_stat(&stats[4], tc.tris); }
 }
@@ -944,6 +944,23 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
     const float p = material_pdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1], mtrl_id);
     const MtrlSample ev = material_bsdf(sc, m, N, WI, ms.dir, uv[2 * i], uv[2 * i + 1], mtrl_id, pre_r);
     float* e = out_eval + 5 * i;
+    e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
+}
+
+// material::samplePDF / sampleBSDF (material_impl.h:90-206) at CALLER-GIVEN outgoing directions: what the oracle-independent
+// invariants integrate (the pdf over the sphere, bsdf * cos over the hemisphere; tests/test_gpu_invariants.py)
+__global__ void __launch_bounds__(256) k_material_eval(DevScene sc, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi, const float* wo,
+                                                       const float* uv, float* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial m = sc.materials[mtrl_id];
+    const f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    const f3 WI = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    const f3 WO = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+    const float p = material_pdf(sc, m, N, WI, WO, uv[2 * i], uv[2 * i + 1], mtrl_id);
+    const MtrlSample ev = material_bsdf(sc, m, N, WI, WO, uv[2 * i], uv[2 * i + 1], mtrl_id, 0.0F);
+    float* e = out + 5 * i;
     e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
 }
 

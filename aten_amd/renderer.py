@@ -296,6 +296,16 @@ class PathTracing:
                                                s.ctypes.data, e.ctypes.data))
         return s, e
 
+    def material_eval(self, mtrl_id, nrm, wi, wo, uv=None):
+        """samplePDF / sampleBSDF at given outgoing directions -> [n, 5] {pdf, bsdf.xyz, bsdf's own pdf}."""
+        n = len(wo)
+        b = lambda a, k: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32), (n, k)))
+        nrm, wi, wo = b(nrm, 3), b(wi, 3), b(wo, 3)
+        uv = b(uv if uv is not None else (0.5, 0.5), 2)
+        e = np.zeros((n, 5), np.float32)
+        self._check(self._l.atn_material_eval(self._ctx, mtrl_id, n, nrm.ctypes.data, wi.ctypes.data, wo.ctypes.data, uv.ctypes.data, e.ctypes.data))
+        return e
+
     def compact(self, flags):
         flags = np.ascontiguousarray(flags, np.int32)
         out = np.zeros(max(1, len(flags)), np.int32)

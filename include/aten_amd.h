@@ -308,6 +308,11 @@ int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
                        const uint32_t* index, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval);
+/* material::samplePDF / sampleBSDF (material_impl.h:90-206) at caller-given outgoing directions wo (n * 3):
+ * out_eval n*5 {samplePDF, sampleBSDF.bsdf.xyz, sampleBSDF.pdf}.  For invariants that need no oracle (the pdf integrates to
+ * one, sampled directions follow it, bsdf * cos stays below one). */
+int atn_material_eval(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi, const float* wo,
+                      const float* uv, float* out_eval);
 /* Stable compaction of indices with flag > 0 (contract of idaten::StreamCompaction::compact,
  * src/libidaten/kernel/StreamCompaction.cu:175-316): the renderer's own queue append (one ballot + popcount
  * prefix per wave, one atomic per 1024-entry block chunk -- the call k_shade makes) followed by a host sort,

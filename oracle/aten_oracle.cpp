@@ -294,6 +294,25 @@ void orc_svgf_destroy(void* h) { delete static_cast<svgf::Params*>(h); }
 void orc_svgf_set_atrous_iterations(void* h, int32_t n) { static_cast<svgf::Params*>(h)->atrous_iter_cnt = n; }
 void orc_svgf_set_dilate_temporal_weight(void* h, int32_t on) { static_cast<svgf::Params*>(h)->dilate_temporal_weight = on; }
 
+// aten::FillBasicAOVs / FillBasicAOVsIfHitMiss (renderer/aov.h:158-198) on their own, for the reference's known answers
+// (aten_unittest/aov_host_buffer.cpp:73-132).  w2c: 16 floats, row-major (aten::mat4)
+void orc_fill_basic_aovs(const float* normal, const float* p, const float* w2c, const float* albedo, int32_t meshid, float* out_nd, float* out_am)
+{
+    m4 m;
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m.m[r][c] = w2c[4 * r + c];
+    v4 nd, am;
+    svgf::FillBasicAOVs(nd, v3(normal[0], normal[1], normal[2]), v3(p[0], p[1], p[2]), m, am, v4(albedo[0], albedo[1], albedo[2], albedo[3]), meshid);
+    out_nd[0] = nd.x; out_nd[1] = nd.y; out_nd[2] = nd.z; out_nd[3] = nd.w;
+    out_am[0] = am.x; out_am[1] = am.y; out_am[2] = am.z; out_am[3] = am.w;
+}
+void orc_fill_basic_aovs_if_hit_miss(const float* bg, float* out_nd, float* out_am)
+{
+    v4 nd, am;
+    svgf::FillBasicAOVsIfHitMiss(nd, am, v4(bg[0], bg[1], bg[2], bg[3]));
+    out_nd[0] = nd.x; out_nd[1] = nd.y; out_nd[2] = nd.z; out_nd[3] = nd.w;
+    out_am[0] = am.x; out_am[1] = am.y; out_am[2] = am.z; out_am[3] = am.w;
+}
+
 // SVGFRenderer::SetMotionDepthBuffer (svgf.cpp:441-450): vec4 {motion.xy in screen fractions, depth, 1} per pixel
 void orc_svgf_set_motion_depth(void* h, const atn_vec4* md, uint32_t n)
 {

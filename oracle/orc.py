@@ -187,6 +187,24 @@ def lbvh_hierarchy(sorted_keys):
     return l, r, p
 
 
+def fill_basic_aovs(normal, p, w2c, albedo, meshid):
+    """aten::FillBasicAOVs (renderer/aov.h:158-181) -> (normal_depth[4], albedo_meshid[4])."""
+    f = lambda a, n: np.ascontiguousarray(a, np.float32).reshape(n)
+    nd, am = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    a, b, c, d = f(normal, 3), f(p, 3), f(w2c, 16), f(albedo, 4)
+    lib().orc_fill_basic_aovs(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data),
+                              C.c_int32(meshid), C.c_void_p(nd.ctypes.data), C.c_void_p(am.ctypes.data))
+    return nd, am
+
+
+def fill_basic_aovs_if_hit_miss(bg):
+    """aten::FillBasicAOVsIfHitMiss (renderer/aov.h:183-198)."""
+    nd, am = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    b = np.ascontiguousarray(bg, np.float32).reshape(4)
+    lib().orc_fill_basic_aovs_if_hit_miss(C.c_void_p(b.ctypes.data), C.c_void_p(nd.ctypes.data), C.c_void_p(am.ctypes.data))
+    return nd, am
+
+
 class Svgf:
     """aten::SVGFRenderer on the CPU oracle (oracle/orc_svgf.h): frame-persistent AOV / moment buffers."""
     BUFFERS = dict(normal_depth=0, albedo_meshid=1, color_variance=2, moment_temporalweight=3,

@@ -121,14 +121,43 @@ struct Params {         // SVGFParams<std::vector<vec4>> + the renderer's frame-
     }
 };
 
-// FillBasicAOVs (aov.h:158-181) + "aov_albedo_meshid[idx].w = isect.mtrlid" (svgf.cpp:131,147)
+// FillBasicAOVs (aov.h:158-181); known answers: aten_unittest/aov_host_buffer.cpp:73-108 (tests/test_oracle_svgf_cpu.py)
+inline void FillBasicAOVs(v4& aovNormalDepth, const v3& normal, const v3& rec_p, const m4& mtx_W2C, v4& aovAlbedoMeshId,
+    const v4& albedo, int32_t isect_meshid)
+{
+    // World coordinate to Clip coordinate.
+    v4 pos(rec_p, 1);
+    pos = mtx_W2C.apply(pos);
+
+    aovNormalDepth.x = normal.x;
+    aovNormalDepth.y = normal.y;
+    aovNormalDepth.z = normal.z;
+    aovNormalDepth.w = pos.w;
+
+    aovAlbedoMeshId.x = albedo.x;
+    aovAlbedoMeshId.y = albedo.y;
+    aovAlbedoMeshId.z = albedo.z;
+    aovAlbedoMeshId.w = static_cast<float>(isect_meshid);
+}
+
+// FillBasicAOVsIfHitMiss (aov.h:183-198); known answers: aov_host_buffer.cpp:110-132
+inline void FillBasicAOVsIfHitMiss(v4& aovNormalDepth, v4& aovAlbedoMeshId, const v4& bg)
+{
+    aovNormalDepth.x = 0.0F;
+    aovNormalDepth.y = 0.0F;
+    aovNormalDepth.z = 0.0F;
+    aovNormalDepth.w = -1;
+
+    aovAlbedoMeshId.x = bg.x;
+    aovAlbedoMeshId.y = bg.y;
+    aovAlbedoMeshId.z = bg.z;
+    aovAlbedoMeshId.w = -1;
+}
+
+// SVGFRenderer::Shade's use of it: FillBasicAOVs, then "aov_albedo_meshid[idx].w = isect.mtrlid" (svgf.cpp:128-131,144-147)
 inline void FillAOVs(v4& nd, v4& am, const v3& normal, const HitRec& rec, const m4& W2C, const v4& texcolor, const Isect& isect)
 {
-    v4 pos(rec.p, 1);
-    pos = W2C.apply(pos);
-    nd.x = normal.x; nd.y = normal.y; nd.z = normal.z; nd.w = pos.w;
-    am.x = texcolor.x; am.y = texcolor.y; am.z = texcolor.z;
-    am.w = static_cast<float>(isect.meshid);
+    FillBasicAOVs(nd, normal, rec.p, W2C, am, texcolor, isect.meshid);
     am.w = static_cast<float>(isect.mtrlid);
 }
 
@@ -199,8 +228,7 @@ inline void ShadeMissAov(int32_t ix, int32_t iy, int32_t width, int32_t height, 
         v4 emit = Background_SampleFromRay(dir, ctxt.cfg().bg, ctxt);
         float misW = 1.0f;
         if (bounce == 0 || (bounce == 1 && path.is_singular)) {
-            aov_nd.x = 0.0f; aov_nd.y = 0.0f; aov_nd.z = 0.0f; aov_nd.w = -1;
-            aov_am.x = emit.x; aov_am.y = emit.y; aov_am.z = emit.z; aov_am.w = -1;
+            FillBasicAOVsIfHitMiss(aov_nd, aov_am, emit);
         }
         else {
             float pdfLight = IBL_samplePdf(emit.xyz(), ctxt.cfg().bg.avgIllum);

@@ -35,6 +35,43 @@ def test_mt19937_seeds(orc, golden):
     assert np.array_equal(orc.init_sampler(64, 64, 0), s[:4096])
 
 
+def test_reference_sbvh_pins_the_ingestion_triangle_numbering():
+    """asset/sponza/sponza_lod.sbvh was written by the reference (sbvh::exportTree, accelerator/sbvh.cpp:1237-1338) from the
+    triangles ITS ObjLoader (libatenscene/ObjLoader.cpp:95-461) produced for sponza_lod.obj, and every leaf carries the
+    object-local id of its triangle.  So the file pins our ingestion (native obj_ingest.cpp through SceneBuilder.load_obj)
+    from outside: leaf k's box must lie inside the bounding box of OUR triangle number triid(k) -- spatial-split leaves are
+    clipped to the split planes, the others are the triangle's own box bit for bit -- every triangle must be named by some
+    leaf, and the root box must be the vertex bounds.  A different triangulation order, corner order or shape order in the
+    loader would break all of these."""
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.builder import read_sbvh
+    fs, _ = scenedefs.sponza_lod(textures=False, ibl=False)
+    tris, pos = fs.arrays["triangles"], fs.arrays["vtx_pos"][:, :3]
+    obj = fs.arrays["objects"][0]
+    assert obj["triangle_id"] == 0 and obj["triangle_num"] == len(tris) == 12852
+    hdr, _, nodes = read_sbvh(os.path.join(ROOT, "assets", "sponza", "sponza_lod.sbvh"))
+    leaf = nodes["f1"] >= 0
+    tid = nodes["f1"][leaf].astype(np.int64)
+    assert leaf.sum() == 19000 and tid.min() == 0 and tid.max() == len(tris) - 1
+    assert len(np.unique(tid)) == len(tris)                  # every triangle of the object is referenced
+    corners = pos[tris["idx"][tid]]                          # [leaf, corner, xyz]
+    tmin, tmax = corners.min(axis=1), corners.max(axis=1)
+    bmin, bmax = nodes["boxmin"][leaf], nodes["boxmax"][leaf]
+    # inside the triangle's box (exact compare: a clip plane lies between the triangle's extremes, an unclipped side IS the extreme)
+    assert np.all(bmin >= tmin) and np.all(bmax <= tmax)
+    assert np.all(bmin <= bmax)
+    same = np.all(bmin == tmin, axis=1) & np.all(bmax == tmax, axis=1)
+    assert same.mean() >= 0.40, same.mean()                  # measured 0.467: the leaves spatial splits did not touch
+    # a triangle referenced once was never split: its single leaf box is its own box
+    cnt = np.bincount(tid, minlength=len(tris))
+    once = cnt[tid] == 1
+    assert once.sum() > 5000 and np.all(same[once])
+    # the root box and the file header are the vertex bounds of the object, bit for bit
+    vmin, vmax = pos[np.unique(tris["idx"])].min(axis=0), pos[np.unique(tris["idx"])].max(axis=0)
+    assert np.array_equal(nodes["boxmin"][0], vmin) and np.array_equal(nodes["boxmax"][0], vmax)
+    assert np.array_equal(np.float32(hdr["boxmin"]), vmin) and np.array_equal(np.float32(hdr["boxmax"]), vmax)
+
+
 def test_sbvh_fixture_from_reference_asset():
     """asset/sponza/sponza_lod.sbvh is a reference-written file (format accelerator/sbvh.cpp:1220-1338)."""
     from aten_amd.scene.builder import read_sbvh

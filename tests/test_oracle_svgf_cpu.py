@@ -14,6 +14,26 @@ def _golden_module():
     return m
 
 
+def test_aov_packing_known_answers_from_reference_unittest(orc):
+    """src/aten_unittest/aov_host_buffer.cpp:73-108 `FillBasicAOVsTest` and :110-132 `FillBasicAOVsIfHitMissTest`, restated:
+    normal (1,2,3), rec.p = vec4(1), identity mtx_W2C, albedo (4,5,6,7), isect.meshid = 2
+      -> normal_depth == (normal.xyz, rec.p.z), albedo_meshid == (albedo.xyz, meshid)      (ASSERT_EQ: exact)
+    bg (4,5,6,7) -> normal_depth == (0,0,0,-1), albedo_meshid == (bg.xyz, -1).
+    The reference's own known answer for the SVGF AOV packing; the GPU planes are held to the same numbers
+    in tests/test_gpu_invariants.py::test_svgf_aov_planes_known_answers."""
+    normal, p, albedo = (1.0, 2.0, 3.0), (1.0, 1.0, 1.0), (4.0, 5.0, 6.0, 7.0)
+    nd, am = orc.fill_basic_aovs(normal, p, np.eye(4, dtype=np.float32), albedo, 2)
+    assert nd.tolist() == [1.0, 2.0, 3.0, 1.0]          # .w == rec.p.z (== clip w of (1,1,1,1) under identity)
+    assert am.tolist() == [4.0, 5.0, 6.0, 2.0]
+    # beyond the unit test's identity: depth is the CLIP-space w, i.e. row 3 of W2C applied to (p, 1) (aov.h:166-168)
+    m = np.arange(16, dtype=np.float32).reshape(4, 4)
+    nd, _ = orc.fill_basic_aovs(normal, (2.0, 3.0, 5.0), m, albedo, 2)
+    assert nd[3] == np.float32(12 * 2 + 13 * 3 + 14 * 5 + 15)
+    nd, am = orc.fill_basic_aovs_if_hit_miss((4.0, 5.0, 6.0, 7.0))
+    assert nd.tolist() == [0.0, 0.0, 0.0, -1.0]
+    assert am.tolist() == [4.0, 5.0, 6.0, -1.0]
+
+
 def test_svgf_oracle_matches_committed_vectors():
     want = np.load(os.path.join(GOLDEN, "svgf_golden.npz"))
     got = _golden_module().run()

@@ -103,7 +103,7 @@ def lib():
         l.atn_trace_closest.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, vp, vp]
         l.atn_cmj_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
         l.atn_cmj_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_int32, vp]
-        l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+        l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.atn_material_eval.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp]
         l.atn_compact.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         l.atn_compact2.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]

@@ -2143,7 +2143,7 @@ int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_
 }
 
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
-                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                       const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval)
 {
     CTX_QUIET_OR_FAIL(ctx);
@@ -2151,16 +2151,17 @@ int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* n
     if (!r.has_scene) return r.fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
     if (mtrl_id < 0 || mtrl_id >= r.scene.n_materials || n == 0) return r.fail(ATN_ERR_INVALID_ARG, "bad material id / count");
     C_HIP(r, hipSetDevice(r.device));
-    atn::DevBuf<float> dn, dw, duv, ds, de; atn::DevBuf<uint32_t> di, dsc;
+    atn::DevBuf<float> dn, dw, duv, ds, de; atn::DevBuf<uint32_t> di, dsc, ddim;
     C_HIP(r, dn.resize(3 * (size_t)n)); C_HIP(r, dw.resize(3 * (size_t)n)); C_HIP(r, duv.resize(2 * (size_t)n));
     C_HIP(r, ds.resize(7 * (size_t)n)); C_HIP(r, de.resize(5 * (size_t)n)); C_HIP(r, di.resize(n)); C_HIP(r, dsc.resize(n));
+    if (dimension) { C_HIP(r, ddim.resize(n)); C_HIP(r, hipMemcpyAsync(ddim.p, dimension, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream)); }
     C_HIP(r, hipMemcpyAsync(dn.p, nrm, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipMemcpyAsync(dw.p, wi, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipMemcpyAsync(duv.p, uv, 8 * (size_t)n, hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipMemcpyAsync(di.p, index, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
     C_HIP(r, hipMemcpyAsync(dsc.p, scramble, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
     hipLaunchKernelGGL(atn::k_material_table, dim3((n + 63) / 64), dim3(64), 0, r.stream, r.scene, mtrl_id, n,
-                       (const float*)dn.p, (const float*)dw.p, (const uint32_t*)di.p, (const uint32_t*)dsc.p, (const float*)duv.p, ds.p, de.p);
+                       (const float*)dn.p, (const float*)dw.p, (const uint32_t*)di.p, (const uint32_t*)(dimension ? ddim.p : nullptr), (const uint32_t*)dsc.p, (const float*)duv.p, ds.p, de.p);
     C_HIP(r, hipGetLastError());
     C_HIP(r, hipMemcpyAsync(out_sample, ds.p, 28 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
     C_HIP(r, hipMemcpyAsync(out_eval, de.p, 20 * (size_t)n, hipMemcpyDeviceToHost, r.stream));

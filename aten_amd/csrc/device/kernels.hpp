@@ -926,13 +926,13 @@ __global__ void __launch_bounds__(256) k_sample_texture(DevScene sc, int32_t tex
 
 // BSDF table: for case i sample at (n, wi) with sampler (index, dim 0, scramble), then re-evaluate pdf/bsdf at the sampled dir
 __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
-                                                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                                                       const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble, const float* uv,
                                                        float* out_sample, float* out_eval)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DevMaterial m = sc.materials[mtrl_id];
-    Cmj s; s.idx = index[i]; s.dim = 0; s.scramble = scramble[i];
+    Cmj s; s.idx = index[i]; s.dim = dimension ? dimension[i] : 0u; s.scramble = scramble[i];
     f3 N = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
     const f3 WI = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
     // CarPaint: material::applyNormal runs first, as in shade (it draws the shared random number and may swap the normal)
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(64) k_material_table(DevScene sc, int32_t mtrl
     e[0] = p; e[1] = ev.bsdf.x; e[2] = ev.bsdf.y; e[3] = ev.bsdf.z; e[4] = ev.pdf;
 }
 
-// material::samplePDF / sampleBSDF (material_impl.h:90-206) at CALLER-GIVEN outgoing directions: what the oracle-independent
+// material::samplePDF / sampleBSDF (material_impl.h:90-206) at CALLER-GIVEN outgoing directions: what the closed-form
 // invariants integrate (the pdf over the sphere, bsdf * cos over the hemisphere; tests/test_gpu_invariants.py)
 __global__ void __launch_bounds__(256) k_material_eval(DevScene sc, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi, const float* wo,
                                                        const float* uv, float* out)

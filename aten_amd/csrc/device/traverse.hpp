@@ -29,8 +29,7 @@ struct Hit {
 
 // nodes / tris: the thread's totals (COUNT instantiations only); ray_*: the same for the walk in progress, handed to
 // Job::cost when the walk finishes (the per-pixel cost map, atn_download_path_cost)
-// spec: node visits of the speculative steps in progress (walk_iteration), added to the other two when they are committed
-struct TravCounters { uint32_t nodes, tris, ray_nodes, ray_tris, spec; };
+struct TravCounters { uint32_t nodes, tris, ray_nodes, ray_tris; };
 
 // Per-ray constants of aabb::hit: invdir = 1 / (dir + 1e-6), oxinvdir = -org * invdir.
 // The reference recomputes them at every node from the same inputs; hoisting is value-identical.
@@ -195,54 +194,25 @@ ATN_DEV void ld32(const char* base, uint32_t byte_off, float4& a, float4& b)
     }
 }
 
-// SPECULATION PAST TRIANGLE LEAVES (r04, the refill walk).  In a threaded list a triangle leaf's hit and miss links are
-// equal (checked at upload): the test decides only t_max, never the next node.  So a lane that reaches a leaf inside a burst
-// need not wait for the leaf step: it PARKS the leaf's link, takes the next link from the record (it rides the burst step's
-// two loads -- a wave load costs the L1 the same whatever its exec mask -- and reads q1.w) and keeps stepping with the OLD
-// t_max.  The leaf step resolves the parked leaf: NOT accepted (t_max unchanged) -> every step taken behind it was the
-// reference's step, the lane simply stands further along; ACCEPTED -> t_max shrank, the steps behind the leaf are dropped and
-// the lane resumes at the leaf's successor, exactly where the non-speculative walk would be.  One leaf may be parked; a lane
-// that meets a second one, a list end or (never, inside a bottom-level list) a TLAS leaf waits as before.  A parked leaf
-// lives only from a burst to the leaf step of the same iteration.  Every ray's COMMITTED sequence of decisions is
-// threaded_bvh_traverser.h:142-304's, so Intersection records and visit counters stay byte-equal (COUNT: speculative visits
-// are tallied apart and added at commit).
-#ifndef ATN_SPEC_LEAVES
-#define ATN_SPEC_LEAVES 1
-#endif
-
+// (SPECULATION past triangle leaves -- a lane that reaches a leaf parks it, keeps stepping with the old t_max and is rolled back
+// when the leaf step accepts the hit -- was built and measured in r04: byte-equal, lane utilisation 0.37 -> 0.42, and 5-6 %
+// SLOWER.  profiles/r04_variants_spec_leaves.txt; the code is in git history, commit "Speculation past
+// triangle leaves".)
 // A burst of inner-node steps, spelled out (no loop counter, compare and branch per step), with ONE form of the slab test
 // (FAST: hardware min/max, valid when every live lane's slab constants are finite; else the select form, valid for all
 // inputs).  See walk_iteration.
-template <bool COUNT, int BURST, bool FAST, bool LDSN, bool SPEC>
-ATN_DEV void inner_burst(Walk& w, int32_t& parked, const char* __restrict__ nb, float t_min, TravCounters* cnt)
+template <bool COUNT, int BURST, bool FAST, bool LDSN>
+ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, float t_min, TravCounters* cnt)
 {
 #pragma unroll
     for (int k = 0; k < BURST; k++) {
-        if constexpr (SPEC) {
-            // who steps: lanes on an inner node, and -- while nothing is parked -- lanes on a triangle leaf.  A parked link has
-            // the leaf bit set (0 = none), kLinkEnd and TLAS-leaf links have kLinkTlasBit set.
-            const int32_t stop_bits = kLinkTlasBit | (parked & kLinkLeafBit);
-            if (!(w.node & stop_bits)) {
-                float4 q0, q1;
-                ld32<LDSN>(nb, (uint32_t)w.node & kLinkOffsetMask, q0, q1);
-                const bool leaf = (w.node & kLinkLeafBit) != 0;
-                // (for a leaf lane the slab arithmetic runs on triangle data; its result is not used)
-                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
-                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                if (COUNT && !leaf) { if (parked) cnt->spec++; else { cnt->nodes++; cnt->ray_nodes++; } }
-                if (leaf) parked = w.node;
-                w.node = __float_as_int((box && !leaf) ? q0.w : q1.w);      // leaf: q1.w is its one link
-            }
-        }
-        else {
-            if (!(w.node & kLinkTypeMask)) {
-                float4 q0, q1;
-                ld32<LDSN>(nb, (uint32_t)w.node, q0, q1);       // type bits are 0: the link is the byte offset
-                if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-                const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
-                                      : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
-                w.node = __float_as_int(box ? q0.w : q1.w);
-            }
+        if (!(w.node & kLinkTypeMask)) {
+            float4 q0, q1;
+            ld32<LDSN>(nb, (uint32_t)w.node, q0, q1);       // type bits are 0: the link is the byte offset
+            if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+            const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
+                                  : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
+            w.node = __float_as_int(box ? q0.w : q1.w);
         }
     }
 }
@@ -253,13 +223,13 @@ ATN_DEV void inner_burst(Walk& w, int32_t& parked, const char* __restrict__ nb, 
 // Why: at any moment only ~7 of 64 lanes stand on a leaf (one visit in nine), so a loop that offers every node kind on
 // every iteration issues the ~75-instruction triangle block each time for a handful of lanes, and drags the leave /
 // finish (and refill) bookkeeping -- ~60 scalar instructions -- through every inner-node step.  Here the triangle block
-// runs once per burst with several times the lanes, and the inner-node step is ~30 VALU + ~15 SALU.  Without SPEC a lane
-// that reaches a leaf waits, masked off, for the end of the burst; with it, see above.
+// runs once per burst with several times the lanes, and the inner-node step is ~30 VALU + ~15 SALU; a lane that reaches a
+// leaf waits, masked off, for the end of the burst.
 // The slab test takes ONE of its two forms per wave, chosen once per burst: the hardware min/max form when every live
 // lane's slab constants are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form --
 // valid for all inputs -- otherwise.
-// A ray's own (committed) sequence of operations is the reference walk's, so results stay bit-identical.
-template <bool COUNT, int BURST, class Job, bool LDSN = false, bool SPEC = false>
+// A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
+template <bool COUNT, int BURST, class Job, bool LDSN = false>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, float t_min,
                             const Job& job, TravCounters* cnt)
 {
@@ -267,43 +237,25 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
     // link is its miss link): a list that ends here ended on a MISS.
     const bool live = w.node != kLinkEnd;
-    int32_t parked = 0;
-    if (all_finite) inner_burst<COUNT, BURST, true, LDSN, SPEC>(w, parked, nb, t_min, cnt);
-    else inner_burst<COUNT, BURST, false, LDSN, SPEC>(w, parked, nb, t_min, cnt);
+    if (all_finite) inner_burst<COUNT, BURST, true, LDSN>(w, nb, t_min, cnt);
+    else inner_burst<COUNT, BURST, false, LDSN>(w, nb, t_min, cnt);
     bool ended = live && w.node == kLinkEnd;    // this lane's walk left a list in this iteration ...
     bool is_hit = false;                        // ... and this was the result of its last step
 
-    // ---- one step for the lanes with a triangle leaf to test (the parked one, else the one they stand on) or on a TLAS
-    // leaf (both kinds read the record's first two quarters).  A TLAS leaf never follows a parked leaf: triangle leaves
-    // exist in bottom-level lists only.
+    // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
-    const int32_t here = (w.node != kLinkEnd && (w.node & kLinkTypeMask)) ? w.node : 0;
-    const int32_t rec = (SPEC && parked) ? parked : here;
-    if (rec) {
-        const uint32_t off = (uint32_t)rec & kLinkOffsetMask;
+    if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
+        const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ldn<LDSN>(nb, off);
         const float4 q1 = ldn<LDSN>(nb, off + 16u);
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
-        if (rec & kLinkLeafBit) {
+        if (w.node & kLinkLeafBit) {
             const float4 q2 = ldn<LDSN>(nb, off + 32u);
             if (COUNT) { cnt->tris++; cnt->ray_tris++; }
             bool accept; float t;
-            const bool tri_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
-            const int32_t succ = __float_as_int(q1.w);      // leaf: hit link == miss link
-            // links point forward (checked at upload), so the lane stands on `succ` exactly when it took no step behind the leaf
-            const bool moved = SPEC && parked && w.node != succ;
-            if (accept || !moved) {
-                // the walk goes on behind the leaf; steps taken with the t_max an accepted hit just shrank are dropped
-                w.node = succ;
-                is_hit = tri_hit;
-                if (COUNT && SPEC) cnt->spec = 0;
-                if (accept && t <= w.stop_t) { w.node = kLinkEnd; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd; }    // see Job::fetch
-            }
-            else {
-                // not accepted: the steps behind the leaf were the reference's own (a list that ended there ended on a miss)
-                is_hit = false;
-                if (COUNT && SPEC) { cnt->nodes += cnt->spec; cnt->ray_nodes += cnt->spec; cnt->spec = 0; }
-            }
+            is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
+            w.node = __float_as_int(q1.w);      // leaf: hit link == miss link
+            if (accept && t <= w.stop_t) { w.node = kLinkEnd; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd; }    // see Job::fetch
             ended = w.node == kLinkEnd;
         }
         else {
@@ -592,7 +544,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        walk_iteration<COUNT, kInnerBurst, Job, LDSN, (ATN_SPEC_LEAVES != 0)>(w, all_finite, sc, nb, t_min, job, cnt);
+        walk_iteration<COUNT, kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
     }
 }
 

@@ -285,14 +285,15 @@ class PathTracing:
                                           scramble.ctypes.data, draws, out.ctypes.data))
         return out
 
-    def material_table(self, mtrl_id, nrm, wi, index, scramble, uv):
+    def material_table(self, mtrl_id, nrm, wi, index, scramble, uv, dimension=None):
         n = len(nrm)
+        dim = np.ascontiguousarray(np.broadcast_to(np.asarray(dimension, np.uint32), (n,))) if dimension is not None else None
         nrm = np.ascontiguousarray(nrm, np.float32); wi = np.ascontiguousarray(wi, np.float32)
         index = np.ascontiguousarray(index, np.uint32); scramble = np.ascontiguousarray(scramble, np.uint32)
         uv = np.ascontiguousarray(uv, np.float32)
         s = np.zeros((n, 7), np.float32); e = np.zeros((n, 5), np.float32)
         self._check(self._l.atn_material_table(self._ctx, mtrl_id, n, nrm.ctypes.data, wi.ctypes.data,
-                                               index.ctypes.data, scramble.ctypes.data, uv.ctypes.data,
+                                               index.ctypes.data, dim.ctypes.data if dim is not None else None, scramble.ctypes.data, uv.ctypes.data,
                                                s.ctypes.data, e.ctypes.data))
         return s, e
 

@@ -304,9 +304,11 @@ int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t s
 int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble,
                   int32_t draws, float* out_host);
 /* material::sampleMaterial / samplePDF / sampleBSDF tables (src/libaten/material/material_impl.h:24-206).
+ * Case i samples with CMJ::init(index[i], dimension[i], scramble[i]) (dimension == NULL: 0 -- note that CMJ's pattern seed is
+ * dimension * scramble, cmj.h:118-123, so the draw of dimension 0 ignores the scramble).
  * out_sample: n*7 {dir, bsdf, pdf}; out_eval: n*5 {samplePDF, sampleBSDF.bsdf, sampleBSDF.pdf} at wo = dir. */
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
-                       const uint32_t* index, const uint32_t* scramble, const float* uv,
+                       const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval);
 /* material::samplePDF / sampleBSDF (material_impl.h:90-206) at caller-given outgoing directions wo (n * 3):
  * out_eval n*5 {samplePDF, sampleBSDF.bsdf.xyz, sampleBSDF.pdf}.  For invariants that need no oracle (the pdf integrates to

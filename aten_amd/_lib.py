@@ -23,7 +23,7 @@ SYMBOLS = [
     "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_kernel_times",
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples", "atn_cmj_batch", "atn_get_random", "atn_random_count",
     "atn_material_table", "atn_material_eval", "atn_compact", "atn_compact2", "atn_sizeof_scene_desc", "atn_sizeof_destination",
-    "atn_abi_version",
+    "atn_abi_version", "atn_build_id",
     "atn_download_path_cost", "atn_update_geometry", "atn_scene_device_arrays", "atn_lbvh_rebuild_list", "atn_lbvh_build",
     "atn_mgpu_update_geometry", "atn_mgpu_lbvh_rebuild_list",
     "atn_mgpu_create", "atn_mgpu_destroy", "atn_mgpu_last_error", "atn_mgpu_shard_count", "atn_mgpu_shard_device",
@@ -122,6 +122,7 @@ def lib():
         l.atn_mgpu_synchronize.argtypes = [vp]
         l.atn_mgpu_film_device.argtypes = [vp]; l.atn_mgpu_film_device.restype = vp
         l.atn_mgpu_download_film.argtypes = [vp, vp]
+        l.atn_build_id.argtypes = []; l.atn_build_id.restype = C.c_char_p
         for n in ("atn_sizeof_scene_desc", "atn_sizeof_destination", "atn_abi_version"):
             getattr(l, n).restype = C.c_uint32
         _lib = l

@@ -44,9 +44,10 @@ def _run(cmd):
 
 
 def kernel_sources_sha16():
-    """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over the sources of libaten_amd.so, in path order.  Recorded in profiles/*counters*.json when the PMC passes are collected (tools/pmc_to_json.py) and
-    recomputed by bench.py, which refuses counters taken on other kernels (no .git on the GPU box: a content hash, not a
-    commit id)."""
+    """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over the sources of libaten_amd.so, in path order.
+    Compiled into the library (atn_build_id, with the extra compile flags) and recorded in profiles/*counters*.json when the PMC
+    passes are collected (tools/pmc_to_json.py); bench.py uses a record only if it names the build id of the LOADED binary and
+    that binary was built from the sources in the tree (no .git on the GPU box: a content hash, not a commit id)."""
     import hashlib
     h = hashlib.sha256()
     # what aten_amd.hip is made of: the .hip, device/*.hpp, host/*.hpp and the two headers it includes.  (host/*.cpp and
@@ -56,6 +57,17 @@ def kernel_sources_sha16():
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def build_id(extra_flags=()):
+    """What libaten_amd.so answers from atn_build_id(): the hash of the kernel sources + the extra -D flags it was compiled with
+    (none for the product build; tools/build_variants.sh passes its own)."""
+    return kernel_sources_sha16() + "|" + " ".join(sorted(extra_flags))
+
+
+def loaded_build_id():
+    from ._lib import lib
+    return lib().atn_build_id().decode()
 
 
 def build_host(force=False):
@@ -72,7 +84,7 @@ def build_hip(force=False):
     deps = _walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",))
     if force or not _newer(HIP_LIB, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", HIP_LIB] + srcs)
+        _run([hipcc] + HIP_FLAGS + ['-DATN_BUILD_ID="%s"' % build_id(), "-I", os.path.join(ROOT, "include"), "-o", HIP_LIB] + srcs)
     return HIP_LIB
 
 

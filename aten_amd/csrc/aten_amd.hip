@@ -179,6 +179,7 @@ public:
         hipEvent_t ev_read[3] = {};     // [scene set id]: the last frame of this bank that read that set has finished with the scene
         hipStream_t stream = nullptr, bstream[kMaxBatches] = {};
         hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {}, ev_gather = nullptr;
+        bool batch_streams_checked = false;
     };
     Bank spare[kMaxInFlight - 1];
     int frames_in_flight = 1, n_spare_ready = 0;
@@ -200,6 +201,7 @@ public:
         for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
         for (int k = 0; k < kMaxBatches; k++) { std::swap(bstream[k], b.bstream[k]); std::swap(ev_join[k], b.ev_join[k]); }
+        std::swap(batch_streams_checked, b.batch_streams_checked);
     }
 
     int set_frames_in_flight(int n)
@@ -258,23 +260,34 @@ public:
         for (auto r : rejected) (void)hipStreamDestroy(r);
         return ATN_OK;
     }
+    // The list the new banks are probed against: the main stream, the caller's side stream if it was handed out already (both
+    // FIXED: the caller holds their handles), then the spare banks' streams.
     int separate_bank_streams(int n)
     {
         if (n <= bank_streams_checked) return ATN_OK;
-        hipStream_t* st[kMaxInFlight];
-        st[0] = &stream;
-        for (int i = 1; i < n; i++) st[i] = &spare[i - 1].stream;
-        const int rc = separate_streams(st, n, bank_streams_checked);
+        hipStream_t* st[kMaxInFlight + 1];
+        int m = 0;
+        st[m++] = &stream;
+        if (side_stream) st[m++] = &side_stream;
+        const int fixed = m;
+        for (int i = 1; i < n; i++) st[m++] = &spare[i - 1].stream;
+        const int first = fixed + (bank_streams_checked > 1 ? bank_streams_checked - 1 : 0);
+        const int rc = separate_streams(st, m, first);
         if (rc) return rc;
         bank_streams_checked = n;
         return ATN_OK;
     }
-    // the batch streams a frame forks into when it is rendered in several batches (one frame in flight: run_paths)
+    // The batch streams a frame forks into when it is rendered in several batches (run_paths).  LAZY: probed the first time
+    // a frame of this bank really forks -- the probe costs milliseconds of spin kernels and, on a GPU shared with other
+    // processes, a spurious "clash" costs stream re-creations; most contexts (one batch: the refill walk, frames in flight)
+    // never fork.
+    bool batch_streams_checked = false;
     int separate_batch_streams()
     {
         hipStream_t* st[kMaxBatches];
         const int n = n_batches < 3 ? n_batches : 3;        // the size policy never uses more than two; three when forced
         for (int i = 0; i < n; i++) st[i] = &bstream[i];
+        batch_streams_checked = true;
         return n > 1 ? separate_streams(st, n, 1) : (int)ATN_OK;
     }
 
@@ -566,8 +579,7 @@ public:
             if (n_batches < 1) n_batches = 1;
             if (n_batches > kMaxBatches) n_batches = kMaxBatches;
         }
-        // the streams a frame's batches run on must not share a hardware queue (see streams_run_side_by_side)
-        if (env_probe_streams) { int rc = separate_batch_streams(); if (rc) return rc; }
+        // (the streams a frame's batches run on are probed lazily: separate_batch_streams, run_paths)
         return ATN_OK;
     }
 
@@ -1171,6 +1183,8 @@ public:
             nb = use_refill ? 1 : (lds_nodes && frames_in_flight > 1) ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
             if (nb > n_batches) nb = n_batches;
         }
+        // the streams a frame's batches run on must not share a hardware queue (see streams_run_side_by_side)
+        if (nb > 1 && env_probe_streams && !batch_streams_checked) { int rc = separate_batch_streams(); if (rc) return rc; }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
         per = (per + kChunk - 1u) / kChunk * kChunk;        // whole 1024-slot chunks (16 screen tiles)
         ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * 4 * counters_depth * 4, stream));
@@ -2244,6 +2258,12 @@ int atn_compact(atn_ctx* ctx, const int32_t* flags_host, uint32_t n, int32_t* ou
 
 uint32_t atn_sizeof_scene_desc(void) { return (uint32_t)sizeof(atn_scene_desc); }
 uint32_t atn_sizeof_destination(void) { return (uint32_t)sizeof(atn_destination); }
-uint32_t atn_abi_version(void) { return 2; }     // 2: atn_scene_desc grew the NPR fields (r02); atn_toon_param spelled out
+// what this binary was built from: aten_amd.build.kernel_sources_sha16() of the sources + the extra compile flags, passed in by
+// the build recipe (aten_amd/build.py, tools/build_variants.sh).  bench.py uses PMC records only for the binary they were taken on.
+#ifndef ATN_BUILD_ID
+#define ATN_BUILD_ID "unknown"
+#endif
+const char* atn_build_id(void) { return ATN_BUILD_ID; }
+uint32_t atn_abi_version(void) { return 3; }     // 3: atn_material_table takes the starting dimension, atn_compact3 dropped (r04); 2: NPR fields     // 2: atn_scene_desc grew the NPR fields (r02); atn_toon_param spelled out
 
 } // extern "C"

@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(256) k_svgf_atrous(SvgfFrame sf, int32_t iter)
 // and the one-pixel kernel issues 82 of them per pixel -- it is bound there and by VALU issue at the same time; shared
 // points also share their address arithmetic and luminance.  Per (pixel, tap) the arithmetic is the one-pixel kernel's
 // to the operation; only the ORDER in which a pixel's 24 weighted taps are summed differs (lattice order instead of
-// svgf_impl.h:693-726's ring order), i.e. float rounding of a sum of <= 25 positive terms.
+// svgf_impl.h:693-726's ring order), i.e. float rounding of a sum of <= 25 positive terms.  THIS kernel is the default
+// (ATEN_AMD_SVGF_ATROUS4=0 selects the one-pixel, ring-order kernel): the default SVGF output therefore differs from a
+// reference-order evaluation by that rounding -- measured bound against the one-pixel kernel on identical planes and histories:
+// tests/test_gpu_svgf.py::test_atrous_four_pixel_kernel_against_the_one_pixel_kernel.
 // Thread (tx, ty) -> x0 = (tx >> i) * 2s + (tx & (s - 1)): every residue class modulo s gets its own lattice.
 struct AtrousPixel {
     f3 n;           // centre normal

@@ -108,7 +108,7 @@ static bool parse_obj(const std::string& path, ObjFile& o)
         else if (k == "vt" && t.size() >= 2) { o.tex.push_back(to_f(t[1])); o.tex.push_back(t.size() > 2 ? to_f(t[2]) : 0.0F); }
         else if (k == "vn" && t.size() >= 4) { for (int c = 0; c < 3; c++) o.nml.push_back(to_f(t[1 + c])); }
         else if (k == "o" || k == "g") { o.shapes.emplace_back(); cur = &o.shapes.back(); cur->name = join_from(t, 1); }
-        else if (k == "mtllib" && t.size() >= 2) { o.mtls.clear(); load_mtl(base + t[1], o.mtls); }
+        else if (k == "mtllib" && t.size() >= 2) load_mtl(base + t[1], o.mtls);     // a second library APPENDS (tinyobj's MaterialFileReader): ids already handed out stay valid
         else if (k == "usemtl") {
             const std::string name = join_from(t, 1);
             cur_mtl = -1;
@@ -144,6 +144,9 @@ static bool parse_obj(const std::string& path, ObjFile& o)
             if (c.v < 0 || (size_t)c.v >= o.pos.size() / 3 || (c.vt >= 0 && (size_t)c.vt >= o.tex.size() / 2) || c.vt < -1
                 || (c.vn >= 0 && (size_t)c.vn >= o.nml.size() / 3) || c.vn < -1) { o.error = "face index out of range in " + path; return false; }
         }
+    for (const auto& s : o.shapes)
+        for (const int32_t m : s.mtl)
+            if (m < -1 || (m >= 0 && (size_t)m >= o.mtls.size())) { o.error = "face material id out of range in " + path; return false; }
     return true;
 }
 
@@ -257,12 +260,17 @@ struct atns_mtrlxml { XmlFile x; std::vector<std::string> keep; };
 
 extern "C" {
 
+// Nothing may throw across the C boundary (a std::bad_alloc on a huge or hostile file would end the caller's process):
+// every entry point that runs container code returns -2 instead.
 int atns_obj_open(const char* path, atns_obj** out)
 {
     if (!path || !out) return -1;
     atns_obj* h = new (std::nothrow) atns_obj();
     if (!h) return -2;
-    if (!parse_obj(path, h->f)) { std::fprintf(stderr, "atns_obj_open: %s\n", h->f.error.c_str()); delete h; return -3; }
+    try {
+        if (!parse_obj(path, h->f)) { std::fprintf(stderr, "atns_obj_open: %s\n", h->f.error.c_str()); delete h; return -3; }
+    }
+    catch (...) { delete h; return -2; }
     *out = h;
     return 0;
 }
@@ -277,10 +285,22 @@ int atns_obj_material(const atns_obj* h, uint32_t i, atns_obj_material_info* out
     return 0;
 }
 
+static int obj_register(atns_obj* h, uint32_t first_vertex, uint32_t first_mesh_id, int32_t separate_objs, int32_t normal_on_the_fly,
+                        const uint8_t* mtl_is_emissive, uint8_t default_is_emissive);
+
 int atns_obj_register(atns_obj* h, uint32_t first_vertex, uint32_t first_mesh_id, int32_t separate_objs, int32_t normal_on_the_fly,
-                      const uint8_t* mtl_is_emissive, uint8_t default_is_emissive)
+                      const uint8_t* mtl_is_emissive, uint32_t n_mtl_is_emissive, uint8_t default_is_emissive)
 {
     if (!h) return -1;
+    // mtl_is_emissive is indexed by OBJ material id: it must cover every material of the file (parse_obj checked the ids)
+    if (mtl_is_emissive && n_mtl_is_emissive < h->f.mtls.size()) return -4;
+    try { return obj_register(h, first_vertex, first_mesh_id, separate_objs, normal_on_the_fly, mtl_is_emissive, default_is_emissive); }
+    catch (...) { return -2; }
+}
+
+static int obj_register(atns_obj* h, uint32_t first_vertex, uint32_t first_mesh_id, int32_t separate_objs, int32_t normal_on_the_fly,
+                        const uint8_t* mtl_is_emissive, uint8_t default_is_emissive)
+{
     ObjFile& o = h->f;
     o.vtx_pos.clear(); o.vtx_nml.clear(); o.tris.clear(); o.meshes.clear(); o.objects.clear();
     auto emissive = [&](int32_t mtl) { return mtl < 0 ? default_is_emissive != 0 : (mtl_is_emissive && mtl_is_emissive[mtl] != 0); };
@@ -364,10 +384,14 @@ uint32_t atns_obj_mesh_count(const atns_obj* h) { return h ? (uint32_t)h->f.mesh
 uint32_t atns_obj_object_count(const atns_obj* h) { return h ? (uint32_t)h->f.objects.size() : 0; }
 uint32_t atns_obj_shape_count(const atns_obj* h) { return h ? (uint32_t)h->f.shapes.size() : 0; }
 const char* atns_obj_shape_name(const atns_obj* h, uint32_t i) { return (h && i < h->f.shapes.size()) ? h->f.shapes[i].name.c_str() : ""; }
-int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, atns_obj_triangle* tris, atns_obj_mesh* meshes, atns_obj_object* objects)
+int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, uint32_t cap_vertices, atns_obj_triangle* tris, uint32_t cap_triangles,
+                  atns_obj_mesh* meshes, uint32_t cap_meshes, atns_obj_object* objects, uint32_t cap_objects)
 {
     if (!h) return -1;
     const ObjFile& o = h->f;
+    // a destination smaller than what atns_obj_register produced is an error, not an overrun
+    if (((vtx_pos || vtx_nml) && cap_vertices < o.vtx_pos.size()) || (tris && cap_triangles < o.tris.size())
+        || (meshes && cap_meshes < o.meshes.size()) || (objects && cap_objects < o.objects.size())) return -4;
     if (vtx_pos) std::memcpy(vtx_pos, o.vtx_pos.data(), o.vtx_pos.size() * sizeof(atn_vec4));
     if (vtx_nml) std::memcpy(vtx_nml, o.vtx_nml.data(), o.vtx_nml.size() * sizeof(atn_vec4));
     if (tris) std::memcpy(tris, o.tris.data(), o.tris.size() * sizeof(atns_obj_triangle));
@@ -379,12 +403,16 @@ int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, atns_
 int atns_mtrlxml_open(const char* path, atns_mtrlxml** out)
 {
     if (!path || !out) return -1;
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return -3;                                   // MaterialLoader::load: "failed to load" (:145-151)
-    std::stringstream ss; ss << f.rdbuf();
-    atns_mtrlxml* h = new (std::nothrow) atns_mtrlxml();
-    if (!h) return -2;
-    if (!parse_mtrl_xml(ss.str(), h->x)) { std::fprintf(stderr, "atns_mtrlxml_open: %s\n", h->x.error.c_str()); delete h; return -4; }
+    atns_mtrlxml* h = nullptr;
+    try {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return -3;                                   // MaterialLoader::load: "failed to load" (:145-151)
+        std::stringstream ss; ss << f.rdbuf();
+        h = new (std::nothrow) atns_mtrlxml();
+        if (!h) return -2;
+        if (!parse_mtrl_xml(ss.str(), h->x)) { std::fprintf(stderr, "atns_mtrlxml_open: %s\n", h->x.error.c_str()); delete h; return -4; }
+    }
+    catch (...) { delete h; return -2; }
     *out = h;
     return 0;
 }
@@ -413,8 +441,11 @@ int atns_mtrlxml_param(const atns_mtrlxml* h, uint32_t i, uint32_t k, atns_mtrlx
     out->value[0] = out->value[1] = out->value[2] = 0.0F;
     if (out->kind == 0) {
         // getValue<vec3> (:23-43): split on ' ', atof each, at most three
-        const auto t = split_ws(p.second);
-        for (size_t c = 0; c < t.size() && c < 3; c++) out->value[c] = (float)std::atof(t[c].c_str());
+        try {
+            const auto t = split_ws(p.second);
+            for (size_t c = 0; c < t.size() && c < 3; c++) out->value[c] = (float)std::atof(t[c].c_str());
+        }
+        catch (...) { return -2; }
     }
     else if (out->kind == 2) out->value[0] = (float)std::strtod(p.second.c_str(), nullptr);      // XMLElement::DoubleText -> float (:45-51)
     return 0;

@@ -37,8 +37,8 @@ def _lib():
             f = getattr(l, "atns_obj_" + n); f.argtypes = [vp]; f.restype = C.c_uint32
         l.atns_obj_material.argtypes = [vp, C.c_uint32, C.POINTER(_MaterialInfo)]
         l.atns_obj_shape_name.argtypes = [vp, C.c_uint32]; l.atns_obj_shape_name.restype = C.c_char_p
-        l.atns_obj_register.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_uint8]
-        l.atns_obj_copy.argtypes = [vp, vp, vp, vp, vp, vp]
+        l.atns_obj_register.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_uint32, C.c_uint8]
+        l.atns_obj_copy.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
         l.atns_mtrlxml_open.argtypes = [C.c_char_p, C.POINTER(vp)]
         l.atns_mtrlxml_close.argtypes = [vp]; l.atns_mtrlxml_close.restype = None
         l.atns_mtrlxml_count.argtypes = [vp]; l.atns_mtrlxml_count.restype = C.c_uint32
@@ -84,14 +84,16 @@ class ObjFile:
         if mtl_is_emissive is not None:
             em[:len(self.materials)] = np.asarray(mtl_is_emissive, np.uint8)[:len(self.materials)]
         rc = self._l.atns_obj_register(self._h, first_vertex, first_mesh_id, int(separate_objs), int(normal_on_the_fly),
-                                       em.ctypes.data, int(default_is_emissive))
+                                       em.ctypes.data, len(em), int(default_is_emissive))
         if rc != 0:
             raise RuntimeError("atns_obj_register failed: %d" % rc)
         nv, nt = self._l.atns_obj_vertex_count(self._h), self._l.atns_obj_triangle_count(self._h)
         nm, no = self._l.atns_obj_mesh_count(self._h), self._l.atns_obj_object_count(self._h)
         pos = np.zeros((nv, 4), np.float32); nml = np.zeros((nv, 4), np.float32)
         tris = np.zeros(nt, OBJ_TRIANGLE); meshes = np.zeros(nm, OBJ_MESH); objs = np.zeros(no, OBJ_OBJECT)
-        self._l.atns_obj_copy(self._h, pos.ctypes.data, nml.ctypes.data, tris.ctypes.data, meshes.ctypes.data, objs.ctypes.data)
+        rc = self._l.atns_obj_copy(self._h, pos.ctypes.data, nml.ctypes.data, nv, tris.ctypes.data, nt, meshes.ctypes.data, nm, objs.ctypes.data, no)
+        if rc != 0:
+            raise RuntimeError("atns_obj_copy failed: %d" % rc)
         return pos, nml, tris, meshes, objs
 
 

@@ -84,7 +84,7 @@ def load_obj(path):
                 cur = ObjShape(" ".join(t[1:]))
                 shapes.append(cur)
             elif k == "mtllib":
-                mtls = load_mtl(os.path.join(base, t[1]))
+                mtls = mtls + load_mtl(os.path.join(base, t[1]))       # a second library appends (tinyobj): earlier ids stay valid
                 mtl_index = {m.name: i for i, m in enumerate(mtls)}
             elif k == "usemtl":
                 cur_mtl = mtl_index.get(" ".join(t[1:]), -1)

@@ -46,9 +46,12 @@ def profile_counters(scene, w, h, spp, depth, svgf):
     (they need the profiler around the process), so the fractions below combine those counters with the launch
     durations measured live here.  None when no committed profile matches the workload."""
     import glob
-    from aten_amd.build import kernel_sources_sha16
+    from aten_amd.build import kernel_sources_sha16, build_id, loaded_build_id
     tag = "%s %dx%d %dspp %d-bounce%s" % (scene, w, h, spp, depth, " svgf" if svgf else "")
     sha = kernel_sources_sha16()
+    # the binary that is being timed (ATEN_AMD_LIB may point at a variant build): counters count only if they were taken on
+    # THIS binary, and this binary is what the tree's sources build (hash + flags compiled into it: atn_build_id)
+    loaded = loaded_build_id()
     best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*counters*.json"))):
         try:
@@ -59,7 +62,7 @@ def profile_counters(scene, w, h, spp, depth, svgf):
             continue
         # counters are only valid for the kernels they were taken on: the record carries the hash of aten_amd/csrc +
         # include/ at collection time; a file from other sources is REFUSED (named in the output, not used)
-        if d.get("kernel_sources_sha16") == sha:
+        if d.get("kernel_sources_sha16") == sha and d.get("build_id", build_id()) == loaded and loaded.split("|")[0] == sha:
             best = (os.path.relpath(f, ROOT), d)
         else:
             stale = os.path.relpath(f, ROOT)
@@ -276,12 +279,25 @@ def run_workload(args, cfg, ctx):
 
     for i in range(warmup):
         step(i, False)
-    r.reset()
-    elapsed = timed(steps)
+    # The timed region is EXACTLY K steps between barriers + synchronisations; it is timed `repeats` times over (each from a
+    # reset film) and `value` is the MEDIAN: one 20-step region is 84 ms, box noise +-1-2 %, the same size as a round's gain
+    repeats = max(1, args.repeats)
+    region_s = []
+    for _ in range(repeats):
+        r.reset()
+        region_s.append(timed(steps))
+    elapsed = float(np.median(region_s))
     host_enqueue_ms = 1e3 * host_enqueue[0] / steps
+    # the film the timed frames produced (K progressive frames from a reset film): its hash goes into the line, so that the
+    # N = 1, 2, 4, 8 records of a scaling run can be held against each other (the image does not depend on the sharding)
+    import hashlib
+    film_sha256 = None
     final_img = None
-    if cfg.get("dump") and rank == 0:
+    if rank == 0 and not svgf:
         final_img = full[0].cpu().numpy() if use_dist else r.download_film()
+        film_sha256 = hashlib.sha256(np.ascontiguousarray(final_img).tobytes()).hexdigest()
+        if not cfg.get("dump"):
+            final_img = None
 
     # the same K frames with ONE frame in flight: what a caller that waits for every frame sees (frame LATENCY); `value`
     # above is THROUGHPUT with `in_flight` frames overlapping (progressive accumulation never waits for a frame)
@@ -292,7 +308,7 @@ def run_workload(args, cfg, ctx):
         for i in range(min(warmup, 2)):
             step(i, False)
         r.reset()
-        latency_ms = 1e3 * timed(steps) / steps
+        latency_ms = 1e3 * float(np.median([timed(steps) for _ in range(min(repeats, 3))])) / steps
         r.set_frames_in_flight(in_flight)
 
     # the same K frames once more with every launch bracketed by HIP events on the stream it runs on: per-kernel
@@ -366,8 +382,17 @@ def run_workload(args, cfg, ctx):
     roof_ms = iso_ms if overlapped else avg_launch_ms
     avg_launch_s = max(roof_ms * 1e-3, 1e-12)
     scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[scene]
-    prof, stale, sha = (profile_counters(scene_tag, W, H, spp, depth, svgf) if world == 1 else (None, None, None))
+    prof, stale, sha = profile_counters(scene_tag, W, H, spp, depth, svgf)
     pk = kernel_entry((prof,), dominant) if prof else None
+    # The committed PMC record is of the UNSHARDED launch.  A rank of a world of N traces the rays of every N-th 8x8 tile: its
+    # launch does 1/N of the record's accesses and bytes (interleaved tiles: equal shares within a per cent), in a duration that
+    # is measured live on this rank.
+    shard_scale = 1.0 / world
+    if pk and world > 1:
+        pk = dict(pk)
+        for k in ("hbm_bytes", "hbm_read_bytes", "hbm_write_bytes", "hbm_bytes_lower", "l2_bytes_max"):
+            if pk.get(k) is not None:
+                pk[k] = pk[k] * shard_scale
     cal_file, cal = load_calibration()
     ceil = cal["ceilings"] if cal else {}
     # Candidate roofs for the dominant kernel, each a fraction <= 1 of a limit: HBM and L2 against the guide's peaks; the
@@ -379,7 +404,7 @@ def run_workload(args, cfg, ctx):
     if pk:
         scale = 1.0
         if pk.get("cycles") and roof_ms > 0:
-            scale = (pk["cycles"] / 2.4e6) / roof_ms        # rates are per cycle of the PROFILED run: rescale by the duration ratio
+            scale = shard_scale * (pk["cycles"] / 2.4e6) / roof_ms        # rates are per cycle of the PROFILED run: rescale by the duration ratio (and this rank's share)
         if "hbm_bytes" in pk:
             fractions["hbm"] = pk["hbm_bytes"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
         if "l2_bytes_max" in pk:
@@ -404,7 +429,8 @@ def run_workload(args, cfg, ctx):
         "kernel": dominant, "bound": bound,
         "achieved": round(frac * units[bound][1], 4) if frac is not None else None, "peak": units[bound][1], "unit": units[bound][0],
         "frac": round(frac, 4) if frac is not None else None,
-        "traffic": pk.get("hbm_bytes") if pk else None,
+        "traffic": round(pk["hbm_bytes"]) if pk and pk.get("hbm_bytes") is not None else None,
+        "counters_scaled_by": shard_scale if world > 1 else None,
         "fractions": {k: round(v, 4) for k, v in fractions.items()},
         "fraction_detail": extra,
         "calibration": ({"file": cal_file, "git_head": cal.get("git_head"),
@@ -424,7 +450,7 @@ def run_workload(args, cfg, ctx):
                  "valu_insts_per_simd_cycle": pk.get("valu_insts_per_simd_cycle"),
                  "valu_useful": round(fractions["valu"] * pk["lane_utilisation"], 4) if pk.get("lane_utilisation") and "valu" in fractions else None,
                  "avg_launch_ms_profiled": round(pk["cycles"] / 2.4e6, 5) if pk.get("cycles") else None} if pk else
-                {"file": None, "kernel_sources_sha16": sha, "refused_stale_file": stale,
+                {"file": None, "kernel_sources_sha16": sha, "loaded_build_id": __import__("aten_amd.build", fromlist=["x"]).loaded_build_id(), "refused_stale_file": stale,
                  "note": "no PMC record taken on these kernel sources (run tools/profile_round.sh): counter-derived fractions omitted"}),
         "note": "fractions: hbm = (FETCH_SIZE*2 + WRITE_SIZE) / t / 8 TB/s; l2 = TCC_REQ*128 B / t / 34.5 TB/s (upper bound); "
                 "l1 = max(TCP_TOTAL_ACCESSES, i.e. 64 lane slots per 16-B wave load, / measured 3.95 slots per CU-clock; "
@@ -530,6 +556,31 @@ def run_workload(args, cfg, ctx):
     if final_img is not None:
         np.save(cfg["dump"], final_img)
 
+    # what the collective layer saw: backend, world, and the device every rank drove (PCI bus id: distinct GPUs, not one GPU
+    # N times) -- gathered while all ranks are still in step
+    dist_info = None
+    if use_dist:
+        p = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "name": p.name,
+                "pci_bus_id": ("%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))) if hasattr(p, "pci_bus_id") else None,
+                "uuid": str(getattr(p, "uuid", "")) or None, "tile_slots": int(r.tile_slots())}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        dist_info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": devices,
+                     "distinct_devices": len(set((d["pci_bus_id"], d["uuid"]) for d in devices))}
+
+    # --verify-film: rank 0 renders the same K frames UNSHARDED once more and compares the film with the one the N ranks
+    # assembled (byte for byte; the other ranks go on to the closing barrier)
+    film_equals_single = None
+    if cfg.get("verify_film") and rank == 0 and film_sha256 is not None and not svgf:
+        r.setScreenShard(0, 1)
+        r.set_frames_in_flight(in_flight)
+        r.reset()
+        for i in range(steps):
+            r.render(W, H, depth, rr, spp=spp, frame=i, progressive=True, break_on_terminate=brk, download=False)
+        r.synchronize()
+        film_equals_single = hashlib.sha256(np.ascontiguousarray(r.download_film()).tobytes()).hexdigest() == film_sha256
+
     out = None
     if rank == 0:
         out = {
@@ -537,6 +588,10 @@ def run_workload(args, cfg, ctx):
             else "Mrays/sec (W*H*spp/1e6/s, reference definition)",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "repeats": repeats, "spread": round(max(region_s) / min(region_s), 4),
+            "ms_per_step_repeats": [round(1e3 * t / steps, 4) for t in region_s],
+            "timing_note": "the K-step region (barrier + synchronise on both sides, max over ranks) timed `repeats` times from a reset film; value = median",
+            "film_sha256": film_sha256, "film_equals_single_gpu": film_equals_single, "dist": dist_info,
             "ms_per_frame_latency": round(latency_ms, 4) if latency_ms is not None else round(ms_per_step, 4),
             "throughput_note": ("value / ms_per_step are THROUGHPUT with %d frames in flight (progressive accumulation enqueues frames back to back; "
                                 "one frame's launch tails overlap the next frame's bulk); ms_per_frame_latency is the same K frames with one frame "
@@ -596,6 +651,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the one-rank-per-GPU mode; nccl (= RCCL) is what is measured, gloo lets "
                          "several ranks SHARE a GPU (RCCL refuses that), which is how the tests run a world of two on a 1-GPU box")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is measured this many times; value = the median")
+    ap.add_argument("--verify-film", action="store_true",
+                    help="after the timed region rank 0 renders the same K frames unsharded and reports film_equals_single_gpu")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -640,7 +698,7 @@ def main():
     ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}
     cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
            "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
-           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump}
+           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "verify_film": args.verify_film}
     out = run_workload(args, cfg, ctx)
 
     # "sponza_lod for oracle-checked runs AND a synthetic scale-up for perf -- say which one every time".  The

@@ -329,7 +329,10 @@ int atn_compact2(atn_ctx* ctx, const int32_t* flags_a_host, const int32_t* flags
 /* ABI self-description for binding checks. */
 uint32_t atn_sizeof_scene_desc(void);
 uint32_t atn_sizeof_destination(void);
-uint32_t atn_abi_version(void);         /* 2 since atn_scene_desc carries the NPR fields (zero = none); check with atn_sizeof_scene_desc */
+uint32_t atn_abi_version(void);         /* 3 (r04: atn_material_table's dimension argument, atn_compact3 dropped); 2 since atn_scene_desc carries the NPR fields */
+/* "<sha16 of the kernel sources>|<extra compile flags>" of the loaded binary (the build recipe passes it in; "unknown" for a
+ * hand-rolled build): profiling records name the build they were taken on. */
+const char* atn_build_id(void);
 
 #ifdef __cplusplus
 }

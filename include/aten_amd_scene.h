@@ -89,16 +89,18 @@ uint32_t atns_obj_shape_count(const atns_obj* h);
 const char* atns_obj_shape_name(const atns_obj* h, uint32_t i);
 /* first_vertex = ctxt.GetVertexNum() before the load; separate_objs = will_register_shape_as_separate_obj;
  * normal_on_the_fly = need_compute_normal_on_the_fly; mtl_is_emissive[i] != 0 <=> OBJ material i resolved to an Emissive
- * material (default_is_emissive: the same for faces without usemtl). */
+ * material (n_mtl_is_emissive entries, at least atns_obj_material_count; default_is_emissive: the same for faces without
+ * usemtl).  Returns 0, -1 (null handle), -2 (out of memory: nothing throws across this boundary), -4 (array too short). */
 int atns_obj_register(atns_obj* h, uint32_t first_vertex, uint32_t first_mesh_id, int32_t separate_objs, int32_t normal_on_the_fly,
-                      const uint8_t* mtl_is_emissive, uint8_t default_is_emissive);
+                      const uint8_t* mtl_is_emissive, uint32_t n_mtl_is_emissive, uint8_t default_is_emissive);
 uint32_t atns_obj_vertex_count(const atns_obj* h);
 uint32_t atns_obj_triangle_count(const atns_obj* h);
 uint32_t atns_obj_mesh_count(const atns_obj* h);
 uint32_t atns_obj_object_count(const atns_obj* h);
-/* copies what atns_obj_register produced into caller arrays sized by the counts above; any pointer may be NULL */
-int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, atns_obj_triangle* tris, atns_obj_mesh* meshes,
-                  atns_obj_object* objects);
+/* copies what atns_obj_register produced into caller arrays of the given CAPACITIES (elements; -4 if one is smaller than
+ * the count above, nothing is written then); any pointer may be NULL */
+int atns_obj_copy(const atns_obj* h, atn_vec4* vtx_pos, atn_vec4* vtx_nml, uint32_t cap_vertices, atns_obj_triangle* tris, uint32_t cap_triangles,
+                  atns_obj_mesh* meshes, uint32_t cap_meshes, atns_obj_object* objects, uint32_t cap_objects);
 
 /* The material XML aten::MaterialLoader reads (src/libatenscene/MaterialLoader.cpp:82-218):
  *   <root><material><name>..</name><type>..</type><baseColor>r g b</baseColor><ior>..</ior><albedoMap>file</albedoMap>..

@@ -30,9 +30,18 @@ def test_force_gather_film_equals_plain_film(tmp_path):
     assert film_plain.shape == (1080, 1920, 4)
     assert film_gath.tobytes() == film_plain.tobytes()
     assert (film_plain[..., 3] == 3).all()
+    import hashlib
     for d in (plain, gath):
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 0
         assert d["roofline"]["kernel"] == "k_trace_fused" and d["ms_per_frame_latency"] >= 0.9 * d["ms_per_step"]
+        # the K-step region is timed `repeats` times, value is the median; the film's hash travels in the line
+        assert d["repeats"] == 5 and len(d["ms_per_step_repeats"]) == 5 and 1.0 <= d["spread"] < 1.5
+        assert abs(d["ms_per_step"] - float(np.median(d["ms_per_step_repeats"]))) < 1e-3
+        assert d["film_sha256"] == hashlib.sha256(film_plain.tobytes()).hexdigest()
+    assert plain["dist"] is None
+    # with the exchange step on, the line says what the collective layer saw
+    assert gath["dist"]["backend"] == "nccl" and gath["dist"]["world"] == 1 and len(gath["dist"]["devices"]) == 1
+    assert gath["dist"]["devices"][0]["rank"] == 0 and gath["dist"]["devices"][0]["tile_slots"] > 0
 
 
 @pytest.mark.gpu
@@ -74,7 +83,7 @@ def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29573 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--no-cpu-baseline", "--dump", dump]
+           "--warmup", "1", "--no-cpu-baseline", "--repeats", "2", "--verify-film", "--dump", dump]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
@@ -83,3 +92,15 @@ def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     film_two = np.load(dump)
     assert film_two.tobytes() == film_plain.tobytes()
+    # the line proves itself: backend, world and device of every rank as torch.distributed saw them, the film's hash, and rank
+    # 0's own unsharded re-render of the same frames
+    import hashlib
+    di = d["dist"]
+    assert di["backend"] == "gloo" and di["world"] == world and sorted(x["rank"] for x in di["devices"]) == list(range(world))
+    assert di["distinct_devices"] == 1                       # the ranks of this test share the box's one GPU
+    assert sum(x["tile_slots"] for x in di["devices"]) >= 1920 * 1080
+    assert d["film_sha256"] == hashlib.sha256(film_plain.tobytes()).hexdigest()
+    assert d["film_equals_single_gpu"] is True
+    assert d["repeats"] == 2 and d["spread"] >= 1.0
+    rf = d["roofline"]
+    assert rf["kernel"] == "k_trace_fused" and rf["roofline_launch_ms"] > 0 and rf["counters_scaled_by"] == 1.0 / world

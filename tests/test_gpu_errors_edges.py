@@ -236,12 +236,21 @@ def test_bank_streams_run_side_by_side():
         # crowd the runtime's queue assignment the way torch.distributed does (a few more live streams) -- whatever it
         # hands out, the banks must end up pairwise concurrent
         r.set_frames_in_flight(3)
-        swaps, concurrent = r.bank_streams()
+        # the probe is a wall-clock measurement (two 300 us spin kernels side by side or one after the other): on a GPU that
+        # other processes use at the same moment a round can read "clash" spuriously -- ask up to three times
+        for attempt in range(3):
+            swaps, concurrent = r.bank_streams()
+            if concurrent:
+                break
         assert concurrent, "three bank streams on fewer than three hardware queues (%d swaps)" % swaps
         side = r.side_stream_ptr()
         assert side and side != r.stream_ptr() and side == r.side_stream_ptr()      # owned by the context, handed out again
         r.set_frames_in_flight(1)
         r.set_frames_in_flight(3)
-        assert r.bank_streams()[1]
+        assert any(r.bank_streams()[1] for _ in range(3))
+        # a fourth bank created AFTER the side stream was handed out is probed against it too: still pairwise concurrent,
+        # and the caller's handle is unchanged
+        r.set_frames_in_flight(4)
+        assert side == r.side_stream_ptr()
     finally:
         r.close()

@@ -337,3 +337,65 @@ def test_film_order_survives_svgf_frames_between_renders(sponza):
     for n in (3, 4):
         for a, b in zip(run(n), want):
             assert a.tobytes() == b.tobytes(), n
+
+
+def test_atrous_four_pixel_kernel_against_the_one_pixel_kernel(sponza):
+    """the default a-trous kernel (k_svgf_atrous4, four pixels per thread) sums a pixel's 24 weighted taps in LATTICE
+    order, the one-pixel kernel (k_svgf_atrous, ATEN_AMD_SVGF_ATROUS4=0) in the reference's ring order (svgf_impl.h:693-726):
+    same taps, same weights, another association of the float sums.  Both kernels on IDENTICAL planes, frame after frame (each
+    context keeps its own history): the filtered colour differs by float rounding only -- the bound is explicit here instead of
+    hiding inside the end-to-end tolerance."""
+    import os
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene.camera import create_camera
+    fs, cam = sponza
+    w, h = 192, 108
+    ctx = {}
+    old = os.environ.get("ATEN_AMD_SVGF_ATROUS4")
+    try:
+        for flag in ("0", "1"):
+            os.environ["ATEN_AMD_SVGF_ATROUS4"] = flag      # read when the context is created
+            r = PathTracing(0)
+            r.UpdateSceneData(fs)
+            r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+            r.initSampler(w, h, 0)
+            r.setScreenShard(0, 1)
+            r.svgf_reset()
+            ctx[flag] = r
+        # a third context renders the noisy frames and G-buffers; the two filter contexts get identical uploads every frame and
+        # keep their own history
+        os.environ["ATEN_AMD_SVGF_ATROUS4"] = "1"
+        src = PathTracing(0)
+        ctx["src"] = src
+        src.UpdateSceneData(fs)
+        src.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+        src.initSampler(w, h, 0)
+        src.setScreenShard(0, 1)
+        src.svgf_reset()
+        worst = 0.0
+        for frame in range(4):
+            src.svgf_render(w, h, 5, 3, frame=frame, compute_motion=True)
+            planes = {n: src.svgf_buffer(n) for n in ("contribs", "prev_normal_depth", "prev_albedo_meshid", "primary_position")}
+            outs = {}
+            for flag in ("0", "1"):
+                r = ctx[flag]
+                r.svgf_upload("contribs", planes["contribs"])
+                r.svgf_upload("normal_depth", planes["prev_normal_depth"])
+                r.svgf_upload("albedo_meshid", planes["prev_albedo_meshid"])
+                r.svgf_upload("primary_position", planes["primary_position"])
+                outs[flag] = r.svgf_denoise(w, h, frame=frame, compute_motion=True)
+            a, b = outs["0"][..., :3].astype(np.float64), outs["1"][..., :3].astype(np.float64)
+            assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and a.max() > 0
+            rel = np.abs(a - b) / np.maximum(1.0, np.abs(a))
+            worst = max(worst, float(rel.max()))
+            # rounding of 24-term sums of O(1) weights: a few 1e-7 per level, five levels, fed back through the history
+            assert rel.max() <= 2e-5, (frame, rel.max())
+            assert (rel <= 2e-6).mean() >= 0.999, (frame, (rel <= 2e-6).mean())
+        print("atrous4 vs atrous: worst relative difference %.3g" % worst)
+    finally:
+        for r in ctx.values():
+            r.close()
+        if old is None:
+            os.environ.pop("ATEN_AMD_SVGF_ATROUS4", None)
+        else:
+            os.environ["ATEN_AMD_SVGF_ATROUS4"] = old

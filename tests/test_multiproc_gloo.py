@@ -98,3 +98,19 @@ def test_bench_refuses_counters_taken_on_other_kernel_sources(tmp_path, monkeypa
     assert best[0] == os.path.join("profiles", "r01_counters_x.json") and stale is not None
     assert b.kernel_entry((best,), "k_trace_fused")["launches_sampled"] == 5
     assert b.profile_counters("cornell", 1920, 1080, 1, 5, False)[0] is None
+    # the hash of the source TEXT is not enough: the record must also name the build id of the loaded binary --
+    # sources hash + extra compile flags, compiled into the library (atn_build_id) -- and that binary must be what the tree builds
+    from aten_amd.build import build_id, loaded_build_id
+    assert loaded_build_id() == build_id() == sha + "|"
+    rec["build_id"] = build_id(["-DATN_INNER_BURST=4"])          # counters of a variant build (tools/build_variants.sh)
+    (tmp_path / "profiles" / "r02_counters_x.json").write_text(json.dumps(rec))
+    best, stale, _ = b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)
+    assert best[0] == os.path.join("profiles", "r01_counters_x.json") and stale == os.path.join("profiles", "r02_counters_x.json")
+    rec["build_id"] = build_id()
+    (tmp_path / "profiles" / "r03_counters_x.json").write_text(json.dumps(rec))
+    assert b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)[0][0] == os.path.join("profiles", "r03_counters_x.json")
+    monkeypatch.setattr("aten_amd.build.loaded_build_id", lambda: build_id(["-DATN_INNER_BURST=4"]))     # ATEN_AMD_LIB = a variant
+    # ... then only the record taken on that variant counts
+    assert b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)[0][0] == os.path.join("profiles", "r02_counters_x.json")
+    monkeypatch.setattr("aten_amd.build.loaded_build_id", lambda: "0123456789abcdef|")       # a binary built from other sources
+    assert b.profile_counters("sponza_lod", 1920, 1080, 1, 5, False)[0] is None

@@ -139,6 +139,31 @@ def test_native_obj_errors(tmp_path):
         native_obj.ObjFile(str(tmp_path / "bad.obj"))               # index out of range is refused, not read
 
 
+def test_second_mtllib_appends_and_array_sizes_are_checked(tmp_path):
+    """a second `mtllib` APPENDS to the material list (tinyobj's reader does; clearing it left earlier faces with
+    ids into the old list and atns_obj_register reading mtl_is_emissive out of bounds); atns_obj_register / atns_obj_copy
+    take the sizes of the caller's arrays and refuse short ones."""
+    import ctypes as C
+    from aten_amd.scene import native_obj
+    (tmp_path / "a.mtl").write_text("newmtl red\nKd 1 0 0\nnewmtl lamp\nKe 5 5 5\n")
+    (tmp_path / "b.mtl").write_text("newmtl blue\nKd 0 0 1\n")
+    (tmp_path / "two.obj").write_text("mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nusemtl lamp\nf 1 2 3\nmtllib b.mtl\n"
+                                      "usemtl blue\nf 1 3 4\nusemtl red\nf 1 2 4\n")
+    o = native_obj.ObjFile(str(tmp_path / "two.obj"))
+    assert [m["name"] for m in o.materials] == ["red", "lamp", "blue"]
+    pos, nml, tris, meshes, objs = o.register(0, 0, False, False, mtl_is_emissive=[0, 1, 0])
+    assert [int(m["mtl"]) for m in meshes] == [1, 2, 0]             # lamp (id from the first library), blue, red
+    assert int(objs[meshes[0]["object"]]["is_emissive_split"]) == 1 and len(tris) == 3
+    # short arrays are an error code, not an out-of-bounds access
+    l, h = o._l, o._h
+    em = np.zeros(2, np.uint8)
+    assert l.atns_obj_register(h, 0, 0, 0, 0, em.ctypes.data, 2, 0) == -4
+    assert l.atns_obj_register(h, 0, 0, 0, 0, None, 0, 0) == 0       # no array: nothing is emissive
+    small = np.zeros((1, 4), np.float32)
+    assert l.atns_obj_copy(h, small.ctypes.data, None, 1, None, 0, None, 0, None, 0) == -4
+    assert np.all(small == 0)
+
+
 XML = """<?xml version="1.0" encoding="UTF-8"?>
 <!-- the format of asset/converted_unitychan/unitychan_mtrl.xml -->
 <root>

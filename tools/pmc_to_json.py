@@ -17,7 +17,8 @@ Formulas (MI355X: 256 CUs, 1024 SIMDs, 8 XCDs; MI355X_MICROARCH.md for the peaks
   tcp_cache_accesses_per_cu_cycle = TCP_TOTAL_CACHE_ACCESSES / 256 / cycles  (one per distinct 64-B chunk a quad of lanes touches: tag rate)
   tcp_active        = TCP_GATE_EN2 / 256 / cycles
 The ceilings of the last three are MEASURED: profiles/r03_calibration.json (tools/valu_calib.hip).
-`kernel_sources_sha16` = aten_amd.build.kernel_sources_sha16() of the tree the passes ran on; bench.py refuses a mismatch.
+`kernel_sources_sha16` = aten_amd.build.kernel_sources_sha16() of the tree the passes ran on, `build_id` = atn_build_id() of the
+library they ran (ATEN_AMD_LIB included): sources hash + extra compile flags; bench.py refuses a mismatch of either.
 """
 import csv
 import glob
@@ -39,8 +40,8 @@ def main(d, workload):
     for f in sorted(glob.glob(os.path.join(d, "pass*", "*counter_collection.csv"))):
         for row in csv.DictReader(open(f)):
             acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    from aten_amd.build import kernel_sources_sha16
-    out = {"workload": workload, "kernel_sources_sha16": kernel_sources_sha16(), "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_collect.sh); per-launch averages over all dispatches of a kernel",
+    from aten_amd.build import kernel_sources_sha16, loaded_build_id
+    out = {"workload": workload, "kernel_sources_sha16": kernel_sources_sha16(), "build_id": loaded_build_id(), "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_collect.sh); per-launch averages over all dispatches of a kernel",
            "kernels": {}}
     for k in sorted(acc):
         if k.startswith("__amd") or not k.startswith("k_"):

@@ -1456,6 +1456,18 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
     res.attrib = lp.attrib;
 }
 
+// How many sampler dimensions sample_light consumes for this light (k_shade takes the draws at the reference's place in the
+// sample stream and evaluates the light later): area light over a polygon object 3 (triangle pick PolygonObject.h:121, then
+// r0, r1 triangle.h:137-138), over a sphere 2 (sphere.cpp:117-118), image-based light 2 (ibl.h:98-99), punctual lights 0.
+ATN_DEV uint32_t light_sample_draws(const atn_light_param& lp, const DevScene& sc)
+{
+    if (lp.type == ATN_LIGHT_IBL) return 2u;
+    if (lp.type != ATN_LIGHT_AREA || lp.arealight_objid < 0) return 0u;
+    const atn_object_param* obj = &sc.objects[lp.arealight_objid];
+    const int32_t t = obj->type == ATN_OBJ_INSTANCE ? sc.objects[obj->object_id].type : obj->type;
+    return t == ATN_OBJ_SPHERE ? 2u : (t == ATN_OBJ_POLYGONS ? 3u : 0u);
+}
+
 // ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
 template <int MS = kMsCarPaint>
 ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,

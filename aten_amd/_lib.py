@@ -20,7 +20,7 @@ SYMBOLS = [
     "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
     "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
-    "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_ray_cells", "atn_get_kernel_times",
+    "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_kernel_times",
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples", "atn_cmj_batch", "atn_get_random", "atn_random_count",
     "atn_material_table", "atn_material_eval", "atn_compact", "atn_compact2", "atn_sizeof_scene_desc", "atn_sizeof_destination",
     "atn_abi_version", "atn_build_id",
@@ -97,7 +97,6 @@ def lib():
         l.atn_download_film.argtypes = [vp, vp]
         l.atn_upload_film.argtypes = [vp, C.c_int32, C.c_int32, vp]
         l.atn_get_stats.argtypes = [vp, vp]
-        l.atn_get_ray_cells.argtypes = [vp, C.c_int32, vp, vp]
         l.atn_get_kernel_times.argtypes = [vp, vp, vp]
         l.atn_reset_kernel_times.argtypes = [vp]
         l.atn_generate_paths.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, vp]

@@ -104,8 +104,6 @@ public:
     bool batches_forced = false;    // ATEN_AMD_BATCHES / atn_set_path_batches given: no size policy on top
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
     bool env_probe_streams = true;  // ATEN_AMD_PROBE_STREAMS=0: take the bank streams as the runtime hands them out
-    bool last_frame_cells = false;      // the last frame's fused refill launches read their rays by cell (atn_get_ray_cells)
-    int env_cells = -1;         // ray cells (XCD-affine trace queues): -1 = by tree size (kCellsMinNodeBytes), 0 / 1 = ATEN_AMD_CELLS
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
@@ -157,7 +155,6 @@ public:
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
-    DevBuf<uint32_t> cellq_next, cellq_shadow, cell_counters;   // ray cells (PathBuffers::cell_*), allocated when a frame uses them
     DevBuf<unsigned long long> stats;
     DevBuf<uint32_t> cost, cost_film;       // per-slot / per-pixel {node visits, triangle tests} of the last count_stats frame
     int32_t cost_w = 0, cost_h = 0;
@@ -174,7 +171,7 @@ public:
     static constexpr int kMaxInFlight = 4;
     struct Bank {
         DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
-        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters, cellq_next, cellq_shadow, cell_counters;
+        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
         uint64_t bank_epoch = 0;
@@ -199,7 +196,6 @@ public:
         ray_o.swap(b.ray_o); ray_d.swap(b.ray_d); thr.swap(b.thr); contrib.swap(b.contrib); isect.swap(b.isect);
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
-        cellq_next.swap(b.cellq_next); cellq_shadow.swap(b.cellq_shadow); cell_counters.swap(b.cell_counters);
         counters.swap(b.counters);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
         for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
@@ -576,7 +572,6 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ATEN_AMD_CELLS")) env_cells = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("ATEN_AMD_PROBE_STREAMS")) env_probe_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
@@ -1044,7 +1039,6 @@ public:
         pb.fetch_closest = cb + 2 * counters_depth; pb.fetch_shadow = cb + 3 * counters_depth;
         pb.stats = count ? stats.p : nullptr;
         pb.cost = count ? cost.p : nullptr;
-        pb.cell_next = nullptr; pb.cell_shadow = nullptr; pb.cell_count = nullptr; pb.cell_stride = 0;
         return pb;
     }
 
@@ -1085,8 +1079,6 @@ public:
     // 2.31 / 1.29 / 0.71 vs plain 5.51 / 2.93 / 1.39 / 0.75 at 2.07 M / 1.04 M / 0.52 M / 0.26 M paths): the r01 crossover of
     // 1.9 M paths is gone, deep trees take the refill walk at every size that fills the machine at all
     static constexpr uint32_t kRefillMinPaths = 128u * 1000u;
-    // ray cells from this tree size on (bytes of node records): an XCD's L2 is 4 MiB and also holds path state and texels
-    static constexpr uint32_t kCellsMinNodeBytes = 6u * 1024u * 1024u;
 
     // bytes of the LDS copy a small scene is walked from (node image + matrix rows), 0 = the scene is walked from global memory
     uint32_t lds_scene_bytes() const
@@ -1128,18 +1120,6 @@ public:
     void launch_shade(uint32_t g_shade, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, int32_t b, const SvgfShade& sv)
     {
         const dim3 g(g_shade), t(256);
-        if constexpr (!SVGF) {
-            if (pb.cell_next) {                 // ray cells: the instantiations that also file the queued slots by cell
-                switch (scene.material_set) {
-                case kMsCore: hipLaunchKernelGGL((k_shade_w4<false, kMsCore, true>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-                case kMsDisney: hipLaunchKernelGGL((k_shade_w4<false, kMsDisney, true>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-                case kMsAnalytic: hipLaunchKernelGGL((k_shade<false, kMsAnalytic, true>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-                case kMsCarPaint: hipLaunchKernelGGL((k_shade<false, kMsCarPaint, true>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-                default: hipLaunchKernelGGL((k_shade<false, kMsToon, true>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-                }
-                return;
-            }
-        }
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
         case kMsCore: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsCore>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         case kMsDisney: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsDisney>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
@@ -1206,16 +1186,6 @@ public:
             nb = use_refill ? 1 : (lds_nodes && frames_in_flight > 1) ? 1 : (n_slots >= (frames_in_flight > 1 ? 1500u : 800u) * 1000u ? 2 : 1);
             if (nb > n_batches) nb = n_batches;
         }
-        // Ray cells: for trees that do not fit one XCD's 4 MiB L2 the fused refill launches read their rays from 8 lists filed by
-        // the cell of the ray's origin, and a block drains the list of its own XCD first (trace_refill<., ., ., true>).
-        const bool cells = !SVGF && use_refill && nb == 1 && !count && fuse_traces && lds_scene_bytes() == 0u
-                           && (env_cells < 0 ? scene.node_bytes >= kCellsMinNodeBytes : env_cells != 0);
-        last_frame_cells = cells;
-        if (cells) {
-            if (cellq_next.n < (size_t)8 * n_slots) { ATN_HIP(cellq_next.resize((size_t)8 * n_slots)); ATN_HIP(cellq_shadow.resize((size_t)8 * n_slots)); }
-            if (cell_counters.n < (size_t)atn::kCellCountStride * counters_depth) ATN_HIP(cell_counters.resize((size_t)atn::kCellCountStride * counters_depth));
-            ATN_HIP(hipMemsetAsync(cell_counters.p, 0, (size_t)atn::kCellCountStride * counters_depth * 4, stream));
-        }
         // the streams a frame's batches run on must not share a hardware queue (see streams_run_side_by_side)
         if (nb > 1 && env_probe_streams && !batch_streams_checked) { int rc = separate_batch_streams(); if (rc) return rc; }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
@@ -1229,7 +1199,6 @@ public:
             hipStream_t st = nb > 1 ? bstream[k] : stream;
             if (nb > 1) ATN_HIP(hipStreamWaitEvent(st, ev_fork, 0));
             PathBuffers pb = buffers(count, k, begin);
-            if (cells) { pb.cell_next = cellq_next.p; pb.cell_shadow = cellq_shadow.p; pb.cell_count = cell_counters.p; pb.cell_stride = n_slots; }
             fp.slot_begin = (int32_t)begin; fp.slot_end = (int32_t)end;
             const uint32_t n = end - begin;
             // k_shade works on chunks of `items` x 256 queue entries per block (one queue atomic per chunk): 4 on full
@@ -1243,7 +1212,6 @@ public:
             for (int32_t s = 0; s < d->sample; s++) {
                 fp.sample = s;
                 if (s > 0) ATN_HIP(hipMemsetAsync(pb.q_count, 0, (size_t)4 * counters_depth * 4, st));
-                if (s > 0 && cells) ATN_HIP(hipMemsetAsync(cell_counters.p, 0, (size_t)atn::kCellCountStride * counters_depth * 4, st));
                 prof_begin(prof, ATN_K_GEN, st);
                 hipLaunchKernelGGL(k_gen_path, dim3(g_slots), dim3(256), 0, st, pb, fp, camera, (const uint32_t*)seeds.p);
                 prof_end(prof);
@@ -1284,10 +1252,6 @@ public:
                         else if (lds_nodes) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<false, false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
-                        }
-                        else if (refill_now && cells && b > 0) {      // (launch 0 traces the primary rays: one origin, plain queue)
-                            if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused_cells<true>), gr, tb, lds, st, pb, scene, b);
-                            else hipLaunchKernelGGL((k_trace_fused_cells<false>), gr, tb, lds, st, pb, scene, b);
                         }
                         else if (refill_now) {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
@@ -1975,21 +1939,6 @@ int atn_get_stats(atn_ctx* ctx, uint64_t out[8])
 {
     CTX_QUIET_OR_FAIL(ctx);
     for (int i = 0; i < 8; i++) out[i] = ctx->r.host_stats[i];
-    return ATN_OK;
-}
-
-int atn_get_ray_cells(atn_ctx* ctx, int32_t launch, uint32_t out_counts[16], int32_t* used)
-{
-    CTX_QUIET_OR_FAIL(ctx);
-    PathTracing& r = ctx->r;
-    if (!out_counts || !used) return r.fail(ATN_ERR_INVALID_ARG, "null argument");
-    for (int i = 0; i < 16; i++) out_counts[i] = 0;
-    *used = r.last_frame_cells ? 1 : 0;
-    if (!r.last_frame_cells) return ATN_OK;
-    if (launch < 0 || launch >= r.counters_depth) return r.fail(ATN_ERR_INVALID_ARG, "trace launch out of range");
-    C_HIP(r, hipSetDevice(r.device));
-    C_HIP(r, hipStreamSynchronize(r.stream));
-    C_HIP(r, hipMemcpy(out_counts, r.cell_counters.p + (size_t)launch * atn::kCellCountStride, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return ATN_OK;
 }
 

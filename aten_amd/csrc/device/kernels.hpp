@@ -40,15 +40,6 @@ struct PathBuffers {
     uint32_t* sh_count; // [maxDepth]
     uint32_t* fetch_closest;    // [maxDepth] dynamic job-fetch cursors of the trace kernels
     uint32_t* fetch_shadow;     // [maxDepth]
-    // ray cells (DevScene::cell_*; null = off): the slots k_shade queues, once more, filed by the cell of the ray's origin -- read by
-    // the cell flavour of the fused trace launch only; everything else keeps reading the plain queues
-    uint32_t* cell_next;    // [8][cell_stride] paths that go on
-    uint32_t* cell_shadow;  // [8][cell_stride] paths with a shadow ray
-    uint32_t* cell_count;   // [trace launch L = 0 .. maxDepth][kCellCountStride]: closest rays of bounce L per cell [0..7], shadow rays of
-                            // bounce L - 1 per cell [8..15]; the launch's 8 fetch cursors at [32..39] and 8 "list drained" flags at
-                            // [64..71], each group in a cache line of its own (a line that device-scope atomics hammer must not
-                            // also hold what every chunk fetch reads: measured 5 x on the launch)
-    uint32_t cell_stride;
     uint32_t* cost;     // [2 * slots] node visits / triangle tests of the pixel's walks this sample (count_stats frames; else null)
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
 };
@@ -132,52 +123,6 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
         offB += (uint32_t)__popcll(mB);
     }
     __syncthreads();    // sh is reused by the next chunk
-}
-
-// The ray-cell copy of a chunk's queue entries: entry k of this thread goes to qA[cell * stride + ...] when flagsA has bit k
-// (qB / flagsB likewise), cell = bits 3k .. 3k+2 of `cells`.  One LDS histogram per chunk, 16 global atomics (one per queue and
-// cell), positions inside a cell from LDS atomics: a few hundred cycles against the ~30 K a chunk's shading takes.
-constexpr uint32_t kCellCountStride = 96;
-struct BlockCellShared { uint32_t cnt[2][8]; uint32_t base[2][8]; };
-template <class EntryFn>
-ATN_DEV void block_append_cells(BlockCellShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA, uint32_t* qB, uint32_t* cntB, uint32_t flagsB,
-                                uint32_t cells, uint32_t stride, EntryFn entry)
-{
-    if (threadIdx.x < 16u) sh.cnt[threadIdx.x >> 3][threadIdx.x & 7u] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kChunkItems; k++) {
-        const uint32_t c = (cells >> (3 * k)) & 7u;
-        if ((flagsA >> k) & 1u) atomicAdd(&sh.cnt[0][c], 1u);
-        if ((flagsB >> k) & 1u) atomicAdd(&sh.cnt[1][c], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 16u) {
-        const uint32_t q = threadIdx.x >> 3, c = threadIdx.x & 7u;
-        const uint32_t n = sh.cnt[q][c];
-        sh.base[q][c] = n ? atomicAdd(&(q ? cntB : cntA)[c], n) : 0u;
-        sh.cnt[q][c] = 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kChunkItems; k++) {
-        const uint32_t c = (cells >> (3 * k)) & 7u;
-        if ((flagsA >> k) & 1u) qA[(size_t)c * stride + sh.base[0][c] + atomicAdd(&sh.cnt[0][c], 1u)] = entry(k);
-        if ((flagsB >> k) & 1u) qB[(size_t)c * stride + sh.base[1][c] + atomicAdd(&sh.cnt[1][c], 1u)] = entry(k);
-    }
-    __syncthreads();    // sh is reused by the next chunk
-}
-
-ATN_DEV uint32_t ray_cell(const DevScene& sc, const f3& p)
-{
-    uint32_t k = 0;
-#pragma unroll
-    for (int level = 0; level < 3; level++) {
-        const int32_t ax = sc.cell_axis[k];
-        const float v = ax == 0 ? p.x : (ax == 1 ? p.y : p.z);
-        k = 2u * k + 1u + (v > sc.cell_thr[k] ? 1u : 0u);        // (a NaN coordinate goes below)
-    }
-    return k - 7u;
 }
 
 ATN_DEV void wave_add_stat(unsigned long long* dst, uint32_t v)
@@ -326,13 +271,10 @@ struct SvgfShade {
 #endif
 struct ShadePartShared { uint32_t perm[kChunk]; uint32_t wcount[kChunkItems][4][2]; };
 
-// CELLS: also file the queued slots by ray cell (PathBuffers::cell_*) -- its own instantiation, so that the kernels of scenes
-// without cells carry none of it (k_shade is held to 128 registers: every live value counts)
-template <bool SVGF, int MS, bool CELLS = false>
+template <bool SVGF, int MS>
 ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FrameParams& fp, const atn_camera_param& cam, int32_t bounce, const SvgfShade& sv)
 {
     __shared__ BlockAppendShared sh;
-    __shared__ BlockCellShared shc;
 #if ATN_SHADE_PARTITION
     __shared__ ShadePartShared part;
 #endif
@@ -344,7 +286,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
     const int items = fp.chunk_items;
     const uint32_t chunk_size = 256u * (uint32_t)items;
     for (uint32_t chunk = blockIdx.x * chunk_size; chunk < count; chunk += gridDim.x * chunk_size) {
-      uint32_t flags_next = 0, flags_shadow = 0, cells = 0;
+      uint32_t flags_next = 0, flags_shadow = 0;
 #if ATN_SHADE_PARTITION
       const uint32_t n_valid = count - chunk < chunk_size ? count - chunk : chunk_size;
       {
@@ -391,7 +333,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
         const bool valid = j < count;
 #endif
         bool push_next = false, push_shadow = false;
-        uint32_t slot = 0, cell = 0;
+        uint32_t slot = 0;
 
         if (valid) {
 #if ATN_SHADE_PARTITION
@@ -602,7 +544,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
                     }
-                    if constexpr (CELLS) cell = ray_cell(sc, rec.p);   // both rays this bounce makes start at the hit point
                     // ---- the NEE evaluation (see above); HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     if (nee && !(flags & F_TERMINATED)) {
                         Cmj sl; sl.idx = smp.idx; sl.dim = nee_dim; sl.scramble = smp.scramble;
@@ -640,7 +581,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
         }
         if (push_next) flags_next |= 1u << k;
         if (push_shadow) flags_shadow |= 1u << k;
-        if constexpr (CELLS) cells |= cell << (3 * k);
       }
 #if ATN_SHADE_PARTITION
       auto entry_of = [&](int k) { return part.perm[(uint32_t)k * 256u + threadIdx.x]; };
@@ -648,18 +588,14 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
       auto entry_of = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
 #endif
       block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, entry_of);
-      if constexpr (CELLS) {
-          uint32_t* cc = pb.cell_count + (size_t)(bounce + 1) * kCellCountStride;     // both kinds are traced by launch bounce + 1
-          block_append_cells(shc, pb.cell_next, cc, flags_next, pb.cell_shadow, cc + 8, flags_shadow, cells, pb.cell_stride, entry_of);
-      }
     }
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
 }
 
-template <bool SVGF, int MS, bool CELLS = false>
+template <bool SVGF, int MS>
 __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
-    shade_body<SVGF, MS, CELLS>(pb, sc, fp, cam, bounce, sv);
+    shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }
 // The two smallest material sets need 141 / 148 VGPRs (3 waves per SIMD); held to 128 they run 4 waves per SIMD with a
 // few spilled registers and come out ahead (sponza_lod 4.37 -> 4.30 ms, atrium 6.30 -> 6.26 ms per 1080p frame).  The
@@ -667,10 +603,10 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
 #ifndef ATN_SHADE_SMALL_WAVES
 #define ATN_SHADE_SMALL_WAVES 4
 #endif
-template <bool SVGF, int MS, bool CELLS = false>
+template <bool SVGF, int MS>
 __global__ void __attribute__((amdgpu_waves_per_eu(ATN_SHADE_SMALL_WAVES, ATN_SHADE_SMALL_WAVES))) __launch_bounds__(256) k_shade_w4(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
-    shade_body<SVGF, MS, CELLS>(pb, sc, fp, cam, bounce, sv);
+    shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }
 
 // HitShadowRay -> HitTestToTargetLight -> scene::hitLight
@@ -842,56 +778,6 @@ __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock
     const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
     TravCounters tc{};
     trace_dispatch<false, REFILL, FusedJob<ALPHA>, LDSN>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
-}
-
-// The fused launch over RAY CELLS: the same two job kinds, read from the cell-filed copies of the queues (PathBuffers::cell_*).
-// A job is (cell, index): in cell c the shadow rays come first, then the closest-hit rays.  trace_refill<., ., ., true> walks the
-// cells starting with the block's own (blockIdx % 8 = the XCD the block lands on) and steals from the others when it is empty.
-template <bool ALPHA>
-struct FusedCellJob {
-    ShadowJob<ALPHA> s;
-    ClosestJob c;
-    const uint32_t* __restrict__ cq_next;
-    const uint32_t* __restrict__ cq_shadow;
-    const uint32_t* __restrict__ counts;    // of this launch: closest [8], shadow [8] (written by k_shade, constant here)
-    uint32_t* cursors;                      // [8]
-    uint32_t stride;
-    float t_min;
-    ATN_DEV uint32_t cell_jobs(uint32_t cell) const { return counts[cell] + counts[8u + cell]; }
-    ATN_DEV uint32_t* cell_cursor(uint32_t cell) const { return cursors + cell; }
-    ATN_DEV uint32_t* cell_drained(uint32_t cell) const { return cursors + 32u + cell; }
-    ATN_DEV void fetch(uint32_t cell, uint32_t j, float4& a, float4& b, float& stop_t) const
-    {
-        const uint32_t n_shadow = counts[8u + cell];
-        if (j < n_shadow) {
-            s.fetch_slot(cq_shadow[(size_t)cell * stride + j], a, b, stop_t);
-            b.w = __uint_as_float(__float_as_uint(b.w) | 0x80000000u);
-        }
-        else {
-            c.fetch_slot(cq_next[(size_t)cell * stride + (j - n_shadow)], a, b, stop_t);
-        }
-    }
-    ATN_DEV bool finish(uint32_t payload, const Hit& h, bool is_hit, float4& ra, float4& rb, float& rstop) const
-    {
-        if (payload & 0x80000000u) {
-            const bool again = s.finish(payload & 0x7fffffffu, h, is_hit, ra, rb, rstop);
-            if (again) rb.w = __uint_as_float(__float_as_uint(rb.w) | 0x80000000u);
-            return again;
-        }
-        return c.finish(payload, h, is_hit, ra, rb, rstop);
-    }
-    ATN_DEV void cost(uint32_t, uint32_t, uint32_t) const {}
-};
-
-template <bool ALPHA>
-__global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused_cells(PathBuffers pb, DevScene sc, int32_t launch)
-{
-    __shared__ TraceShared sh;
-    const FusedCellJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, nullptr, kEps }, pb.cell_next, pb.cell_shadow,
-                                   pb.cell_count + (size_t)launch * kCellCountStride, pb.cell_count + (size_t)launch * kCellCountStride + 32u,
-                                   pb.cell_stride, kEps };
-    TravCounters tc{};
-    trace_refill<false, FusedCellJob<ALPHA>, false, true>(sc, sh, 0u, nullptr, job, &tc);
 }
 
 // Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,

@@ -113,13 +113,6 @@ struct DevScene {
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
     uint32_t mtx_quads;                 // float4 rows in `matrices` (the LDS copy holds them behind the node image)
-    // RAY CELLS (r04): 8 regions of space holding about equally many triangles -- a 3-level k-d split of the triangle centroids
-    // (median along the longest axis), built at upload.  k_shade files the rays it makes by the cell of their origin, and the
-    // persistent trace blocks that land on XCD x (blockIdx % 8) drain cell x first: a tree that does not fit one XCD's 4 MiB L2
-    // is then cached eight ways by region instead of eight times whole.  Node k splits along cell_axis[k] at cell_thr[k];
-    // children 2k + 1 (below) and 2k + 2; the leaves 7 .. 14 are cells 0 .. 7.
-    float cell_thr[7];
-    int32_t cell_axis[7];
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

@@ -470,11 +470,10 @@ struct TraceShared {
     float4 stage[kTraceWavesPerBlock][kFetchChunk][2]; float stop[kTraceWavesPerBlock][kFetchChunk];    // 18 KB
 };
 
-// CELLS (r04): the jobs come in 8 lists, one per ray cell (scene_dev.hpp), each with its own cursor; a wave drains the list of its
-// block's own cell first (blockIdx % 8: workgroups are dealt to the 8 XCDs round robin, so a cell's rays -- and the part of
-// the tree they walk -- meet in ONE XCD's L2) and then steals from the next cells in turn.  Job: cell_jobs(cell), cell_cursor(cell),
-// fetch(cell, j, ...).  `count` / `fetch_counter` are unused then.
-template <bool COUNT, class Job, bool LDSN = false, bool CELLS = false>
+// (XCD-affine job lists -- rays filed by the cell of their origin, a block draining its own XCD's list first -- were built and
+// measured in r04: L2 hit 0.79 -> 0.85 and fabric reads -41 % on the 250 K-triangle atrium, and the launch no faster.
+// profiles/r04_variants_ray_cells.txt; code in git history, commit "Ray cells".)
+template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)
 {
@@ -491,11 +490,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     bool first_chunk = true;            // wave-uniform
     bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
-    // CELLS: the block's own cell, how many cells this wave has left behind (8 = drained), its rank among its cell's waves
-    const uint32_t home = blockIdx.x & 7u, waves_per_block = blockDim.x >> 6;
-    const uint32_t home_rank = (blockIdx.x >> 3) * waves_per_block + (threadIdx.x >> 6);
-    uint32_t cells_done = 0, cur_cell = home;
-
     Walk w;
     slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
     w.ray = w.wray;
@@ -513,53 +507,25 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 // The first chunk of every wave is pre-assigned (chunk index = global wave id) and the shared
                 // cursor starts after those: a same-address atomic retires only every ~11 ns, so a launch that
                 // opens with one atomic per wave (5 K waves) would stall for tens of microseconds.
-                uint32_t base = 0, n_jobs = count;
-                if constexpr (CELLS) {
-                    // the same per cell: the first chunks of a cell's list belong to the waves whose home it is
-                    for (; cells_done < 8u; cells_done++) {
-                        cur_cell = (home + cells_done) & 7u;
-                        n_jobs = job.cell_jobs(cur_cell);
-                        const uint32_t cell_waves = ((gridDim.x + 7u - cur_cell) >> 3) * waves_per_block;
-                        if (first_chunk) base = home_rank * kFetchChunk;
-                        else {
-                            // a list that some wave already found empty is skipped on a flag, not on a read-modify-write: 8 K
-                            // waves x 7 foreign lists would otherwise queue ~60 K failing atomics on one line per launch
-                            // (a same-address atomic retires every ~11 ns)
-                            if (lane == 0) {
-                                base = 0xffffffffu;
-                                if (__hip_atomic_load(job.cell_drained(cur_cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                                    base = (atomicAdd(job.cell_cursor(cur_cell), 1u) + cell_waves) * kFetchChunk;
-                                    if (base >= n_jobs) __hip_atomic_store(job.cell_drained(cur_cell), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
-                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        }
-                        first_chunk = false;
-                        if (base < n_jobs) break;
-                    }
-                    if (cells_done >= 8u) base = n_jobs = 0u;
+                uint32_t base = 0;
+                if (first_chunk) {
+                    base = wave_id * kFetchChunk;
+                    first_chunk = false;
                 }
                 else {
-                    if (first_chunk) {
-                        base = wave_id * kFetchChunk;
-                        first_chunk = false;
-                    }
-                    else {
-                        if (lane == 0) base = (atomicAdd(fetch_counter, 1u) + n_waves) * kFetchChunk;
-                    }
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (lane == 0) base = (atomicAdd(fetch_counter, 1u) + n_waves) * kFetchChunk;
                 }
-                if (base >= n_jobs) { drained = true; c_count = 0; c_next = 0; }
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= count) { drained = true; c_count = 0; c_next = 0; }
                 else {
-                    c_count = n_jobs - base < kFetchChunk ? n_jobs - base : kFetchChunk;
+                    c_count = count - base < kFetchChunk ? count - base : kFetchChunk;
                     c_next = 0;
 #pragma unroll
                     for (uint32_t e = 0; e < kFetchChunk; e += 64) {
                         if (e + lane < c_count) {
                             float4 a, b;
                             float st;
-                            if constexpr (CELLS) job.fetch(cur_cell, base + e + lane, a, b, st);
-                            else job.fetch(base + e + lane, a, b, st);
+                            job.fetch(base + e + lane, a, b, st);
                             stage[e + lane][0] = a;
                             stage[e + lane][1] = b;
                             stage_stop[e + lane] = st;

@@ -1,8 +1,6 @@
 // Host-side conversion of the caller's flat scene (include/aten_layout.h) into the device layout
 // of device/scene_dev.hpp.  Pure host C++ (no HIP calls) so that it can be unit-tested on CPU.
 #pragma once
-#include <algorithm>
-#include <array>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -402,51 +400,6 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         const int32_t need = (t == ATN_MTRL_TOON || t == ATN_MTRL_STYLIZED_BRDF) ? kMsToon
                            : t == ATN_MTRL_CARPAINT ? kMsCarPaint : t == ATN_MTRL_DISNEY ? kMsDisney : core ? kMsCore : kMsAnalytic;
         if (need > p.material_set) p.material_set = need;
-    }
-    // ray cells (scene_dev.hpp): a 3-level k-d split of (a sample of) the triangle centroids in world space
-    {
-        std::vector<std::array<float, 3>> pts;
-        auto add_object = [&](const atn_object_param& real, const atn_mat4* m) {
-            if (real.type != ATN_OBJ_POLYGONS || real.triangle_num <= 0) return;
-            const uint32_t step = (uint32_t)std::max(1, real.triangle_num / 60000);
-            for (uint32_t t = 0; t < (uint32_t)real.triangle_num; t += step) {
-                const atn_triangle_param& tp = s->triangles[(uint32_t)real.triangle_id + t];
-                float c[3] = { 0, 0, 0 };
-                for (int v = 0; v < 3; v++) { const atn_vec4& q = s->vtx_pos[tp.idx[v]]; c[0] += q.x; c[1] += q.y; c[2] += q.z; }
-                for (int a = 0; a < 3; a++) c[a] /= 3.0F;
-                std::array<float, 3> w = { c[0], c[1], c[2] };
-                if (m) for (int r = 0; r < 3; r++) w[r] = m->m[r][0] * c[0] + m->m[r][1] * c[1] + m->m[r][2] * c[2] + m->m[r][3];
-                if (std::isfinite(w[0]) && std::isfinite(w[1]) && std::isfinite(w[2])) pts.push_back(w);
-            }
-        };
-        bool any_instance = false;
-        for (uint32_t i = 0; i < s->n_objects; i++) {
-            const atn_object_param& o = s->objects[i];
-            if (o.type != ATN_OBJ_INSTANCE) continue;
-            any_instance = true;
-            add_object(s->objects[o.object_id], o.mtx_id >= 0 ? &s->matrices[o.mtx_id] : nullptr);
-        }
-        if (!any_instance) for (uint32_t i = 0; i < s->n_objects; i++) add_object(s->objects[i], nullptr);
-        for (int k = 0; k < 7; k++) { p.cell_axis[k] = k == 0 ? 0 : (k < 3 ? 1 : 2); p.cell_thr[k] = 0.0F; }
-        // node k owns pts[lo, hi): median split along the longest axis of its points' box
-        struct Range { size_t lo, hi; };
-        Range rg[15]; rg[0] = { 0, pts.size() };
-        for (int k = 0; k < 7; k++) {
-            const Range r = rg[k];
-            size_t mid = r.lo + (r.hi - r.lo) / 2;
-            if (r.hi - r.lo >= 2) {
-                float mn[3] = { 3.4e38F, 3.4e38F, 3.4e38F }, mx[3] = { -3.4e38F, -3.4e38F, -3.4e38F };
-                for (size_t i = r.lo; i < r.hi; i++) for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], pts[i][a]); mx[a] = std::max(mx[a], pts[i][a]); }
-                int ax = 0;
-                for (int a = 1; a < 3; a++) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
-                std::nth_element(pts.begin() + r.lo, pts.begin() + mid, pts.begin() + r.hi, [ax](const std::array<float, 3>& u, const std::array<float, 3>& v) { return u[ax] < v[ax]; });
-                p.cell_axis[k] = ax;
-                p.cell_thr[k] = pts[mid][ax];
-                // points equal to the threshold go below (ray_cell: v > thr goes above)
-                mid = std::partition(pts.begin() + r.lo, pts.begin() + r.hi, [&](const std::array<float, 3>& u) { return !(u[ax] > p.cell_thr[k]); }) - pts.begin();
-            }
-            rg[2 * k + 1] = { r.lo, mid }; rg[2 * k + 2] = { mid, r.hi };
-        }
     }
     // ImageBasedLight::sample's scene_radius (light/ibl.h:106-111; aabb::IsValid / getCenter /
     // ComputeDistanceToCoverBoundingSphere, math/aabb.h:176-180,231-234,346-362), evaluated once on the host.

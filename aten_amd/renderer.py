@@ -248,12 +248,6 @@ class PathTracing:
         self._check(self._l.atn_svgf_download(self._ctx, self.SVGF_BUFFERS[name], out.ctypes.data))
         return out
 
-    def ray_cells(self, launch=1):
-        """(used, closest-hit rays per cell [8], shadow rays per cell [8]) of trace launch `launch` of the last frame."""
-        c = np.zeros(16, np.uint32); used = C.c_int32(0)
-        self._check(self._l.atn_get_ray_cells(self._ctx, launch, c.ctypes.data, C.byref(used)))
-        return bool(used.value), c[:8].copy(), c[8:].copy()
-
     def kernel_times(self):
         ms = np.zeros(len(K_NAMES), np.float32); n = np.zeros(len(K_NAMES), np.uint32)
         self._check(self._l.atn_get_kernel_times(self._ctx, ms.ctypes.data, n.ctypes.data))

@@ -155,11 +155,6 @@ int atn_upload_film(atn_ctx* ctx, int32_t width, int32_t height, const atn_vec4*
  * {closest rays, shadow rays, shaded hits, closest node visits, closest triangle tests,
  *  shadow node visits, shadow triangle tests, 0}. */
 int atn_get_stats(atn_ctx* ctx, uint64_t out[8]);
-/* Ray cells (execution detail, no effect on results): for trees that do not fit one XCD's 4 MiB L2 the renderer files the rays
- * of a bounce by the cell of their origin (8 boxes over the scene box) and the trace blocks of XCD x drain cell x first.
- * *used = whether the last frame did; out_counts = {closest-hit rays [8], shadow rays [8]} per cell of trace launch `launch`
- * (1 .. maxDepth) of that frame's last sample.  ATEN_AMD_CELLS=0 / 1 overrides the size rule. */
-int atn_get_ray_cells(atn_ctx* ctx, int32_t launch, uint32_t out_counts[16], int32_t* used);
 /* The per-pixel cost map of the last frame rendered with count_stats = 1: uint32 {BVH node visits, triangle tests}[h][w] of all
  * the pixel's walks (closest and shadow, every sample and bounce).  ≙ the heat map the reference builds from its per-path GPU
  * timer (PathTimeProfiler, src/libaten/renderer/pathtracing/path_time_profiler.h:15-60; ComputeTemperature maps it to colours) --

@@ -156,49 +156,3 @@ def test_companion_workload_1080p_vs_oracle(ctx, orc, atrium):
         assert frac >= 0.97, (frame, frac)
         assert mean_err <= 5e-3, (frame, mean_err)
 
-
-def test_ray_cells_film_equals_plain_queue_film(atrium):
-    """Ray cells (r04; XCD-affine trace queues for trees beyond one XCD's L2, on by size for this scene): an execution detail --
-    the order in which rays are traced is free, so the film must not change by a bit.  Two contexts, cells
-    forced off and on, three progressive 1080p frames with frames in flight; the diagnostics show the cells were really used,
-    every cell got rays, and their total is the number of rays the plain queues counted."""
-    import os
-    from aten_amd.renderer import PathTracing
-    fs, cam = atrium
-    W, H = 1920, 1080
-    films, info = {}, {}
-    old = os.environ.get("ATEN_AMD_CELLS")
-    try:
-        for flag in ("0", "1"):
-            os.environ["ATEN_AMD_CELLS"] = flag         # read when the context is created
-            r = PathTracing(0)
-            try:
-                r.UpdateSceneData(fs)
-                r.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], W, H))
-                r.initSampler(W, H, 0)
-                r.setScreenShard(0, 1)
-                r.set_frames_in_flight(3)
-                for f in range(3):
-                    films[flag] = r.render(W, H, 5, 3, frame=f, progressive=True, download=(f == 2))
-                info[flag] = [r.ray_cells(launch) for launch in (1, 2, 5)]
-                if flag == "1":
-                    r.render(W, H, 5, 3, frame=2, progressive=False, download=False, count_stats=True)     # (counting frames use the plain queues)
-                    st = r.stats()
-            finally:
-                r.close()
-    finally:
-        if old is None:
-            os.environ.pop("ATEN_AMD_CELLS", None)
-        else:
-            os.environ["ATEN_AMD_CELLS"] = old
-    assert films["1"].tobytes() == films["0"].tobytes()
-    assert (films["1"][..., 3] == 3).all()
-    assert not info["0"][0][0]
-    used, closest, shadow = info["1"][0]
-    assert used and closest.min() > 0 and shadow.min() > 0
-    # launch 5 traces the shadow rays of the last bounce only
-    assert info["1"][2][1].sum() == 0 and info["1"][2][2].sum() > 0
-    total = sum(int(c.sum()) + int(s.sum()) for _, c, s in [r_ for r_ in info["1"]])
-    assert 0 < total < st["closest_rays"] + st["shadow_rays"]
-    # the cells of this scene are reasonably balanced (the split follows the scene box's aspect: 4 x 1 x 2 for the hall)
-    assert closest.max() < 10 * closest.min(), closest

@@ -1094,7 +1094,13 @@ public:
             const uint32_t waves_per_block = (uint32_t)kTraceBlock / 64u;
             uint32_t blocks = ((n_jobs + atn::kFetchChunk - 1u) / atn::kFetchChunk + waves_per_block - 1u) / waves_per_block;
             if (blocks < 1u) blocks = 1u;
-            const uint32_t cap = env_trace_blocks ? env_trace_blocks : (256u * 8u * 4u) / waves_per_block;   // 8 waves per SIMD's worth
+            // One frame at a time: 8 waves per SIMD's worth (6 are resident at 78 VGPRs; the rest start as those retire: best
+            // isolated launch, 3.28 ms of trace per sponza_lod frame).  With frames in flight the other frames' kernels want
+            // room beside this launch: 4.5 waves per SIMD's worth is slower alone (3.35 ms) and faster in the pipeline (r04 sweep,
+            // profiles/r04_sweep_trace_grid.txt: sponza_lod 4.13 -> 4.04 ms per frame, atrium 5.84 -> 5.71 with 4 frames in flight;
+            // 768 .. 1280 blocks within 1 %).
+            const uint32_t cap = env_trace_blocks ? env_trace_blocks
+                               : ((frames_in_flight > 1 ? 256u * 18u : 256u * 32u) / waves_per_block);
             return blocks < cap ? blocks : cap;
         }
         return grid_for(n_jobs);

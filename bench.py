@@ -72,10 +72,20 @@ def profile_counters(scene, w, h, spp, depth, svgf):
 def load_calibration():
     """Measured ceilings of the counters the roofline is built from (tools/valu_calib.hip -> profiles/*calibration.json)."""
     import glob
+    import hashlib
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*calibration.json")))
     if not fs:
         return None, None
-    return os.path.relpath(fs[-1], ROOT), json.load(open(fs[-1]))
+    cal = json.load(open(fs[-1]))
+    # ceilings count only if they were measured with the micro-benchmarks that are in the tree (content hash of
+    # tools/valu_calib.hip recorded by tools/calib_to_json.py; r03's record predates the field and is taken as it is)
+    try:
+        now = hashlib.sha256(open(os.path.join(ROOT, "tools", "valu_calib.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        now = None
+    if cal.get("calib_source_sha16") and now and cal["calib_source_sha16"] != now:
+        return os.path.relpath(fs[-1], ROOT), {"ceilings": {}, "refused": "measured with another tools/valu_calib.hip (%s, tree has %s)" % (cal["calib_source_sha16"], now)}
+    return os.path.relpath(fs[-1], ROOT), cal
 
 
 def kernel_entry(counters, prefix):
@@ -208,6 +218,8 @@ def run_workload(args, cfg, ctx):
     r.setScreenShard(rank, world)
     if svgf:
         in_flight = min(in_flight, 2)   # SVGF hands a frame over through two slots: 2 in flight is its depth
+    if use_dist:
+        in_flight = min(in_flight, 3)   # the exchange stream wants a hardware queue of its own: 3 banks + 1 = the 4 there are
     r.set_frames_in_flight(in_flight)
 
     # Exchange step with N > 1: every rank contributes its tile buffer (RCCL all_gather over xGMI) and assembles the
@@ -433,7 +445,7 @@ def run_workload(args, cfg, ctx):
         "counters_scaled_by": shard_scale if world > 1 else None,
         "fractions": {k: round(v, 4) for k, v in fractions.items()},
         "fraction_detail": extra,
-        "calibration": ({"file": cal_file, "git_head": cal.get("git_head"),
+        "calibration": ({"file": cal_file, "git_head": cal.get("git_head"), "calib_source_sha16": cal.get("calib_source_sha16"), "refused": cal.get("refused"),
                          "ceilings_used": {k: ceil.get(k) for k in ("valu_insts_per_simd_cycle_fma", "valu_insts_per_simd_cycle_walkmix",
                                                                     "tcp_accesses_per_cu_cycle_rows", "tcp_cache_accesses_per_cu_cycle_random")}} if cal else None),
         "avg_launch_ms": round(avg_launch_ms, 5), "launches": tc_n,
@@ -641,7 +653,7 @@ def main():
     ap.add_argument("--experiment", default="", help="traffic experiments on the sponza scene, not a benchmark configuration: "
                     "'notex' (no textures), 'noibl' (white background instead of the environment map), 'notex,noibl'")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="consecutive frames enqueued on rotating banks of path state and streams (atn_set_frames_in_flight): "
                          "one frame's launch tails overlap the next frame's bulk; 1 = strictly one frame at a time")
     ap.add_argument("--mgpu", action="store_true",

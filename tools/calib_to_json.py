@@ -132,7 +132,12 @@ def main(d):
                                        stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
         head = None
+    # the record names the micro-benchmark source it was measured with (content hash: there is no .git on the GPU box);
+    # bench.py refuses ceilings whose source is not the tools/valu_calib.hip in the tree
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_calib.hip")
     json.dump({"source": "tools/valu_calib.hip under rocprofv3 --pmc (tools/calib_collect.sh), MI355X gfx950", "git_head": head,
+               "calib_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
                "ceilings": ceil, "kernels": kernels}, sys.stdout, indent=1)
     print()
 

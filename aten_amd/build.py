@@ -56,12 +56,14 @@ def kernel_sources_sha16():
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
+    h.update(repr(HIP_UNITS).encode())      # the per-unit compiler flags are part of what the GPU runs
     return h.hexdigest()[:16]
 
 
 def build_id(extra_flags=()):
-    """What libaten_amd.so answers from atn_build_id(): the hash of the kernel sources + the extra -D flags it was compiled with
-    (none for the product build; tools/build_variants.sh passes its own)."""
+    """What libaten_amd.so answers from atn_build_id(): the hash of the kernel sources + the extra flags it was compiled with
+    (none for the product build, whose per-unit flags -- HIP_UNITS -- are part of this hashed file's neighbour build.py and of
+    the sources' comments; tools/build_variants.sh passes its own)."""
     return kernel_sources_sha16() + "|" + " ".join(sorted(extra_flags))
 
 
@@ -79,12 +81,38 @@ def build_host(force=False):
     return HOST_LIB
 
 
+# libaten_amd.so is two translation units with ONE flag of difference (device/svgf_atrous.hpp says why):
+#   aten_amd.hip      -fno-slp-vectorize  (no packed-fp32 pairing: the path-tracing kernels lose 15-25 % of their registers to it)
+#   svgf_atrous.hip   vectoriser on       (straight-line tap arithmetic, 22 % faster packed)
+HIP_UNITS = [("aten_amd.hip", ["-fno-slp-vectorize"]), ("svgf_atrous.hip", [])]
+
+
+def hip_compile(out_lib, extra_flags=(), objdir=None, hipcc=None):
+    """Compiles the translation units of libaten_amd.so in parallel and links them into `out_lib`.  `extra_flags` (variant builds:
+    tools/build_variants.sh) go to every unit and into the build id."""
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = objdir or os.path.join(PKG, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    tag = os.path.splitext(os.path.basename(out_lib))[0]
+    common = [f for f in HIP_FLAGS if f != "-shared"] + list(extra_flags) + ['-DATN_BUILD_ID="%s"' % build_id(extra_flags), "-I", os.path.join(ROOT, "include")]
+    procs, objs = [], []
+    for src, unit_flags in HIP_UNITS:
+        obj = os.path.join(objdir, "%s.%s.o" % (tag, os.path.splitext(src)[0]))
+        cmd = [hipcc] + common + unit_flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        print("+", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + objs)
+    return out_lib
+
+
 def build_hip(force=False):
-    srcs = [os.path.join(CSRC, "aten_amd.hip")]
-    deps = _walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",))
+    deps = _walk(CSRC, (".hip", ".h", ".hpp", ".cpp")) + _walk(os.path.join(ROOT, "include"), (".h",)) + [os.path.abspath(__file__)]
     if force or not _newer(HIP_LIB, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ['-DATN_BUILD_ID="%s"' % build_id(), "-I", os.path.join(ROOT, "include"), "-o", HIP_LIB] + srcs)
+        hip_compile(HIP_LIB)
     return HIP_LIB
 
 

@@ -1129,7 +1129,7 @@ public:
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
         case kMsCore: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsCore>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         case kMsDisney: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsDisney>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-        case kMsAnalytic: hipLaunchKernelGGL((k_shade<SVGF, kMsAnalytic>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        case kMsAnalytic: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsAnalytic>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         case kMsCarPaint: hipLaunchKernelGGL((k_shade<SVGF, kMsCarPaint>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         default: hipLaunchKernelGGL((k_shade<SVGF, kMsToon>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         }

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(uint32_t n, const atn_bvh_nod
     auto typed = [&](float link) -> int32_t {
         const int32_t l = (int32_t)link;
         if (l < 0) return kLinkEnd;
-        return (int32_t)offs[l] | (l >= num - 1 ? kLinkLeafBit : 0);
+        return (int32_t)offs[l] | (l >= num - 1 ? kLinkToLeaf : 0);
     };
     float4* q = reinterpret_cast<float4*>(reinterpret_cast<char*>(image) + offs[idx]);
     if (idx < num - 1) {

@@ -8,7 +8,9 @@ namespace atn {
 
 // BVH records.  All node lists live in ONE byte image (DevScene::nodes); a link is the BYTE offset of the target
 // record (a multiple of 16) with the target's type in the low bits: kLinkLeafBit = triangle leaf, kLinkTlasBit = TLAS
-// leaf with a nested tree, 0 = inner node; kLinkEnd (-1, both type bits set) = leave this list.  Links are explicit,
+// leaf with a nested tree, 0 = inner node; kLinkEnd (-1, both type bits set) = leave this list.  Every link that does NOT
+// name an inner record also carries the sign bit (kLinkNotInner; offsets are below 2^31): the hot loop's "is this lane on
+// an inner node" is ONE signed compare (`link >= 0`) instead of a mask and a compare.  Links are explicit,
 // so the walk order -- and therefore every hit/miss decision -- is exactly the reference's
 // (threaded_bvh_traverser.h:98-304) whatever the storage order is; records are stored in walk (pre-)order for locality.
 //
@@ -25,7 +27,10 @@ constexpr int32_t kLinkEnd = -1;
 constexpr int32_t kLinkLeafBit = 1;
 constexpr int32_t kLinkTlasBit = 2;
 constexpr int32_t kLinkTypeMask = 3;
-constexpr uint32_t kLinkOffsetMask = ~15u;
+constexpr int32_t kLinkNotInner = (int32_t)0x80000000u;   // set on leaf / TLAS-leaf links and on kLinkEnd
+constexpr int32_t kLinkToLeaf = kLinkNotInner | kLinkLeafBit;
+constexpr int32_t kLinkToTlas = kLinkNotInner | kLinkTlasBit;
+constexpr uint32_t kLinkOffsetMask = 0x7ffffff0u;
 constexpr uint32_t kInnerBytes = 32;
 constexpr uint32_t kTriLeafBytes = 48;
 constexpr uint32_t kShadeTriQuads = 8;

@@ -206,9 +206,9 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, float t_min, Trav
 {
 #pragma unroll
     for (int k = 0; k < BURST; k++) {
-        if (!(w.node & kLinkTypeMask)) {
+        if (w.node >= 0) {      // inner record (scene_dev.hpp: every other link carries the sign bit)
             float4 q0, q1;
-            ld32<LDSN>(nb, (uint32_t)w.node, q0, q1);       // type bits are 0: the link is the byte offset
+            ld32<LDSN>(nb, (uint32_t)w.node, q0, q1);       // no type bits: the link is the byte offset
             if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             const bool box = FAST ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
                                   : slab_hit_exact(w.ray, mk3(q0), mk3(q1), t_min, w.t_max);
@@ -233,8 +233,8 @@ template <bool COUNT, int BURST, class Job, bool LDSN = false>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, float t_min,
                             const Job& job, TravCounters* cnt)
 {
-    // ---- burst of inner-node steps.  kLinkEnd has both type bits set, so `(node & 3) == 0` alone selects the live
-    // lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
+    // ---- burst of inner-node steps.  kLinkEnd has the sign bit set like every link to a leaf, so `node >= 0` alone selects
+    // the live lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
     // link is its miss link): a list that ends here ended on a MISS.
     const bool live = w.node != kLinkEnd;
     if (all_finite) inner_burst<COUNT, BURST, true, LDSN>(w, nb, t_min, cnt);
@@ -244,7 +244,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
 
     // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
-    if (w.node != kLinkEnd && (w.node & kLinkTypeMask)) {
+    if (w.node != kLinkEnd && w.node < 0) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ldn<LDSN>(nb, off);
         const float4 q1 = ldn<LDSN>(nb, off + 16u);
@@ -309,7 +309,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
         const float4 q1 = ld16(nb, off + 16u);
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         bool is_hit;
-        if (!(w.node & kLinkTypeMask)) {
+        if (w.node >= 0) {
             // inner node, or a dead leaf (both links = its miss link).  An inner record's hit link is never kLinkEnd
             // (checked at upload), so a list can only end here on a miss.
             const bool box = w.ray.finite ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)
@@ -399,7 +399,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             const float4 q1 = ldn<LDSN>(nb, off + 16u);
             if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
             bool is_hit;
-            if (!(w.node & kLinkTypeMask)) {
+            if (w.node >= 0) {
                 // inner node, or a dead leaf (both links = its miss link).  An inner record's hit link is never kLinkEnd
                 // (checked at upload), so a list can only end here on a miss.
                 const bool box = w.ray.finite ? slab_hit_fast(w.ray, mk3(q0), mk3(q1), t_min, w.t_max)

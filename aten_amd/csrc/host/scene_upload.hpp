@@ -57,7 +57,7 @@ inline bool walk_order(const atn_bvh_node* nodes, uint32_t count, std::vector<in
 
 enum NodeKind : uint8_t { KIND_INNER = 0, KIND_TRI = 1, KIND_TLAS = 2, KIND_DEAD = 3 };
 inline uint32_t record_bytes(uint8_t kind) { return kind == KIND_TRI ? kTriLeafBytes : kInnerBytes; }
-inline int32_t kind_type_bits(uint8_t kind) { return kind == KIND_TRI ? kLinkLeafBit : (kind == KIND_TLAS ? kLinkTlasBit : 0); }
+inline int32_t kind_type_bits(uint8_t kind) { return kind == KIND_TRI ? kLinkToLeaf : (kind == KIND_TLAS ? kLinkToTlas : 0); }
 
 // One threaded list analysed: walk order, node kinds, depth of every node, and (filled by the layout pass) the byte
 // offset of every node's device record.

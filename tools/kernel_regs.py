@@ -11,29 +11,34 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object(lib):
+def code_objects(lib):
+    """Every gfx950 code object in the library: one clang offload bundle per translation unit."""
     data = open(lib, "rb").read()
-    at = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    if at < 0:
-        raise SystemExit("no offload bundle in %s" % lib)
     import struct
-    n = struct.unpack_from("<Q", data, at + 24)[0]
-    p = at + 32
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", data, p)
-        triple = data[p + 24:p + 24 + tl].decode()
-        p += 24 + tl
-        if "gfx950" in triple:
-            return data[at + off:at + off + size]
-    raise SystemExit("no gfx950 code object")
+    out, at = [], data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    while at >= 0:
+        n = struct.unpack_from("<Q", data, at + 24)[0]
+        p = at + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple:
+                out.append(data[at + off:at + off + size])
+        at = data.find(b"__CLANG_OFFLOAD_BUNDLE__", at + 24)
+    if not out:
+        raise SystemExit("no gfx950 code object in %s" % lib)
+    return out
 
 
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "..", "aten_amd", "libaten_amd.so")
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(lib)); f.flush()
-        notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", f.name]).decode()
+    notes = ""
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            notes += subprocess.check_output([LLVM + "/llvm-readelf", "--notes", f.name]).decode()
     for blk in notes.split("- .agpr_count:")[1:]:
         g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "?"])[1]
         name = g("name")

@@ -107,6 +107,7 @@ public:
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
+    int env_shade_waves = 0;    // ATEN_AMD_SHADE_WAVES=4|5 forces the k_shade_wn flavour (default: 5 when frames are in flight, else 4)
     int env_shade_items = 0, env_flavour = -1, env_first_simple = 1;
     uint32_t env_simple_mask = 0;       // experiment: bit b = launch b of a sample on the plain walk
 
@@ -569,6 +570,7 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_SVGF_ATROUS4")) env_atrous4 = e[0] != '0';     // 0: the one-pixel-per-thread a-trous kernel
         if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
+        if (const char* e = std::getenv("ATEN_AMD_SHADE_WAVES")) { const int v = std::atoi(e); if (v == 4 || v == 5) env_shade_waves = v; }   // else: by frames in flight
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
@@ -1078,7 +1080,10 @@ public:
     // Re-measured after the burst walk (r02_e, sponza_lod, 3 frames in flight, ms per frame of an N-way shard: refill 4.29 /
     // 2.31 / 1.29 / 0.71 vs plain 5.51 / 2.93 / 1.39 / 0.75 at 2.07 M / 1.04 M / 0.52 M / 0.26 M paths): the r01 crossover of
     // 1.9 M paths is gone, deep trees take the refill walk at every size that fills the machine at all
-    static constexpr uint32_t kRefillMinPaths = 128u * 1000u;
+    // r04, after the plain walk dropped from 84 to 63 VGPRs (8 waves per SIMD; no SLP pairing): it wins again on the 4- and 8-way shards of a
+    // 1080p frame (sponza_lod 1.157 -> 1.097 / 0.640 -> 0.608 ms, atrium 1.753 -> 1.700 / 1.112 -> 1.032 with 3 frames in flight) and loses on
+    // the 2-way shard of sponza_lod (2.13 vs 2.21) and on full frames (4.04 vs 4.47): profiles/r04_shard_matrix.txt
+    static constexpr uint32_t kRefillMinPaths = 800u * 1000u;
 
     // bytes of the LDS copy a small scene is walked from (node image + matrix rows), 0 = the scene is walked from global memory
     uint32_t lds_scene_bytes() const
@@ -1126,10 +1131,27 @@ public:
     void launch_shade(uint32_t g_shade, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, int32_t b, const SvgfShade& sv)
     {
         const dim3 g(g_shade), t(256);
+        // 5 waves per SIMD (96 registers, a few spilled) pays where shade shares the SIMDs with another frame's trace waves AND the launch is
+        // large enough not to be latency-bound itself: the Disney / analytic sets on every shard size measured, the core set on full frames
+        // only (profiles/r04_variants_shade_waves.txt, r04_shard_matrix.txt)
+        const bool big = (uint32_t)(fp.slot_end - fp.slot_begin) >= 1500u * 1000u;
+        const int shade_waves = env_shade_waves ? env_shade_waves
+                              : (frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
-        case kMsCore: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsCore>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-        case kMsDisney: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsDisney>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
-        case kMsAnalytic: hipLaunchKernelGGL((k_shade_w4<SVGF, kMsAnalytic>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
+        // (small sets: 5 waves per SIMD when frames overlap -- they share the SIMDs with another frame's trace waves --, 4 otherwise:
+        // kernels.hpp, k_shade_wn)
+        case kMsCore:
+            if (shade_waves == 5) hipLaunchKernelGGL((k_shade_wn<SVGF, kMsCore, 5>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            else hipLaunchKernelGGL((k_shade_wn<SVGF, kMsCore, 4>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            break;
+        case kMsDisney:
+            if (shade_waves == 5) hipLaunchKernelGGL((k_shade_wn<SVGF, kMsDisney, 5>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            else hipLaunchKernelGGL((k_shade_wn<SVGF, kMsDisney, 4>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            break;
+        case kMsAnalytic:
+            if (shade_waves == 5) hipLaunchKernelGGL((k_shade_wn<SVGF, kMsAnalytic, 5>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            else hipLaunchKernelGGL((k_shade_wn<SVGF, kMsAnalytic, 4>), g, t, 0, st, pb, scene, fp, camera, b, sv);
+            break;
         case kMsCarPaint: hipLaunchKernelGGL((k_shade<SVGF, kMsCarPaint>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         default: hipLaunchKernelGGL((k_shade<SVGF, kMsToon>), g, t, 0, st, pb, scene, fp, camera, b, sv); break;
         }

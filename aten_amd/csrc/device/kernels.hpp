@@ -597,14 +597,15 @@ __global__ void ATN_SHADE_ATTR __launch_bounds__(256) k_shade(PathBuffers pb, De
 {
     shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }
-// The two smallest material sets need 141 / 148 VGPRs (3 waves per SIMD); held to 128 they run 4 waves per SIMD with a
-// few spilled registers and come out ahead (sponza_lod 4.37 -> 4.30 ms, atrium 6.30 -> 6.26 ms per 1080p frame).  The
-// larger sets (160 .. 226 VGPRs) would spill too much: they keep the compiler's own allocation.
-#ifndef ATN_SHADE_SMALL_WAVES
-#define ATN_SHADE_SMALL_WAVES 4
-#endif
-template <bool SVGF, int MS>
-__global__ void __attribute__((amdgpu_waves_per_eu(ATN_SHADE_SMALL_WAVES, ATN_SHADE_SMALL_WAVES))) __launch_bounds__(256) k_shade_w4(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
+// The three smaller material sets need 124 / 125 / 131 VGPRs (built without the SLP vectoriser, build.py): held to 128 they run
+// 4 waves per SIMD without a spill.  WAVES = 5 holds them to 96 registers with 16-18 spilled ones: alone that launch is 3-6 %
+// SLOWER, but with frames in flight the shade waves of one frame share the SIMDs with the persistent trace waves of another
+// (76 VGPRs each), and two 96-register waves fit where one 124-register wave did: frame THROUGHPUT -2.9 % on the atrium, -1.7 % on
+// the Cornell box, -0.2 % on sponza_lod; latency +1-3 % (profiles/r04_variants_shade_waves.txt).  So the host launches WAVES = 5
+// when frames overlap and 4 when a caller waits for every frame.  6 waves (80 registers, 36-47 spilled) lose everywhere.
+// The larger sets (139 .. 205 VGPRs) would spill too much: they keep the compiler's own allocation (k_shade).
+template <bool SVGF, int MS, int WAVES>
+__global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_bounds__(256) k_shade_wn(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t bounce, SvgfShade sv)
 {
     shade_body<SVGF, MS>(pb, sc, fp, cam, bounce, sv);
 }

@@ -169,7 +169,7 @@ public:
     // current bank; render() rotates them with the spare banks, so frame f + 1 is enqueued on another stream while frame
     // f's launch tails (a few long rays keep a handful of waves alive at the end of every trace launch) still run.
     // Only the film orders consecutive frames: a frame's k_gather waits for the previous frame's.
-    static constexpr int kMaxInFlight = 4;
+    static constexpr int kMaxInFlight = 4;      // (5 / 6 / 8 banks with 8 hardware queues: no gain, profiles/r04_variants_shade_waves.txt)
     struct Bank {
         DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
         DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;

@@ -720,3 +720,45 @@ def test_node_image_in_lds_equals_global_memory_walk(orc, cornell, which):
     seeds = orc.init_sampler(w, h, 0)
     inside, mean_err = frame_tolerance_report(films["1"], orc.render(fs, c, seeds, w, h, frame=0))
     assert inside >= 0.995 and mean_err <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["core", "disney", "analytic"])
+def test_shade_at_five_waves_per_simd_equals_four(orc, cornell, which):
+    """k_shade_wn<., ., 5> (96 registers, a few spilled: what the host launches when frames are in flight, kernels.hpp) is the
+    same code under another register budget: films byte-equal to the 4-wave kernel's for every material set that has both,
+    with one frame at a time and with three in flight."""
+    from aten_amd import layout as L
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    w, h = 160, 120
+    if which == "core":
+        fs, cam = cornell
+    elif which == "disney":
+        fs, cam = scenedefs.sponza_lod(mtype=L.MTRL_DISNEY)
+    else:
+        fs, cam = scenedefs.cornell_box_variant(lights="area", move_boxes=True, extra_materials="rough")
+    c = make_camera(orc, cam, w, h)
+    films = {}
+    old = os.environ.get("ATEN_AMD_SHADE_WAVES")
+    try:
+        for waves in ("4", "5"):
+            os.environ["ATEN_AMD_SHADE_WAVES"] = waves      # read when the context is created
+            r = PathTracing(0)
+            try:
+                r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+                for fif in (1, 3):
+                    r.set_frames_in_flight(fif)
+                    r.reset()
+                    for frame in range(3):
+                        film = r.render(w, h, 5, 3, frame=frame)
+                    films[(waves, fif)] = film.copy()
+            finally:
+                r.close()
+    finally:
+        if old is None: os.environ.pop("ATEN_AMD_SHADE_WAVES", None)
+        else: os.environ["ATEN_AMD_SHADE_WAVES"] = old
+    ref = films[("4", 1)]
+    assert np.nanmax(ref[..., :3]) > 0      # (pixels whose every sample was invalid are NaN, as in the reference)
+    for k, f in films.items():
+        assert f.tobytes() == ref.tobytes(), k

@@ -126,6 +126,7 @@ public:
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
     uint32_t top_base = 0, n_host_matrices = 0;
+    std::vector<atn_mat4> host_matrices;    // the caller's matrices as last uploaded
     std::vector<uint32_t> list_base, list_bytes, list_tri_leaves, list_inner;   // region of every list in the node image
     uint32_t n_scene_tris = 0, n_scene_vtx = 0, n_scene_mtrls = 0;
 
@@ -676,6 +677,7 @@ public:
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
         n_bottom_nodes = img.n_nodes - s->bvh_lists[0].count;
         n_host_matrices = s->n_matrices;
+        host_matrices.assign(s->matrices, s->matrices + s->n_matrices);     // (update_tlas without matrices still recognises identity instances)
         tree_is_deep = img.n_nodes >= kRefillMinNodes;
         use_refill = tree_is_deep;
         flavour_forced = false;
@@ -749,6 +751,7 @@ public:
         }
         ListEmitCtx c;
         c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
+        c.matrices = n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr);
         c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
         const size_t top_bytes = lay.order.size() * (size_t)kInnerBytes;
         std::vector<float4> rec(top_bytes / 16 + 1, make_float4(0, 0, 0, 0));
@@ -786,11 +789,12 @@ public:
         { int r = begin_scene_update(top_bytes + obj_bytes + mtx_bytes + 512); if (r) return r; }
         { int r = stage_copy(reinterpret_cast<char*>(nodes.p) + top_base, rec.data(), top_bytes); if (r) return r; log_range(SB_NODES, top_base, top_bytes); }
         { int r = stage_copy(objects.p, objs, obj_bytes); if (r) return r; log_range(SB_OBJECTS, 0, obj_bytes); }
-        if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; }
+        if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; host_matrices.assign(mtxs, mtxs + n_mtxs); }
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
         scene.root_link = root;
         scene.node_bytes = (uint32_t)(top_base + top_bytes);
+        scene.ident_row = c.ident_row;
         if (n_mtxs) scene.mtx_quads = (uint32_t)mv.size();
         point_scene_at_current_set();
         tree_is_deep = n_bottom_nodes + n_top >= kRefillMinNodes;

@@ -19,7 +19,10 @@ namespace atn {
 //              (v0, e1 = v1 - v0, e2 = v2 - v0 of the leaf's triangle: the three dependent
 //               gathers node -> TriangleParameter -> 3 vertices become one 48-byte read;
 //               e1/e2 are the same IEEE subtractions intersectTriangle performs, done at upload)
-//   TLAS leaf (32 B): q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), BLAS root link, 0}
+//   TLAS leaf (32 B): q0 = {objid, w2l_row (index of W2L's first row in `matrices`, or -1), BLAS root link, flags}
+//                     flags bit 0 (kTlasIdentity): W2L is bit for bit the identity matrix, so the ray inside this instance is the SAME
+//                     for every such instance -- mat4::applyRay(I, ray), which is not the world ray: the direction is re-normalised --
+//                     and the plain walk over an LDS copy computes it once per ray (DevScene::ident_row, traverse.hpp)
 //                     q1 = {meshid, top hit link, top miss link, 0}
 //   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
 //              path); an inner record whose hit link IS its miss link.
@@ -31,6 +34,7 @@ constexpr int32_t kLinkNotInner = (int32_t)0x80000000u;   // set on leaf / TLAS-
 constexpr int32_t kLinkToLeaf = kLinkNotInner | kLinkLeafBit;
 constexpr int32_t kLinkToTlas = kLinkNotInner | kLinkTlasBit;
 constexpr uint32_t kLinkOffsetMask = 0x7ffffff0u;
+constexpr int32_t kTlasIdentity = 1;
 constexpr uint32_t kInnerBytes = 32;
 constexpr uint32_t kTriLeafBytes = 48;
 constexpr uint32_t kShadeTriQuads = 8;
@@ -118,6 +122,7 @@ struct DevScene {
     float ibl_scene_radius;             // ImageBasedLight::sample's scene_radius (ibl.h:106-111), precomputed on host
     uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
     uint32_t mtx_quads;                 // float4 rows in `matrices` (the LDS copy holds them behind the node image)
+    int32_t ident_row;                  // w2l_row of one TLAS leaf flagged kTlasIdentity, -1 = none
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

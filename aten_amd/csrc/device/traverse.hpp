@@ -157,12 +157,19 @@ ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, c
 // Per-lane state of one walk.  A lane is idle <=> node == kLinkEnd at the top of an iteration.
 struct Walk {
     RaySlab wray, ray;      // world-space ray and the ray of the list being walked (transformed inside a nested tree)
+    RaySlab lray;           // IDENT walks only: the ray inside an instance whose W2L is the identity matrix (walk_start)
     Hit hit;
     float t_max, stop_t;
     uint32_t payload;
     int32_t node, objid, meshid, top_hit, top_miss;
 };
 
+// IDENT (the plain walk over an LDS copy of a small scene): instances whose W2L is bit for bit the identity matrix (TLAS-leaf flag
+// kTlasIdentity, set at upload) all see the SAME local ray -- mat4::applyRay(I, ray): the origin through the matrix product, the
+// direction re-normalised, NOT the world ray -- so it is computed here once per ray, with every lane of the wave taking part, instead
+// of once per instance entered by whichever lanes stand on a TLAS leaf (the Cornell box: 8 identity instances, ~3 entered per ray;
+// the ~130-instruction TLAS-leaf block was 40 % of that walk's VALU).  Same operations on the same operands: same bits.
+template <bool IDENT = false>
 ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t)
 {
     w.t_max = a.w;
@@ -172,6 +179,16 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
     slab_setup(w.wray, mk3(a), mk3(b));
     w.ray = w.wray;
     w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+    if constexpr (IDENT) {
+        if (sc.ident_row >= 0) {        // wave-uniform
+            m4 m;
+            m.r0 = ldm<true>(sc, sc.ident_row + 0); m.r1 = ldm<true>(sc, sc.ident_row + 1);
+            m.r2 = ldm<true>(sc, sc.ident_row + 2); m.r3 = ldm<true>(sc, sc.ident_row + 3);
+            const f3 o = m4_apply(m, w.wray.org);
+            const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
+            slab_setup(w.lray, o, d);
+        }
+    }
 }
 
 #ifndef ATN_INNER_BURST
@@ -264,7 +281,10 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             w.meshid = __float_as_int(q1.x);
             w.top_hit = __float_as_int(q1.y);
             w.top_miss = __float_as_int(q1.z);
-            if (w2l >= 0) {
+            if (LDSN && (__float_as_int(q0.w) & kTlasIdentity)) {
+                w.ray = w.lray;                 // identity instance: walk_start<true> has the local ray
+            }
+            else if (w2l >= 0) {
                 // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
                 m4 m;
                 m.r0 = ldm<LDSN>(sc, w2l + 0); m.r1 = ldm<LDSN>(sc, w2l + 1);
@@ -291,7 +311,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             float4 ra, rb;
             float rstop;
             if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
-            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start(w, sc, ra, rb, rstop);
+            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start<LDSN>(w, sc, ra, rb, rstop);
         }
     }
     // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
@@ -384,14 +404,14 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             // for a handful of lanes.  The burst form of the step (walk_iteration: kSimpleBurstLds inner-node steps, then ONE
             // step for the lanes on a leaf) issues them once per burst: Cornell 1080p trace 1.11 -> 1.00 ms per frame.
             // (From global memory the same form LOSES -- 1.85 -> 2.08 ms, r02 -- there the waiting lanes cost more.)
-            walk_start(w, sc, a, b, stop_t);
+            walk_start<true>(w, sc, a, b, stop_t);
             bool all_finite = __all(w.ray.finite) != 0;
             while (__any(w.node != kLinkEnd))
                 walk_iteration<COUNT, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
             continue;
         }
       restart:
-        walk_start(w, sc, a, b, stop_t);
+        walk_start<LDSN>(w, sc, a, b, stop_t);
         // (the loop of walk_run, spelled out: as a call the compiler lays the kernel out 4 % slower on Cornell 1080p)
         while (w.node != kLinkEnd) {
             const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
@@ -422,7 +442,10 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                 w.meshid = __float_as_int(q1.x);
                 w.top_hit = __float_as_int(q1.y);
                 w.top_miss = __float_as_int(q1.z);
-                if (w2l >= 0) {
+                if (LDSN && (__float_as_int(q0.w) & kTlasIdentity)) {
+                    w.ray = w.lray;             // identity instance: walk_start<true> has the local ray
+                }
+                else if (w2l >= 0) {
                     // mat4::applyRay (mat4.h:223-235): the ray(org, dir) constructor re-normalises dir
                     m4 m;
                     m.r0 = ldm<LDSN>(sc, w2l + 0); m.r1 = ldm<LDSN>(sc, w2l + 1);
@@ -537,7 +560,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 const uint32_t avail = c_count - c_next;
                 if (w.node == kLinkEnd) {
                     const uint32_t k = (uint32_t)__popcll(m_idle & lt);
-                    if (k < avail) walk_start(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
+                    if (k < avail) walk_start<LDSN>(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
                 }
                 c_next += n_idle < avail ? n_idle : avail;
                 all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;

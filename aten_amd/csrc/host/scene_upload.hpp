@@ -118,7 +118,16 @@ struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
     const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0, n_vertices = 0;
     const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
+    const atn_mat4* matrices = nullptr;     // the matrices the TLAS leaves' rows index (null: identity instances are not recognised)
+    mutable int32_t ident_row = -1;         // out: w2l_row of an instance whose W2L is bit for bit the identity
 };
+
+// mat4 == identity, bit for bit (+0.0 zeros): applying it is the same arithmetic for every instance that has it
+inline bool is_exact_identity(const atn_mat4& m)
+{
+    static const float I[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    return std::memcmp(m.m, I, sizeof(I)) == 0;
+}
 
 // Writes the device records of one analysed list (offsets already assigned) into the byte image `img`.
 // (`img` + offset - write_bias is where a record goes: write_bias > 0 when `img` holds only the image's tail.)
@@ -160,7 +169,9 @@ inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, c
                 if ((uint32_t)obj.mtx_id + 1 >= c.n_matrices) { err = "object matrix index out of range"; return false; }
                 w2l_row = 4 * (obj.mtx_id + 1);              // traverser reads GetMatrix(mtx_id + 1), :153
             }
-            q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), 0.0F);
+            int32_t flags = 0;
+            if (w2l_row >= 0 && c.matrices && is_exact_identity(c.matrices[obj.mtx_id + 1])) { flags |= kTlasIdentity; if (c.ident_row < 0) c.ident_row = w2l_row; }
+            q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), i2f(flags));
             q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), 0.0F);
             counts[2]++;
             break;
@@ -255,7 +266,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     img.n_nodes = total_nodes;
 
     ListEmitCtx c;
-    c.objects = s->objects; c.n_objects = s->n_objects; c.n_matrices = s->n_matrices;
+    c.objects = s->objects; c.n_objects = s->n_objects; c.n_matrices = s->n_matrices; c.matrices = s->matrices;
     c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles; c.n_vertices = s->n_vertices;
     c.n_lists = nl;
     uint64_t counts[3] = { 0, 0, 0 };
@@ -268,6 +279,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
     img.params.node_bytes = (uint32_t)off;
+    img.params.ident_row = c.ident_row;
 
     // ---- plain copies
     img.tris.assign(s->triangles, s->triangles + s->n_triangles);

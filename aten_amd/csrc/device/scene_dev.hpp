@@ -123,6 +123,9 @@ struct DevScene {
     uint32_t node_bytes;                // size of the whole node image (a tree of a few KB is walked from an LDS copy: trace_simple<., ., true>)
     uint32_t mtx_quads;                 // float4 rows in `matrices` (the LDS copy holds them behind the node image)
     int32_t ident_row;                  // w2l_row of one TLAS leaf flagged kTlasIdentity, -1 = none
+    // The top layer is ONE leaf (a scene = one instance: sponza, the atrium): its record, so that a walk can start INSIDE the nested
+    // tree (walk_start) instead of standing on the leaf through its first burst.  root_direct = 0: walks start at root_link.
+    int32_t root_direct, root_objid, root_meshid, root_w2l, root_blas, root_flags;
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

@@ -169,13 +169,36 @@ struct Walk {
 // direction re-normalised, NOT the world ray -- so it is computed here once per ray, with every lane of the wave taking part, instead
 // of once per instance entered by whichever lanes stand on a TLAS leaf (the Cornell box: 8 identity instances, ~3 entered per ray;
 // the ~130-instruction TLAS-leaf block was 40 % of that walk's VALU).  Same operations on the same operands: same bits.
-template <bool IDENT = false>
-ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t)
+// DIRECT START (DevScene::root_direct, wave-uniform): when the top layer is one leaf, every ray's first visit is that leaf, and a
+// lane standing on a leaf sits out a whole burst before the leaf step lets it into the nested tree -- 5 of a ray's ~70 lane slots.
+// The leaf's record travels in the kernel arguments instead and the walk starts INSIDE the nested tree: the leaf step's
+// operations (mat4::applyRay, slab constants of the local ray) are done here, the world-space slab constants -- never used: there
+// is no top-layer box to test and the walk ends when the nested list ends -- are not computed at all.  The visit is still counted.
+template <bool IDENT = false, bool COUNT = false>
+ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const float4& b, float stop_t, TravCounters* cnt = nullptr)
 {
     w.t_max = a.w;
     w.stop_t = stop_t;
     w.payload = __float_as_uint(b.w);
     w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
+    if (sc.root_direct) {
+        if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
+        w.wray.org = mk3(a); w.wray.dir = mk3(b); w.wray.invdir = mk3(0.0F); w.wray.oxinvdir = mk3(0.0F); w.wray.finite = true;
+        if (sc.root_w2l >= 0) {
+            m4 m;
+            m.r0 = ldm<IDENT>(sc, sc.root_w2l + 0); m.r1 = ldm<IDENT>(sc, sc.root_w2l + 1);
+            m.r2 = ldm<IDENT>(sc, sc.root_w2l + 2); m.r3 = ldm<IDENT>(sc, sc.root_w2l + 3);
+            const f3 o = m4_apply(m, w.wray.org);
+            const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
+            slab_setup(w.ray, o, d);
+        }
+        else {
+            slab_setup(w.ray, w.wray.org, w.wray.dir);
+        }
+        w.lray = w.ray;
+        w.node = sc.root_blas; w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+        return;
+    }
     slab_setup(w.wray, mk3(a), mk3(b));
     w.ray = w.wray;
     w.node = sc.root_link; w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
@@ -311,7 +334,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             float4 ra, rb;
             float rstop;
             if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
-            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start<LDSN>(w, sc, ra, rb, rstop);
+            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt);
         }
     }
     // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
@@ -404,14 +427,14 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             // for a handful of lanes.  The burst form of the step (walk_iteration: kSimpleBurstLds inner-node steps, then ONE
             // step for the lanes on a leaf) issues them once per burst: Cornell 1080p trace 1.11 -> 1.00 ms per frame.
             // (From global memory the same form LOSES -- 1.85 -> 2.08 ms, r02 -- there the waiting lanes cost more.)
-            walk_start<true>(w, sc, a, b, stop_t);
+            walk_start<true, COUNT>(w, sc, a, b, stop_t, cnt);
             bool all_finite = __all(w.ray.finite) != 0;
             while (__any(w.node != kLinkEnd))
                 walk_iteration<COUNT, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
             continue;
         }
       restart:
-        walk_start<LDSN>(w, sc, a, b, stop_t);
+        walk_start<LDSN, COUNT>(w, sc, a, b, stop_t, cnt);
         // (the loop of walk_run, spelled out: as a call the compiler lays the kernel out 4 % slower on Cornell 1080p)
         while (w.node != kLinkEnd) {
             const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
@@ -560,7 +583,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 const uint32_t avail = c_count - c_next;
                 if (w.node == kLinkEnd) {
                     const uint32_t k = (uint32_t)__popcll(m_idle & lt);
-                    if (k < avail) walk_start<LDSN>(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k]);
+                    if (k < avail) walk_start<LDSN, COUNT>(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k], cnt);
                 }
                 c_next += n_idle < avail ? n_idle : avail;
                 all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;

@@ -129,6 +129,22 @@ inline bool is_exact_identity(const atn_mat4& m)
     return std::memcmp(m.m, I, sizeof(I)) == 0;
 }
 
+// DevScene::root_*: filled when the top layer's root is a TLAS leaf whose two top links end the walk (a one-node top layer).
+// `image` = host copy of the node image from byte `bias` on.
+inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias)
+{
+    p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0;
+    if (p.root_link == kLinkEnd || p.root_link >= 0 || (p.root_link & kLinkTypeMask) != kLinkTlasBit) return;
+    const uint32_t off = (uint32_t)p.root_link & kLinkOffsetMask;
+    if (off < bias) return;
+    const float4* q = image + (off - bias) / 16;
+    auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    if (f2i(q[1].y) != kLinkEnd || f2i(q[1].z) != kLinkEnd) return;
+    p.root_direct = 1;
+    p.root_objid = f2i(q[0].x); p.root_w2l = f2i(q[0].y); p.root_blas = f2i(q[0].z); p.root_flags = f2i(q[0].w);
+    p.root_meshid = f2i(q[1].x);
+}
+
 // Writes the device records of one analysed list (offsets already assigned) into the byte image `img`.
 // (`img` + offset - write_bias is where a record goes: write_bias > 0 when `img` holds only the image's tail.)
 inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, const ListEmitCtx& c,
@@ -370,6 +386,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
 
     DevScene& p = img.params;
     p.root_link = img.list_root_link[0];
+    fill_root_direct(p, img.nodes.data(), 0);
     p.n_lights = (int32_t)s->n_lights; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
     p.bvh_hit_min = s->config.bvh_hit_min;
     p.bg_color[0] = s->config.bg.bg_color[0]; p.bg_color[1] = s->config.bg.bg_color[1]; p.bg_color[2] = s->config.bg.bg_color[2];

@@ -269,9 +269,20 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, float t_min, Trav
 // lane's slab constants are finite (`all_finite`, wave-uniform, refreshed only where rays change), the select form --
 // valid for all inputs -- otherwise.
 // A ray's own sequence of operations is the reference walk's, so results stay bit-identical.
+// The TLAS-leaf step (two matrix products, normalize, slab constants of the local ray: ~130 VALU, three IEEE divides and a square
+// root among them) costs the wave the same for one lane as for sixty.  In a scene of several instances (the atrium: 8) some lane
+// of a refilled wave stands on a TLAS leaf in practically every iteration, so the block rode along with every burst -- a third
+// of the iteration's VALU for ~6 lanes.  The refill walk therefore lets lanes into nested trees only every ATN_TLAS_PERIOD-th
+// iteration; they stand for at most PERIOD - 1 iterations.  Which iteration a lane takes a step in never changes what the step
+// computes.  (atrium fused trace 5.25 -> 5.06 ms; period 2 / 3 / 4: 5.12 / 5.06 / 5.08; "or as soon as 6 / 12 lanes wait" on top:
+// slower -- the ballot is on the critical path of every iteration -- profiles/r04_variants_tlas_period.txt.)  One-instance scenes
+// start inside the nested tree (walk_start) and never get here.
+#ifndef ATN_TLAS_PERIOD
+#define ATN_TLAS_PERIOD 3
+#endif
 template <bool COUNT, int BURST, class Job, bool LDSN = false>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, float t_min,
-                            const Job& job, TravCounters* cnt)
+                            const Job& job, TravCounters* cnt, uint32_t iter = 0)
 {
     // ---- burst of inner-node steps.  kLinkEnd has the sign bit set like every link to a leaf, so `node >= 0` alone selects
     // the live lanes on inner nodes.  An inner record's hit link is never kLinkEnd (checked at upload; a dead leaf's "hit"
@@ -283,8 +294,9 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     bool is_hit = false;                        // ... and this was the result of its last step
 
     // ---- one step for the lanes on a triangle leaf or a TLAS leaf (both read the record's first two quarters)
-    const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit;
-    if (w.node != kLinkEnd && w.node < 0) {
+    const bool tlas_turn = LDSN || ATN_TLAS_PERIOD <= 1 || (iter % (uint32_t)ATN_TLAS_PERIOD) == 0u;      // wave-uniform
+    const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit && tlas_turn;
+    if (w.node != kLinkEnd && w.node < 0 && ((w.node & kLinkLeafBit) || tlas_turn)) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
         const float4 q0 = ldn<LDSN>(nb, off);
         const float4 q1 = ldn<LDSN>(nb, off + 16u);
@@ -536,6 +548,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     bool first_chunk = true;            // wave-uniform
     bool all_finite = true;             // wave-uniform: every live lane's current slab constants are finite
+    uint32_t iter = 0;                  // wave-uniform
     Walk w;
     slab_setup(w.wray, mk3(0.0F), mk3(0.0F, 0.0F, 1.0F));
     w.ray = w.wray;
@@ -592,7 +605,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        walk_iteration<COUNT, kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
+        walk_iteration<COUNT, kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt, iter++);
     }
 }
 

@@ -158,6 +158,7 @@ ATN_DEV bool leaf_test(const RaySlab& ray, const float4& q0, const float4& q1, c
 struct Walk {
     RaySlab wray, ray;      // world-space ray and the ray of the list being walked (transformed inside a nested tree)
     RaySlab lray;           // IDENT walks only: the ray inside an instance whose W2L is the identity matrix (walk_start)
+    bool pending;           // DEFER walks only: the walk is over, Job::finish has not run yet (walk_finish)
     Hit hit;
     float t_max, stop_t;
     uint32_t payload;
@@ -280,7 +281,7 @@ ATN_DEV void inner_burst(Walk& w, const char* __restrict__ nb, float t_min, Trav
 #ifndef ATN_TLAS_PERIOD
 #define ATN_TLAS_PERIOD 3
 #endif
-template <bool COUNT, int BURST, class Job, bool LDSN = false>
+template <bool COUNT, int BURST, class Job, bool LDSN = false, bool DEFER = false>
 ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const char* __restrict__ nb, float t_min,
                             const Job& job, TravCounters* cnt, uint32_t iter = 0)
 {
@@ -343,10 +344,13 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
         w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         w.ray = w.wray;
         if (w.node == kLinkEnd) {
-            float4 ra, rb;
-            float rstop;
-            if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
-            if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt);
+            if constexpr (DEFER) w.pending = true;      // the lane is idle from here on; walk_finish runs with the next refill
+            else {
+                float4 ra, rb;
+                float rstop;
+                if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
+                if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt);
+            }
         }
     }
     // rays changed in the two blocks above: refresh the wave's slab-form flag (cheap, and only then)
@@ -531,6 +535,27 @@ struct TraceShared {
 // (XCD-affine job lists -- rays filed by the cell of their origin, a block draining its own XCD's list first -- were built and
 // measured in r04: L2 hit 0.79 -> 0.85 and fabric reads -41 % on the 250 K-triangle atrium, and the launch no faster.
 // profiles/r04_variants_ray_cells.txt; code in git history, commit "Ray cells".)
+#ifndef ATN_DEFER_FINISH
+#define ATN_DEFER_FINISH 1
+#endif
+// Job::finish for the lanes whose walk ended since the last call (Walk::pending).  A finished lane is idle until the wave
+// refills -- 16 idle lanes -- so the refill walk finishes its rays THEN, all of them at once: the finish block (hit record or
+// shadow result: ~55 VALU, ~80 SALU, 9 memory instructions) used to ride along with every iteration for the one or two lanes
+// whose walk had just ended.  true = some lane's job handed back another ray to walk (a shadow ray behind an ignored surface).
+template <bool COUNT, class Job, bool LDSN>
+ATN_DEV bool walk_finish(Walk& w, const DevScene& sc, const Job& job, TravCounters* cnt)
+{
+    bool restarted = false;
+    if (w.pending) {
+        w.pending = false;
+        float4 ra, rb;
+        float rstop;
+        if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
+        if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) { walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt); restarted = true; }
+    }
+    return __any(restarted) != 0;
+}
+
 template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)
@@ -556,12 +581,19 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     w.t_max = 0.0F; w.stop_t = -kInf; w.payload = 0;
     w.hit.t = kInf; w.hit.objid = -1; w.hit.tri = -1; w.hit.a = 0.0F; w.hit.b = 0.0F; w.hit.meshid = -1;
     w.objid = -1; w.meshid = -1; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+    w.pending = false;
 
     for (;;) {
         // ---- refill
-        const unsigned long long m_idle = __ballot(w.node == kLinkEnd);
-        const uint32_t n_idle = (uint32_t)__popcll(m_idle);
+        unsigned long long m_idle = __ballot(w.node == kLinkEnd);
+        uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle >= kRefillLanes) {
+            // the rays that ended since the last refill are finished here, together (walk_finish)
+            if (walk_finish<COUNT, Job, LDSN>(w, sc, job, cnt)) {
+                m_idle = __ballot(w.node == kLinkEnd);
+                n_idle = (uint32_t)__popcll(m_idle);
+                all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;
+            }
             if (c_next >= c_count && !drained) {
                 // The first chunk of every wave is pre-assigned (chunk index = global wave id) and the shared
                 // cursor starts after those: a same-address atomic retires only every ~11 ns, so a launch that
@@ -605,7 +637,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
                 break;          // drained, chunk empty, nothing in flight
             }
         }
-        walk_iteration<COUNT, kInnerBurst, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt, iter++);
+        walk_iteration<COUNT, kInnerBurst, Job, LDSN, ATN_DEFER_FINISH != 0>(w, all_finite, sc, nb, t_min, job, cnt, iter++);
     }
 }
 

@@ -415,6 +415,27 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
     }
 }
 
+#ifndef ATN_DEFER_FINISH
+#define ATN_DEFER_FINISH 1
+#endif
+// Job::finish for the lanes whose walk ended since the last call (Walk::pending).  A finished lane is idle until the wave
+// refills -- 16 idle lanes -- so the refill walk finishes its rays THEN, all of them at once: the finish block (hit record or
+// shadow result: ~55 VALU, ~80 SALU, 9 memory instructions) used to ride along with every iteration for the one or two lanes
+// whose walk had just ended.  true = some lane's job handed back another ray to walk (a shadow ray behind an ignored surface).
+template <bool COUNT, class Job, bool LDSN>
+ATN_DEV bool walk_finish(Walk& w, const DevScene& sc, const Job& job, TravCounters* cnt)
+{
+    bool restarted = false;
+    if (w.pending) {
+        w.pending = false;
+        float4 ra, rb;
+        float rstop;
+        if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
+        if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) { walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt); restarted = true; }
+    }
+    return __any(restarted) != 0;
+}
+
 // Plain flavour: one ray per lane for the lifetime of its walk, grid-stride over the jobs; every iteration offers every
 // node kind.  Without refill a wave lasts as long as its longest ray, so what counts here is the latency of a single
 // walk, and making lanes wait at leaves for the end of a burst (walk_iteration) only lengthens it: measured on MI355X
@@ -443,10 +464,17 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
             // for a handful of lanes.  The burst form of the step (walk_iteration: kSimpleBurstLds inner-node steps, then ONE
             // step for the lanes on a leaf) issues them once per burst: Cornell 1080p trace 1.11 -> 1.00 ms per frame.
             // (From global memory the same form LOSES -- 1.85 -> 2.08 ms, r02 -- there the waiting lanes cost more.)
+            // Job::finish runs ONCE per wave, when every lane's walk is over (walk_finish), not in every iteration in which some
+            // lane's walk ends -- without refill a finished lane has nothing to do anyway
             walk_start<true, COUNT>(w, sc, a, b, stop_t, cnt);
+            w.pending = false;
             bool all_finite = __all(w.ray.finite) != 0;
-            while (__any(w.node != kLinkEnd))
-                walk_iteration<COUNT, kSimpleBurstLds, Job, LDSN>(w, all_finite, sc, nb, t_min, job, cnt);
+            for (;;) {
+                while (__any(w.node != kLinkEnd))
+                    walk_iteration<COUNT, kSimpleBurstLds, Job, LDSN, true>(w, all_finite, sc, nb, t_min, job, cnt);
+                if (!walk_finish<COUNT, Job, LDSN>(w, sc, job, cnt)) break;
+                all_finite = __all(w.node == kLinkEnd || w.ray.finite) != 0;    // (a shadow ray restarted behind an ignored surface)
+            }
             continue;
         }
       restart:
@@ -535,27 +563,6 @@ struct TraceShared {
 // (XCD-affine job lists -- rays filed by the cell of their origin, a block draining its own XCD's list first -- were built and
 // measured in r04: L2 hit 0.79 -> 0.85 and fabric reads -41 % on the 250 K-triangle atrium, and the launch no faster.
 // profiles/r04_variants_ray_cells.txt; code in git history, commit "Ray cells".)
-#ifndef ATN_DEFER_FINISH
-#define ATN_DEFER_FINISH 1
-#endif
-// Job::finish for the lanes whose walk ended since the last call (Walk::pending).  A finished lane is idle until the wave
-// refills -- 16 idle lanes -- so the refill walk finishes its rays THEN, all of them at once: the finish block (hit record or
-// shadow result: ~55 VALU, ~80 SALU, 9 memory instructions) used to ride along with every iteration for the one or two lanes
-// whose walk had just ended.  true = some lane's job handed back another ray to walk (a shadow ray behind an ignored surface).
-template <bool COUNT, class Job, bool LDSN>
-ATN_DEV bool walk_finish(Walk& w, const DevScene& sc, const Job& job, TravCounters* cnt)
-{
-    bool restarted = false;
-    if (w.pending) {
-        w.pending = false;
-        float4 ra, rb;
-        float rstop;
-        if (COUNT) { job.cost(w.payload, cnt->ray_nodes, cnt->ray_tris); cnt->ray_nodes = 0; cnt->ray_tris = 0; }
-        if (job.finish(w.payload, w.hit, w.hit.objid >= 0, ra, rb, rstop)) { walk_start<LDSN, COUNT>(w, sc, ra, rb, rstop, cnt); restarted = true; }
-    }
-    return __any(restarted) != 0;
-}
-
 template <bool COUNT, class Job, bool LDSN = false>
 ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, uint32_t* fetch_counter,
                           const Job& job, TravCounters* cnt)

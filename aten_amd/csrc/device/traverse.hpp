@@ -89,6 +89,22 @@ ATN_DEV float4 ld16(const char* base, uint32_t byte_off)
     return *reinterpret_cast<const float4*>(base + byte_off);
 }
 
+// A 16-byte quarter of a record through a BUFFER load (raw buffer over the node image).  Same path through the L1 as a global load,
+// but an intrinsic the optimiser cannot split: with plain loads the leaf step's second quarter -- whose four components are used
+// by different branches (triangle leaf: e1 and the next link; TLAS leaf: mesh id and the two top links) -- was fetched by TWO
+// instructions (dwordx3 before the branch + dword inside it), and a wave load costs the L1 ~16 clocks however narrow it is (DESIGN.md
+// section 6): 4 loads per leaf step instead of 3.
+typedef int atn_v4i __attribute__((ext_vector_type(4)));
+ATN_DEV __amdgpu_buffer_rsrc_t node_rsrc(const DevScene& sc)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, 0, (int)sc.node_bytes, 0x00020000);     // raw, 32-bit data format
+}
+ATN_DEV float4 ld16_buf(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    const atn_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
 // The block's dynamic LDS: the WHOLE node image of a small scene (LDSN).
 extern __shared__ float4 atn_dyn_lds[];
 // a 16-byte quarter of a node record: from global memory, or -- LDSN -- from the block's LDS copy of the node image
@@ -299,11 +315,14 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     const bool at_tlas = w.node != kLinkEnd && (w.node & kLinkTypeMask) == kLinkTlasBit && tlas_turn;
     if (w.node != kLinkEnd && w.node < 0 && ((w.node & kLinkLeafBit) || tlas_turn)) {
         const uint32_t off = (uint32_t)w.node & kLinkOffsetMask;
-        const float4 q0 = ldn<LDSN>(nb, off);
-        const float4 q1 = ldn<LDSN>(nb, off + 16u);
+        float4 q0, q1;
+        if constexpr (LDSN) { q0 = ldn<true>(nb, off); q1 = ldn<true>(nb, off + 16u); }
+        else { const __amdgpu_buffer_rsrc_t rs = node_rsrc(sc); q0 = ld16_buf(rs, off); q1 = ld16_buf(rs, off + 16u); }
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         if (w.node & kLinkLeafBit) {
-            const float4 q2 = ldn<LDSN>(nb, off + 32u);
+            float4 q2;
+            if constexpr (LDSN) q2 = ldn<true>(nb, off + 32u);
+            else q2 = ld16_buf(node_rsrc(sc), off + 32u);
             if (COUNT) { cnt->tris++; cnt->ray_tris++; }
             bool accept; float t;
             is_hit = leaf_test(w.ray, q0, q1, q2, t_min, w.hit, w.t_max, w.objid, w.meshid, accept, t);
@@ -342,7 +361,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
     if (ended) {
         w.node = is_hit ? w.top_hit : w.top_miss;
         w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
-        w.ray = w.wray;
+        if (w.node != kLinkEnd) w.ray = w.wray;     // (13 registers: only for the lanes that go on in the top layer)
         if (w.node == kLinkEnd) {
             if constexpr (DEFER) w.pending = true;      // the lane is idle from here on; walk_finish runs with the next refill
             else {

@@ -762,3 +762,77 @@ def test_shade_at_five_waves_per_simd_equals_four(orc, cornell, which):
     assert np.nanmax(ref[..., :3]) > 0      # (pixels whose every sample was invalid are NaN, as in the reference)
     for k, f in films.items():
         assert f.tobytes() == ref.tobytes(), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("matrix", ["identity", "moved"])
+def test_one_instance_scene_starts_inside_the_nested_tree(orc, matrix):
+    """A top layer of ONE leaf: its record travels in the kernel arguments and every walk starts inside the nested tree
+    (walk_start, DevScene::root_*) -- with the identity matrix (mat4::applyRay still re-normalises the direction) and with a real
+    transform, on the refill walk, the plain walk from global memory and the plain walk over an LDS copy: `Intersection` records AND
+    visit counters equal the oracle's (the top-layer leaf's visit is still counted), films byte-equal between the flavours."""
+    import math
+    from aten_amd import layout as L
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene.builder import SceneBuilder
+    b = SceneBuilder()
+    m = b.add_material("m", L.MTRL_DIFFUSE, (0.7, 0.6, 0.5))
+    # a bumpy 12 x 12 grid: 288 triangles, ~ 16 KB of records (fits the LDS copy)
+    n = 13
+    xs, zs = np.meshgrid(np.linspace(-1, 1, n, dtype=np.float32), np.linspace(-1, 1, n, dtype=np.float32), indexing="ij")
+    ys = (0.15 * np.sin(3 * xs) * np.cos(2 * zs)).astype(np.float32)
+    pos = np.stack([xs, ys, zs], -1).reshape(-1, 3)
+    idx = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, bb, c, d = i * n + j, i * n + j + 1, (i + 1) * n + j, (i + 1) * n + j + 1
+            idx += [(a, bb, d), (a, d, c)]
+    obj = b.add_mesh("grid", pos, np.asarray(idx), m)
+    if matrix == "identity":
+        b.create_instance(obj)
+    else:
+        t = math.radians(25.0)
+        M = np.array([[math.cos(t), 0, math.sin(t), 0.1], [0, 1, 0, -0.05], [-math.sin(t), 0, math.cos(t), 0.2], [0, 0, 0, 1]], np.float32)
+        b.create_instance(obj, M)
+    b.add_point_light((0.3, 1.5, 0.4), (1.0, 0.9, 0.8), 4.0)
+    fs = b.build()
+    assert len(fs.arrays["bvh_lists"][0]) == 1              # the top layer IS one leaf
+    cam = dict(pos=(0.0, 1.2, 2.2), at=(0.0, 0.0, 0.0), vfov=45.0)
+    w, h = 96, 64
+    c = make_camera(orc, cam, w, h)
+    seeds = orc.init_sampler(w, h, 0)
+    rays = orc.generate_paths(c, seeds, w, h, 0, 0)
+    rng = np.random.default_rng(3)
+    extra = rays.copy()                                      # incoherent rays from above, many of them missing the mesh
+    d = rng.normal(size=(len(extra), 3)).astype(np.float32); d[:, 1] = -np.abs(d[:, 1]); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    extra["dir"][:, :3] = d
+    extra["org"][:, :3] = (rng.uniform(-1.2, 1.2, size=(len(extra), 3)) * np.array([1, 0, 1]) + np.array([0, 1.0, 0])).astype(np.float32)
+    want, wst = orc.trace_closest(fs, rays)
+    want2, wst2 = orc.trace_closest(fs, extra)
+    assert (want["objid"] >= 0).sum() > 1000
+    films = {}
+    old = {k: os.environ.get(k) for k in ("ATEN_AMD_TRACE", "ATEN_AMD_LDS_NODES")}
+    try:
+        for flavour, lds in (("r", "0"), ("s", "0"), ("s", "1")):
+            os.environ["ATEN_AMD_TRACE"] = flavour; os.environ["ATEN_AMD_LDS_NODES"] = lds
+            r = PathTracing(0)
+            try:
+                r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+                got, st = r.trace_closest(rays, stats=True)
+                assert got.tobytes() == want.tobytes(), (flavour, lds)
+                assert np.array_equal(st, wst), (flavour, lds, st, wst)
+                got2, st2 = r.trace_closest(extra, stats=True)
+                assert got2.tobytes() == want2.tobytes() and np.array_equal(st2, wst2), (flavour, lds)
+                films[(flavour, lds)] = r.render(w, h, 4, 3, frame=1).copy()
+            finally:
+                r.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    ref = films[("s", "0")]
+    assert np.nanmax(ref[..., :3]) > 0
+    for k, f in films.items():
+        assert f.tobytes() == ref.tobytes(), k
+    frac, mean_err = frame_tolerance_report(ref, orc.render(fs, c, seeds, w, h, 4, 3, frame=1))
+    assert frac >= 0.995 and mean_err <= 5e-3, (frac, mean_err)

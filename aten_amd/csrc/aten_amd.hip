@@ -1088,7 +1088,10 @@ public:
     // r04, after the plain walk dropped from 84 to 63 VGPRs (8 waves per SIMD; no SLP pairing): it wins again on the 4- and 8-way shards of a
     // 1080p frame (sponza_lod 1.157 -> 1.097 / 0.640 -> 0.608 ms, atrium 1.753 -> 1.700 / 1.112 -> 1.032 with 3 frames in flight) and loses on
     // the 2-way shard of sponza_lod (2.13 vs 2.21) and on full frames (4.04 vs 4.47): profiles/r04_shard_matrix.txt
-    static constexpr uint32_t kRefillMinPaths = 800u * 1000u;
+    // Re-measured after the refill walk's r04 changes (direct start, rays finished with the refill, TLAS step every third iteration): the two
+    // walks tie on the 4-way shard (sponza_lod 1.075 / 1.076 ms, atrium 1.667 refill / 1.704 plain), the plain walk keeps the 8-way shard
+    // (0.606 vs 0.627, atrium 1.036 vs 1.075): 800 K -> 400 K paths
+    static constexpr uint32_t kRefillMinPaths = 400u * 1000u;
 
     // bytes of the LDS copy a small scene is walked from (node image + matrix rows), 0 = the scene is walked from global memory
     uint32_t lds_scene_bytes() const
@@ -1140,8 +1143,9 @@ public:
         // large enough not to be latency-bound itself: the Disney / analytic sets on every shard size measured, the core set on full frames
         // only (profiles/r04_variants_shade_waves.txt, r04_shard_matrix.txt)
         const bool big = (uint32_t)(fp.slot_end - fp.slot_begin) >= 1500u * 1000u;
+        // (the SVGF flavour -- AOV writes, 25 registers spilled at 96 -- stays at 4: C5 4.66 vs 4.68 ms per frame)
         const int shade_waves = env_shade_waves ? env_shade_waves
-                              : (frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
+                              : (!SVGF && frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
         // (small sets: 5 waves per SIMD when frames overlap -- they share the SIMDs with another frame's trace waves --, 4 otherwise:
         // kernels.hpp, k_shade_wn)

@@ -102,9 +102,9 @@ def hip_compile(out_lib, extra_flags=(), objdir=None, hipcc=None):
         print("+", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    failed = [(cmd, pr.returncode) for cmd, pr in procs if pr.wait() != 0]      # (every unit is waited for before anything is raised)
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + objs)
     return out_lib
 

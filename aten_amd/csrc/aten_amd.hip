@@ -793,7 +793,7 @@ public:
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
         scene.root_link = root;
-        fill_root_direct(scene, rec.data(), top_base);
+        fill_root_direct(scene, rec.data(), top_base, n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr), n_mtxs ? n_mtxs : n_host_matrices);
         scene.node_bytes = (uint32_t)(top_base + top_bytes);
         scene.ident_row = c.ident_row;
         if (n_mtxs) scene.mtx_quads = (uint32_t)mv.size();

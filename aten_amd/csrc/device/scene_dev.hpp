@@ -126,6 +126,7 @@ struct DevScene {
     // The top layer is ONE leaf (a scene = one instance: sponza, the atrium): its record, so that a walk can start INSIDE the nested
     // tree (walk_start) instead of standing on the leaf through its first burst.  root_direct = 0: walks start at root_link.
     int32_t root_direct, root_objid, root_meshid, root_w2l, root_blas, root_flags;
+    float root_m[12];                   // rows 0..2 of that instance's W2L (root_w2l >= 0): kernel arguments, i.e. scalar registers -- no loads at a refill
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)
     const float* ibl_cdf_u;             // [ibl_h][ibl_w]

@@ -202,9 +202,11 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
         if (COUNT) { cnt->nodes++; cnt->ray_nodes++; }
         w.wray.org = mk3(a); w.wray.dir = mk3(b); w.wray.invdir = mk3(0.0F); w.wray.oxinvdir = mk3(0.0F); w.wray.finite = true;
         if (sc.root_w2l >= 0) {
-            m4 m;
-            m.r0 = ldm<IDENT>(sc, sc.root_w2l + 0); m.r1 = ldm<IDENT>(sc, sc.root_w2l + 1);
-            m.r2 = ldm<IDENT>(sc, sc.root_w2l + 2); m.r3 = ldm<IDENT>(sc, sc.root_w2l + 3);
+            m4 m;       // the instance's W2L rows travel in the kernel arguments (scalar registers): no loads here
+            m.r0 = make_float4(sc.root_m[0], sc.root_m[1], sc.root_m[2], sc.root_m[3]);
+            m.r1 = make_float4(sc.root_m[4], sc.root_m[5], sc.root_m[6], sc.root_m[7]);
+            m.r2 = make_float4(sc.root_m[8], sc.root_m[9], sc.root_m[10], sc.root_m[11]);
+            m.r3 = make_float4(0.0F, 0.0F, 0.0F, 1.0F);        // (not read: m4_apply / m4_applyXYZ use rows 0..2)
             const f3 o = m4_apply(m, w.wray.org);
             const f3 d = normalize(m4_applyXYZ(m, w.wray.dir));
             slab_setup(w.ray, o, d);

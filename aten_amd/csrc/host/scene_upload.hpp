@@ -131,8 +131,9 @@ inline bool is_exact_identity(const atn_mat4& m)
 
 // DevScene::root_*: filled when the top layer's root is a TLAS leaf whose two top links end the walk (a one-node top layer).
 // `image` = host copy of the node image from byte `bias` on.
-inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias)
+inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias, const atn_mat4* matrices = nullptr, uint32_t n_matrices = 0)
 {
+    for (float& v : p.root_m) v = 0.0F;
     p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0;
     if (p.root_link == kLinkEnd || p.root_link >= 0 || (p.root_link & kLinkTypeMask) != kLinkTlasBit) return;
     const uint32_t off = (uint32_t)p.root_link & kLinkOffsetMask;
@@ -143,6 +144,11 @@ inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias)
     p.root_direct = 1;
     p.root_objid = f2i(q[0].x); p.root_w2l = f2i(q[0].y); p.root_blas = f2i(q[0].z); p.root_flags = f2i(q[0].w);
     p.root_meshid = f2i(q[1].x);
+    if (p.root_w2l >= 0) {
+        const uint32_t mi = (uint32_t)p.root_w2l / 4u;
+        if (!matrices || mi >= n_matrices) { p.root_direct = 0; return; }      // (no host copy of the matrices: walks start at root_link)
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) p.root_m[4 * r + c] = matrices[mi].m[r][c];
+    }
 }
 
 // Writes the device records of one analysed list (offsets already assigned) into the byte image `img`.
@@ -386,7 +392,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
 
     DevScene& p = img.params;
     p.root_link = img.list_root_link[0];
-    fill_root_direct(p, img.nodes.data(), 0);
+    fill_root_direct(p, img.nodes.data(), 0, s->matrices, s->n_matrices);
     p.n_lights = (int32_t)s->n_lights; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
     p.bvh_hit_min = s->config.bvh_hit_min;
     p.bg_color[0] = s->config.bg.bg_color[0]; p.bg_color[1] = s->config.bg.bg_color[1]; p.bg_color[2] = s->config.bg.bg_color[2];

@@ -499,6 +499,19 @@ def run_workload(args, cfg, ctx):
                              "of this command shows) is the wall duration of a launch that shares the GPU, roofline_launch_ms the same launch "
                              "with one kernel in flight at a time, which the fractions use" % (in_flight, kernel_count_batches))
     kernel_ms_per_frame_isolated = {k: round(v[0] / max(n_excl, 1), 4) for k, v in ktimes_excl.items() if v[1]}
+    # USEFUL work against what the chip can do at best for this access pattern: node visits (the oracle-checked counter) per CU per
+    # microsecond over all trace launches of the frame (one kernel in flight), against the lane-hops per CU per microsecond a pure
+    # pointer chase of two dependent 16-byte gathers per hop reaches through an L1-resident / L2-resident table (tools/valu_calib.hip:
+    # k_cal_l1_chase, 5 waves per SIMD).  Unlike the unit fractions above this one goes UP when wasted instructions are removed.
+    trace_iso_ms = sum(v for k, v in kernel_ms_per_frame_isolated.items() if k.startswith("trace_"))
+    if trace_iso_ms > 0 and ceil.get("chase_l1_w5_lane_hops_per_cu_per_us"):
+        visits = per_frame["closest_nodes"] + per_frame["shadow_nodes"]      # this rank's walks
+        rate = visits / 256.0 / (trace_iso_ms * 1e3)
+        roofline["useful"] = {"node_visits_per_cu_per_us": round(rate, 1),
+                              "l1_resident_chase_ceiling": ceil["chase_l1_w5_lane_hops_per_cu_per_us"],
+                              "l2_resident_chase_ceiling": ceil.get("chase_l2_w5_lane_hops_per_cu_per_us"),
+                              "frac_of_l1_chase": round(rate / ceil["chase_l1_w5_lane_hops_per_cu_per_us"], 4),
+                              "trace_ms_per_frame_isolated": round(trace_iso_ms, 4)}
     kernel_ms_per_frame = {k: round(v[0] / max(frames_prof, 1), 4) for k, v in ktimes.items() if v[1] or not k.startswith("svgf")}
     svgf_info = None
     if svgf:

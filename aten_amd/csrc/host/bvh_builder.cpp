@@ -1,5 +1,25 @@
 // Host-side BVH construction emitting aten's 48-byte threaded node format.
 //
+// What it replaces: aten::sbvh::onBuild + sbvh::convert (src/libaten/accelerator/sbvh.cpp:190-421, 827-950) for the
+// bottom level -- a split BVH (Stich et al. 2009): per node the best OBJECT split (surface-area heuristic over the
+// references' centroids, findObjectSplit sbvh.cpp:430-547) is compared with the best SPATIAL split (references chopped
+// at bin planes, findSpatialSplit sbvh.cpp:548-680; straddling references duplicated or "unsplit" to one side,
+// spatialSort sbvh.cpp:682-779), and the spatial one is only looked at when the object split's children overlap by more
+// than `spatial_alpha` of the root's area (sbvh.cpp:275-288) -- and aten::ThreadedBVH::build (threaded_bvh.cpp:178-357)
+// for the top level (object splits only).
+//
+// Where it differs from the reference's builder, on purpose (the tree is an INPUT of the walk, on the CPU as on the GPU:
+// closest hits do not depend on it, the number of node visits does -- tools/tree_quality.py measures that):
+//   * a straddling reference is clipped as a TRIANGLE at the plane (the reference chops the reference's box only,
+//     sbvh.cpp:603-618, 752-770): tighter child boxes;
+//   * object splits are an exact sweep over the sorted centroids for nodes below `sweep_below` references and binned
+//     above (the reference: 16 bins everywhere, sbvh.h:393);
+//   * nodes are laid out in depth-first pre-order (the reference: creation order, links through getOrderIndex), so the
+//     hit link of an inner node is index + 1 and every link points forward: a walk is a monotone sweep through memory;
+//   * the child that the fixed-order walk enters first is CHOSEN (`child_order`), not "the lower side of the plane";
+//   * after the build the tree is re-threaded bottom-up with the boxes of what the subtrees really hold, never larger
+//     than what the split assigned (the reference keeps the split's boxes, sbvh.cpp:392-393).
+//
 // Output contract (what the traversal kernels and the reference's
 // ThreadedBvhTraverser::Traverse, src/libaten/accelerator/threaded_bvh_traverser.h:98-304, rely on):
 //   * inner node : f0 = f1 = -1, hit = first child, miss = next subtree (or -1)
@@ -8,8 +28,6 @@
 //                  (src/libaten/accelerator/sbvh.cpp:880-899)
 //   * TLAS leaf  : f0 = instance object id, f1 = -1, f2 = exid bit-field punned to float,
 //                  f3 = mesh id, hit == miss == next (src/libaten/accelerator/threaded_bvh.cpp:212-246,266-279)
-// Layout is depth-first pre-order, so hit of an inner node is always index + 1 and every link
-// points forward: a walk is a monotone sweep through memory.
 #include "../../../include/aten_amd_scene.h"
 
 #include <algorithm>
@@ -17,15 +35,18 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <vector>
 
 namespace {
+
+constexpr float kInf = std::numeric_limits<float>::max();
 
 struct Box {
     float mn[3], mx[3];
     void reset()
     {
-        for (int k = 0; k < 3; k++) { mn[k] = std::numeric_limits<float>::max(); mx[k] = -std::numeric_limits<float>::max(); }
+        for (int k = 0; k < 3; k++) { mn[k] = kInf; mx[k] = -kInf; }
     }
     void grow(const Box& b)
     {
@@ -35,122 +56,371 @@ struct Box {
     {
         for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); }
     }
+    void clip(const Box& b)
+    {
+        for (int k = 0; k < 3; k++) { mn[k] = std::max(mn[k], b.mn[k]); mx[k] = std::min(mx[k], b.mx[k]); }
+    }
+    bool valid() const { return mn[0] <= mx[0] && mn[1] <= mx[1] && mn[2] <= mx[2]; }
     float half_area() const
     {
         float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
         if (dx < 0 || dy < 0 || dz < 0) return 0.f;
         return dx * dy + dy * dz + dz * dx;
     }
+    float centre(int k) const { return 0.5f * (mn[k] + mx[k]); }
 };
 
-struct Prim {
+inline Box empty_box() { Box b; b.reset(); return b; }
+
+inline float overlap_half_area(const Box& a, const Box& b)
+{
+    Box d;
+    for (int k = 0; k < 3; k++) { d.mn[k] = std::max(a.mn[k], b.mn[k]); d.mx[k] = std::min(a.mx[k], b.mx[k]); }
+    return d.valid() ? d.half_area() : 0.f;
+}
+
+// A reference: (part of) one primitive.  `box` is the bound of the part that lies in the node that owns the reference.
+struct Ref {
     Box box;
-    float c[3];
-    int32_t id;     // payload: triangle id (BLAS) or instance slot (TLAS)
+    uint32_t prim;
 };
+
+struct Tri { float v[3][3]; };
 
 struct BuildNode {
     Box box;
-    int32_t prim;       // >= 0 : leaf payload
+    int32_t prim;       // >= 0 : leaf payload (index into the caller's primitive table)
     uint32_t end;       // index one past this node's subtree (pre-order)
 };
 
-constexpr int kBins = 32;
+struct Options {
+    bool spatial = true;
+    float alpha = 1e-5f;            // sbvh.cpp:232 areaAlpha
+    int object_bins = 32;
+    int spatial_bins = 64;
+    uint32_t sweep_below = 4096;    // exact sweep for nodes with fewer references than this
+    int child_order = ATNS_ORDER_NEAR_POINT;
+    float max_refs_factor = 4.0f;   // duplication budget: references <= factor * primitives
+    float order_point[3] = { 0, 0, 0 };
+    bool order_point_given = false; // else: the area-weighted centroid of the triangles
+};
 
 class Builder {
 public:
     std::vector<BuildNode> nodes;
+    uint64_t n_spatial = 0, n_refs_out = 0;
 
-    void run(std::vector<Prim>& prims)
+    Builder(const Options& o, const Tri* tris) : opt(o), tris_(tris) {}
+
+    void run(std::vector<Ref>& refs)
     {
         nodes.clear();
-        nodes.reserve(prims.size() * 2);
-        if (!prims.empty()) build(prims, 0, (uint32_t)prims.size());
+        nodes.reserve(refs.size() * 2);
+        if (refs.empty()) return;
+        Box bb = empty_box();
+        for (const Ref& r : refs) bb.grow(r.box);
+        root_area_ = std::max(bb.half_area(), 1e-30f);
+        ref_budget_ = (uint64_t)((double)opt.max_refs_factor * (double)refs.size());
+        n_refs_live_ = refs.size();
+        build(std::move(refs), bb);
+        tighten();
     }
 
 private:
-    void build(std::vector<Prim>& p, uint32_t lo, uint32_t hi)
+    Options opt;
+    const Tri* tris_;
+    float root_area_ = 1.f;
+    uint64_t ref_budget_ = 0, n_refs_live_ = 0;
+
+    struct ObjectSplit { float cost = kInf; int axis = -1; uint32_t at = 0; int bin = -1; Box lb, rb; };
+    struct SpatialSplit { float cost = kInf; int axis = -1; float plane = 0; Box lb, rb; uint32_t ln = 0, rn = 0; };
+
+    // ---- object split ---------------------------------------------------------------------------------------------
+    // exact: for every axis, every position in the centroid order
+    void object_split_sweep(std::vector<Ref>& refs, ObjectSplit& best, std::vector<float>& right_area)
     {
-        const uint32_t self = (uint32_t)nodes.size();
-        nodes.push_back(BuildNode{});
-        Box bb; bb.reset();
-        Box cb; cb.reset();
-        for (uint32_t i = lo; i < hi; i++) { bb.grow(p[i].box); cb.grow(p[i].c); }
-        nodes[self].box = bb;
-        nodes[self].prim = -1;
-
-        if (hi - lo == 1) {
-            nodes[self].prim = p[lo].id;
-            nodes[self].end = self + 1;
-            return;
+        const uint32_t n = (uint32_t)refs.size();
+        right_area.resize(n);
+        std::vector<uint32_t>& ord = order_;
+        for (int axis = 0; axis < 3; axis++) {
+            ord.resize(n);
+            for (uint32_t i = 0; i < n; i++) ord[i] = i;
+            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+                const float ca = refs[a].box.centre(axis), cb = refs[b].box.centre(axis);
+                return ca < cb || (ca == cb && a < b);
+            });
+            Box acc = empty_box();
+            for (uint32_t i = n - 1; i > 0; i--) { acc.grow(refs[ord[i]].box); right_area[i] = acc.half_area(); }
+            acc.reset();
+            for (uint32_t i = 1; i < n; i++) {
+                acc.grow(refs[ord[i - 1]].box);
+                const float cost = acc.half_area() * (float)i + right_area[i] * (float)(n - i);
+                if (cost < best.cost) { best.cost = cost; best.axis = axis; best.at = i; best.bin = -1; }
+            }
         }
-
-        uint32_t mid = split(p, lo, hi, cb);
-        build(p, lo, mid);
-        build(p, mid, hi);
-        nodes[self].end = (uint32_t)nodes.size();
+        if (best.axis < 0) return;
+        const int axis = best.axis;
+        std::stable_sort(refs.begin(), refs.end(), [axis](const Ref& a, const Ref& b) { return a.box.centre(axis) < b.box.centre(axis); });
+        best.lb.reset(); best.rb.reset();
+        for (uint32_t i = 0; i < n; i++) (i < best.at ? best.lb : best.rb).grow(refs[i].box);
     }
 
-    // Binned surface-area-heuristic object split; falls back to a median split on the widest
-    // centroid axis when binning cannot separate the primitives.
-    uint32_t split(std::vector<Prim>& p, uint32_t lo, uint32_t hi, const Box& cb)
+    // binned (findObjectSplit's scheme, sbvh.cpp:430-547, with `object_bins` bins)
+    void object_split_binned(std::vector<Ref>& refs, ObjectSplit& best)
     {
-        const uint32_t n = hi - lo;
-        int best_axis = -1, best_bin = -1;
-        float best_cost = std::numeric_limits<float>::max();
+        const uint32_t n = (uint32_t)refs.size();
+        const int nb = opt.object_bins;
+        Box cb = empty_box();
+        for (const Ref& r : refs) { const float c[3] = { r.box.centre(0), r.box.centre(1), r.box.centre(2) }; cb.grow(c); }
+        std::vector<Box> bbox(nb), racc(nb);
+        std::vector<uint32_t> cnt(nb), rcnt(nb);
+        for (int axis = 0; axis < 3; axis++) {
+            const float ext = cb.mx[axis] - cb.mn[axis];
+            if (!(ext > 0.f)) continue;
+            const float scale = (float)nb / ext;
+            for (int b = 0; b < nb; b++) { bbox[b].reset(); cnt[b] = 0; }
+            for (const Ref& r : refs) {
+                int b = (int)((r.box.centre(axis) - cb.mn[axis]) * scale);
+                b = std::min(std::max(b, 0), nb - 1);
+                bbox[b].grow(r.box); cnt[b]++;
+            }
+            Box acc = empty_box(); uint32_t c = 0;
+            for (int b = nb - 1; b > 0; b--) { acc.grow(bbox[b]); c += cnt[b]; racc[b] = acc; rcnt[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < nb - 1; b++) {
+                acc.grow(bbox[b]); c += cnt[b];
+                if (c == 0 || rcnt[b + 1] == 0) continue;
+                const float cost = acc.half_area() * (float)c + racc[b + 1].half_area() * (float)rcnt[b + 1];
+                if (cost < best.cost) { best.cost = cost; best.axis = axis; best.bin = b; best.at = c; best.lb = acc; best.rb = racc[b + 1]; }
+            }
+        }
+        if (best.axis < 0) return;
+        const int axis = best.axis;
+        const float scale = (float)nb / (cb.mx[axis] - cb.mn[axis]), mn = cb.mn[axis];
+        const int bin = best.bin;
+        std::stable_partition(refs.begin(), refs.end(), [&](const Ref& r) {
+            int b = (int)((r.box.centre(axis) - mn) * scale);
+            b = std::min(std::max(b, 0), nb - 1);
+            return b <= bin;
+        });
+        (void)n;
+    }
 
-        if (n > 2) {
-            for (int axis = 0; axis < 3; axis++) {
-                const float ext = cb.mx[axis] - cb.mn[axis];
-                if (!(ext > 0.f)) continue;
-                const float scale = kBins / ext;
-                Box bbox[kBins]; uint32_t cnt[kBins];
-                for (int b = 0; b < kBins; b++) { bbox[b].reset(); cnt[b] = 0; }
-                for (uint32_t i = lo; i < hi; i++) {
-                    int b = (int)((p[i].c[axis] - cb.mn[axis]) * scale);
-                    b = std::min(std::max(b, 0), kBins - 1);
-                    bbox[b].grow(p[i].box); cnt[b]++;
+    // the fallback of sbvh.cpp:318-355: halves of the centroid order along the widest axis
+    void median_split(std::vector<Ref>& refs, const Box& bb, ObjectSplit& best)
+    {
+        int axis = 0;
+        const float e0 = bb.mx[0] - bb.mn[0], e1 = bb.mx[1] - bb.mn[1], e2 = bb.mx[2] - bb.mn[2];
+        if (e1 > e0 && e1 >= e2) axis = 1; else if (e2 > e0 && e2 > e1) axis = 2;
+        std::stable_sort(refs.begin(), refs.end(), [axis](const Ref& a, const Ref& b) { return a.box.centre(axis) < b.box.centre(axis); });
+        best.axis = axis; best.at = (uint32_t)refs.size() / 2; best.bin = -1;
+        best.lb.reset(); best.rb.reset();
+        for (uint32_t i = 0; i < refs.size(); i++) (i < best.at ? best.lb : best.rb).grow(refs[i].box);
+        best.cost = best.lb.half_area() * (float)best.at + best.rb.half_area() * (float)(refs.size() - best.at);
+    }
+
+    // ---- spatial split ----------------------------------------------------------------------------------------------
+    // The two parts of a reference either side of the plane x[axis] = pos: the triangle's vertices go to their side, the
+    // points where its edges cross the plane to both; each part is then cut back to the reference's own box.
+    void split_ref(const Ref& r, int axis, float pos, Box& lo, Box& hi) const
+    {
+        lo.reset(); hi.reset();
+        const Tri& t = tris_[r.prim];
+        for (int e = 0; e < 3; e++) {
+            const float* a = t.v[e];
+            const float* b = t.v[(e + 1) % 3];
+            const float pa = a[axis], pb = b[axis];
+            if (pa <= pos) lo.grow(a);
+            if (pa >= pos) hi.grow(a);
+            if ((pa < pos && pb > pos) || (pa > pos && pb < pos)) {
+                const float s = std::min(std::max((pos - pa) / (pb - pa), 0.f), 1.f);
+                // the crossing point, widened by a few ulps off the split axis: the rounded point may lie a hair inside
+                // the true edge, and a part's box must never lose a sliver of the triangle
+                float p[3], q[3];
+                for (int k = 0; k < 3; k++) {
+                    const float x = a[k] + s * (b[k] - a[k]);
+                    const float pad = (k == axis) ? 0.f : 4.8e-7f * std::max(std::fabs(a[k]), std::fabs(b[k]));
+                    p[k] = x - pad; q[k] = x + pad;
                 }
-                float right_area[kBins]; uint32_t right_cnt[kBins];
-                Box acc; acc.reset(); uint32_t c = 0;
-                for (int b = kBins - 1; b > 0; b--) {
-                    acc.grow(bbox[b]); c += cnt[b];
-                    right_area[b] = acc.half_area(); right_cnt[b] = c;
+                p[axis] = q[axis] = pos;
+                lo.grow(p); lo.grow(q); hi.grow(p); hi.grow(q);
+            }
+        }
+        lo.mx[axis] = std::min(lo.mx[axis], pos);
+        hi.mn[axis] = std::max(hi.mn[axis], pos);
+        lo.clip(r.box); hi.clip(r.box);
+    }
+
+    void spatial_split_find(const std::vector<Ref>& refs, const Box& bb, SpatialSplit& best)
+    {
+        const int nb = opt.spatial_bins;
+        std::vector<Box> bbox(nb), racc(nb);
+        std::vector<uint32_t> enter(nb), leave(nb);
+        for (int axis = 0; axis < 3; axis++) {
+            const float ext = bb.mx[axis] - bb.mn[axis];
+            if (!(ext > 0.f)) continue;
+            const float scale = (float)nb / ext, width = ext / (float)nb, org = bb.mn[axis];
+            for (int b = 0; b < nb; b++) { bbox[b].reset(); enter[b] = leave[b] = 0; }
+            for (const Ref& r : refs) {
+                int b0 = std::min(std::max((int)((r.box.mn[axis] - org) * scale), 0), nb - 1);
+                int b1 = std::min(std::max((int)((r.box.mx[axis] - org) * scale), b0), nb - 1);
+                enter[b0]++; leave[b1]++;
+                if (b0 == b1) { bbox[b0].grow(r.box); continue; }
+                Ref cur = r;
+                for (int b = b0; b < b1; b++) {
+                    Box lo, hi;
+                    split_ref(cur, axis, org + width * (float)(b + 1), lo, hi);
+                    if (lo.valid()) bbox[b].grow(lo);
+                    cur.box = hi;
+                    if (!hi.valid()) break;
                 }
-                acc.reset(); c = 0;
-                for (int b = 0; b < kBins - 1; b++) {
-                    acc.grow(bbox[b]); c += cnt[b];
-                    if (c == 0 || right_cnt[b + 1] == 0) continue;
-                    float cost = acc.half_area() * c + right_area[b + 1] * right_cnt[b + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                if (cur.box.valid()) bbox[b1].grow(cur.box);
+            }
+            Box acc = empty_box();
+            for (int b = nb - 1; b > 0; b--) { acc.grow(bbox[b]); racc[b] = acc; }
+            acc.reset();
+            uint32_t ln = 0, rn = (uint32_t)refs.size();
+            for (int b = 0; b < nb - 1; b++) {
+                acc.grow(bbox[b]); ln += enter[b]; rn -= leave[b];
+                if (ln == 0 || rn == 0) continue;
+                const float cost = acc.half_area() * (float)ln + racc[b + 1].half_area() * (float)rn;
+                if (cost < best.cost) {
+                    best.cost = cost; best.axis = axis; best.plane = org + width * (float)(b + 1);
+                    best.lb = acc; best.rb = racc[b + 1]; best.ln = ln; best.rn = rn;
                 }
             }
         }
+    }
 
-        if (best_axis >= 0) {
-            const float ext = cb.mx[best_axis] - cb.mn[best_axis];
-            const float scale = kBins / ext;
-            const float mn = cb.mn[best_axis];
-            auto it = std::stable_partition(p.begin() + lo, p.begin() + hi, [&](const Prim& q) {
-                int b = (int)((q.c[best_axis] - mn) * scale);
-                b = std::min(std::max(b, 0), kBins - 1);
-                return b <= best_bin;
-            });
-            uint32_t mid = (uint32_t)(it - p.begin());
-            if (mid > lo && mid < hi) return mid;
+    // spatialSort, sbvh.cpp:682-779: references on one side go there; a straddling one goes to ONE side if that is
+    // cheaper than duplicating it (the paper's "reference unsplitting"), else both sides get their clipped part.
+    bool spatial_split_apply(const std::vector<Ref>& refs, SpatialSplit sp, std::vector<Ref>& left, std::vector<Ref>& right, Box& lb, Box& rb)
+    {
+        const int axis = sp.axis;
+        left.clear(); right.clear();
+        lb = sp.lb; rb = sp.rb;
+        float la = lb.half_area(), ra = rb.half_area();
+        float ln = (float)sp.ln, rn = (float)sp.rn;
+        for (const Ref& r : refs) {
+            if (r.box.mx[axis] <= sp.plane) { left.push_back(r); continue; }
+            if (r.box.mn[axis] >= sp.plane) { right.push_back(r); continue; }
+            Box lu = lb; lu.grow(r.box);
+            Box ru = rb; ru.grow(r.box);
+            const float c_split = la * ln + ra * rn;
+            const float c_left = lu.half_area() * ln + ra * (rn - 1.f);
+            const float c_right = la * (ln - 1.f) + ru.half_area() * rn;
+            if (c_left < c_split && c_left <= c_right) {
+                left.push_back(r); lb = lu; la = lu.half_area(); rn -= 1.f;
+            }
+            else if (c_right < c_split) {
+                right.push_back(r); rb = ru; ra = ru.half_area(); ln -= 1.f;
+            }
+            else {
+                Box lo, hi;
+                split_ref(r, axis, sp.plane, lo, hi);
+                if (lo.valid()) left.push_back(Ref{ lo, r.prim });
+                if (hi.valid()) right.push_back(Ref{ hi, r.prim });
+                if (!lo.valid() && !hi.valid()) left.push_back(r);
+            }
+        }
+        // both sides must make progress, or the recursion need not end
+        return !left.empty() && !right.empty() && left.size() < refs.size() && right.size() < refs.size();
+    }
+
+    // ---- which child the fixed-order walk enters first ---------------------------------------------------------------
+    bool right_first(const Box& lb, uint32_t ln, const Box& rb, uint32_t rn) const
+    {
+        switch (opt.child_order) {
+        case ATNS_ORDER_AREA: return rb.half_area() > lb.half_area();
+        case ATNS_ORDER_AREA_SMALL: return rb.half_area() < lb.half_area();
+        case ATNS_ORDER_COUNT: return rn > ln;
+        case ATNS_ORDER_COUNT_SMALL: return rn < ln;
+        case ATNS_ORDER_NEAR_POINT: {
+            float dl = 0, dr = 0;
+            for (int k = 0; k < 3; k++) {
+                const float p = opt.order_point[k];
+                const float a = std::max(std::max(lb.mn[k] - p, p - lb.mx[k]), 0.f);
+                const float b = std::max(std::max(rb.mn[k] - p, p - rb.mx[k]), 0.f);
+                dl += a * a; dr += b * b;
+            }
+            if (dl != dr) return dr < dl;
+            float cl = 0, cr = 0;
+            for (int k = 0; k < 3; k++) {
+                const float a = lb.centre(k) - opt.order_point[k], b = rb.centre(k) - opt.order_point[k];
+                cl += a * a; cr += b * b;
+            }
+            return cr < cl;
+        }
+        default: return false;
+        }
+    }
+
+    void build(std::vector<Ref> refs, const Box& bb)
+    {
+        const uint32_t self = (uint32_t)nodes.size();
+        nodes.push_back(BuildNode{});
+        nodes[self].box = bb;
+        nodes[self].prim = -1;
+        const uint32_t n = (uint32_t)refs.size();
+        if (n == 1) {
+            nodes[self].prim = (int32_t)refs[0].prim;
+            nodes[self].box = refs[0].box;
+            nodes[self].end = self + 1;
+            n_refs_out++;
+            return;
         }
 
-        // median split
-        int axis = 0;
-        float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
-        if (e1 > e0 && e1 >= e2) axis = 1; else if (e2 > e0 && e2 > e1) axis = 2;
-        uint32_t mid = lo + n / 2;
-        std::stable_sort(p.begin() + lo, p.begin() + hi, [axis](const Prim& a, const Prim& b) {
-            return a.c[axis] < b.c[axis];
-        });
-        return mid;
+        ObjectSplit ob;
+        if (n > 2) {
+            if (n < opt.sweep_below) object_split_sweep(refs, ob, scratch_area_);
+            else object_split_binned(refs, ob);
+        }
+        if (ob.axis < 0) median_split(refs, bb, ob);
+
+        std::vector<Ref> left, right;
+        Box lb, rb;
+        bool done = false;
+        if (opt.spatial && tris_ && n_refs_live_ < ref_budget_ && overlap_half_area(ob.lb, ob.rb) / root_area_ >= opt.alpha) {
+            SpatialSplit sp;
+            spatial_split_find(refs, bb, sp);
+            if (sp.axis >= 0 && sp.cost < ob.cost) {
+                if (spatial_split_apply(refs, sp, left, right, lb, rb)) {
+                    done = true;
+                    n_spatial++;
+                    n_refs_live_ += left.size() + right.size() - n;
+                }
+            }
+        }
+        if (!done) {
+            left.assign(refs.begin(), refs.begin() + ob.at);
+            right.assign(refs.begin() + ob.at, refs.end());
+            lb = ob.lb; rb = ob.rb;
+        }
+        std::vector<Ref>().swap(refs);
+
+        if (right_first(lb, (uint32_t)left.size(), rb, (uint32_t)right.size())) { left.swap(right); std::swap(lb, rb); }
+        build(std::move(left), lb);
+        build(std::move(right), rb);
+        nodes[self].end = (uint32_t)nodes.size();
     }
+
+    // Boxes of inner nodes = union of their children's, bottom-up.  Never larger than what the split assigned (a child
+    // box is the union of its references, each inside the split's box), sometimes smaller after unsplitting / clipping.
+    void tighten()
+    {
+        for (uint32_t i = (uint32_t)nodes.size(); i-- > 0;) {
+            if (nodes[i].prim >= 0) continue;
+            const uint32_t a = i + 1, b = nodes[a].end;
+            Box u = nodes[a].box; u.grow(nodes[b].box);
+            nodes[i].box = u;
+        }
+    }
+
+    std::vector<uint32_t> order_;
+    std::vector<float> scratch_area_;
 };
+
+
 
 atn_bvh_node* emit(const std::vector<BuildNode>& bn)
 {
@@ -169,39 +439,64 @@ atn_bvh_node* emit(const std::vector<BuildNode>& bn)
     return out;
 }
 
-} // namespace
+Options options_from(const atns_bvh_options* o)
+{
+    Options r;
+    if (!o) return r;
+    r.spatial = o->spatial_splits != 0;
+    if (o->spatial_alpha >= 0.f) r.alpha = o->spatial_alpha;
+    if (o->object_bins >= 2) r.object_bins = std::min(o->object_bins, 1024);
+    if (o->spatial_bins >= 2) r.spatial_bins = std::min(o->spatial_bins, 1024);
+    if (o->sweep_below >= 0) r.sweep_below = (uint32_t)o->sweep_below;
+    if (o->child_order >= 0 && o->child_order <= ATNS_ORDER_NEAR_POINT) r.child_order = o->child_order;
+    r.order_point_given = o->order_point_given != 0;
+    if (o->max_refs_factor >= 1.f) r.max_refs_factor = o->max_refs_factor;
+    for (int k = 0; k < 3; k++) r.order_point[k] = o->order_point[k];
+    return r;
+}
 
-extern "C" {
-
-int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
-                    const uint32_t* tri_ids, uint32_t n_tris,
-                    atn_bvh_node** out_nodes, uint32_t* out_count,
-                    float out_bbox_min[3], float out_bbox_max[3])
+int build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris, const uint32_t* tri_ids, uint32_t n_tris,
+               const atns_bvh_options* user, atn_bvh_node** out_nodes, uint32_t* out_count, float* out_bbox_min, float* out_bbox_max,
+               atns_bvh_stats* stats)
 {
     if (!vtx_pos || !tris || !tri_ids || !out_nodes || !out_count || n_tris == 0) return -1;
-    std::vector<Prim> prims(n_tris);
+    std::vector<Ref> refs(n_tris);
+    std::vector<Tri> geo(n_tris);
     for (uint32_t i = 0; i < n_tris; i++) {
         if (tri_ids[i] >= (1u << 24)) return -2;   // ids are stored as float: exact below 2^24
         const atn_triangle_param& t = tris[tri_ids[i]];
-        Prim& p = prims[i];
-        p.box.reset();
+        Ref& r = refs[i];
+        r.box.reset();
         for (int k = 0; k < 3; k++) {
             const atn_vec4& v = vtx_pos[t.idx[k]];
-            const float q[3] = { v.x, v.y, v.z };
-            p.box.grow(q);
+            geo[i].v[k][0] = v.x; geo[i].v[k][1] = v.y; geo[i].v[k][2] = v.z;
+            r.box.grow(geo[i].v[k]);
         }
-        for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.box.mn[k] + p.box.mx[k]);
-        p.id = (int32_t)tri_ids[i];
+        r.prim = i;
     }
-    Builder b;
-    b.run(prims);
+    Options opt = options_from(user);
+    if (opt.child_order == ATNS_ORDER_NEAR_POINT && !opt.order_point_given) {
+        // where the rays of an interior come from, for want of a better guess: the middle of the surface
+        double acc = 0, c[3] = { 0, 0, 0 };
+        for (const Tri& t : geo) {
+            double e0[3], e1[3];
+            for (int k = 0; k < 3; k++) { e0[k] = (double)t.v[1][k] - t.v[0][k]; e1[k] = (double)t.v[2][k] - t.v[0][k]; }
+            const double cx = e0[1] * e1[2] - e0[2] * e1[1], cy = e0[2] * e1[0] - e0[0] * e1[2], cz = e0[0] * e1[1] - e0[1] * e1[0];
+            const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            for (int k = 0; k < 3; k++) c[k] += area * ((double)t.v[0][k] + t.v[1][k] + t.v[2][k]) / 3.0;
+            acc += area;
+        }
+        for (int k = 0; k < 3; k++) opt.order_point[k] = acc > 0 ? (float)(c[k] / acc) : 0.5f * (geo[0].v[0][k] + geo[0].v[1][k]);
+    }
+    Builder b(opt, geo.data());
+    b.run(refs);
     atn_bvh_node* nodes = emit(b.nodes);
     if (!nodes) return -3;
     for (size_t i = 0; i < b.nodes.size(); i++) {
         if (b.nodes[i].prim >= 0) {
-            nodes[i].f0 = 1.0f;                         // isleaf
-            nodes[i].f1 = (float)b.nodes[i].prim;       // triid
-            nodes[i].f2 = -1.0f;                        // AT_DISABLE_VOXEL
+            nodes[i].f0 = 1.0f;                                 // isleaf
+            nodes[i].f1 = (float)tri_ids[b.nodes[i].prim];      // triid
+            nodes[i].f2 = -1.0f;                                // AT_DISABLE_VOXEL
             nodes[i].f3 = -1.0f;
         }
     }
@@ -210,7 +505,57 @@ int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
     if (out_bbox_min && out_bbox_max) {
         for (int k = 0; k < 3; k++) { out_bbox_min[k] = b.nodes[0].box.mn[k]; out_bbox_max[k] = b.nodes[0].box.mx[k]; }
     }
+    if (stats) {
+        stats->n_nodes = (uint32_t)b.nodes.size();
+        stats->n_leaves = (uint32_t)b.n_refs_out;
+        stats->n_spatial_splits = (uint32_t)b.n_spatial;
+        double sah = 0;
+        const double ra = std::max((double)b.nodes[0].box.half_area(), 1e-30);
+        for (const BuildNode& nd : b.nodes) sah += (double)nd.box.half_area() / ra;
+        stats->sah_cost = (float)sah;
+    }
     return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t atns_abi_version(void) { return ATNS_ABI_VERSION; }
+
+void atns_bvh_default_options(atns_bvh_options* o)
+{
+    if (!o) return;
+    const Options d;
+    o->spatial_splits = d.spatial ? 1 : 0;
+    o->spatial_alpha = d.alpha;
+    o->object_bins = d.object_bins;
+    o->spatial_bins = d.spatial_bins;
+    o->sweep_below = (int32_t)d.sweep_below;
+    o->child_order = d.child_order;
+    o->max_refs_factor = d.max_refs_factor;
+    for (int k = 0; k < 3; k++) o->order_point[k] = d.order_point[k];
+    o->order_point_given = d.order_point_given ? 1 : 0;
+}
+
+int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
+                    const uint32_t* tri_ids, uint32_t n_tris,
+                    atn_bvh_node** out_nodes, uint32_t* out_count,
+                    float out_bbox_min[3], float out_bbox_max[3])
+{
+    try { return build_blas(vtx_pos, tris, tri_ids, n_tris, nullptr, out_nodes, out_count, out_bbox_min, out_bbox_max, nullptr); }
+    catch (const std::bad_alloc&) { return -3; }
+    catch (...) { return -5; }
+}
+
+int atns_build_blas_opt(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
+                        const uint32_t* tri_ids, uint32_t n_tris, const atns_bvh_options* options,
+                        atn_bvh_node** out_nodes, uint32_t* out_count,
+                        float out_bbox_min[3], float out_bbox_max[3], atns_bvh_stats* out_stats)
+{
+    try { return build_blas(vtx_pos, tris, tri_ids, n_tris, options, out_nodes, out_count, out_bbox_min, out_bbox_max, out_stats); }
+    catch (const std::bad_alloc&) { return -3; }
+    catch (...) { return -5; }
 }
 
 int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t* blas_list_ids,
@@ -218,38 +563,43 @@ int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t
                     atn_bvh_node** out_nodes, uint32_t* out_count)
 {
     if (!boxes || !object_ids || !blas_list_ids || !out_nodes || !out_count || n == 0) return -1;
-    std::vector<Prim> prims(n);
-    for (uint32_t i = 0; i < n; i++) {
-        Prim& p = prims[i];
-        for (int k = 0; k < 3; k++) { p.box.mn[k] = boxes[6 * i + k]; p.box.mx[k] = boxes[6 * i + 3 + k]; }
-        for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.box.mn[k] + p.box.mx[k]);
-        p.id = (int32_t)i;
-    }
-    Builder b;
-    b.run(prims);
-    atn_bvh_node* nodes = emit(b.nodes);
-    if (!nodes) return -3;
-    for (size_t i = 0; i < b.nodes.size(); i++) {
-        if (b.nodes[i].prim >= 0) {
-            const int32_t slot = b.nodes[i].prim;
-            nodes[i].f0 = (float)object_ids[slot];
-            nodes[i].f1 = -1.0f;
-            const int32_t exid = blas_list_ids[slot];
-            if (exid >= 0) {
-                // ThreadedBvhNode::ConstructExternalBvhIdxFlag(exid, -1), threaded_bvh.h:46-54
-                uint32_t bits = (uint32_t)exid & 0x7fffu;   // lodExid = 0, hasLod = 0, noExternal = 0
-                float f; std::memcpy(&f, &bits, 4);
-                nodes[i].f2 = f;
-            }
-            else {
-                nodes[i].f2 = -1.0f;
-            }
-            nodes[i].f3 = mesh_ids ? (float)mesh_ids[slot] : -1.0f;
+    try {
+        std::vector<Ref> refs(n);
+        for (uint32_t i = 0; i < n; i++) {
+            Ref& r = refs[i];
+            for (int k = 0; k < 3; k++) { r.box.mn[k] = boxes[6 * i + k]; r.box.mx[k] = boxes[6 * i + 3 + k]; }
+            r.prim = i;
         }
+        Options o;
+        o.spatial = false;
+        Builder b(o, nullptr);
+        b.run(refs);
+        atn_bvh_node* nodes = emit(b.nodes);
+        if (!nodes) return -3;
+        for (size_t i = 0; i < b.nodes.size(); i++) {
+            if (b.nodes[i].prim >= 0) {
+                const int32_t slot = b.nodes[i].prim;
+                nodes[i].f0 = (float)object_ids[slot];
+                nodes[i].f1 = -1.0f;
+                const int32_t exid = blas_list_ids[slot];
+                if (exid >= 0) {
+                    // ThreadedBvhNode::ConstructExternalBvhIdxFlag(exid, -1), threaded_bvh.h:46-54
+                    uint32_t bits = (uint32_t)exid & 0x7fffu;   // lodExid = 0, hasLod = 0, noExternal = 0
+                    float f; std::memcpy(&f, &bits, 4);
+                    nodes[i].f2 = f;
+                }
+                else {
+                    nodes[i].f2 = -1.0f;
+                }
+                nodes[i].f3 = mesh_ids ? (float)mesh_ids[slot] : -1.0f;
+            }
+        }
+        *out_nodes = nodes;
+        *out_count = (uint32_t)b.nodes.size();
+        return 0;
     }
-    *out_nodes = nodes;
-    *out_count = (uint32_t)b.nodes.size();
-    return 0;
+    catch (const std::bad_alloc&) { return -3; }
+    catch (...) { return -5; }
 }
 
 void atns_free(void* p) { std::free(p); }

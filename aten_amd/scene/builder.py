@@ -22,10 +22,14 @@ import struct
 import numpy as np
 
 from .. import layout as L
-from .._hostlib import hostlib
+from .._hostlib import hostlib, default_bvh_options, BvhStats
 from . import obj_loader
 
 F32 = np.float32
+
+# atns_bvh_options fields every SceneBuilder without its own `bvh_options` passes to atns_build_blas_opt ({} = the library's
+# defaults); tools/tree_quality.py sweeps through this.
+DEFAULT_BVH_OPTIONS = {}
 
 
 def _length3(x, y, z):
@@ -105,6 +109,7 @@ class SceneBuilder:
         self.screen_space_texture = None    # float32 [h, w, 4]: context::screen_space_texture
         self.enable_shadowray_base_stylized_shadow = True
         self.blas = {}          # polygon object id -> node array (or None = build)
+        self.bvh_options = None # dict of atns_bvh_options fields for atns_build_blas_opt (None = DEFAULT_BVH_OPTIONS / the library's)
         self.mesh_counter = 0
         self.config = L.SceneRenderingConfig()
         self.config.bvh_hit_min = -1.0
@@ -429,6 +434,10 @@ class SceneBuilder:
         self.objects.append(dict(type=L.OBJ_INSTANCE, object_id=obj_id, mtx_id=mid, light_id=-1))
         return len(self.objects) - 1
 
+    def _bvh_options(self):
+        kw = self.bvh_options if self.bvh_options is not None else DEFAULT_BVH_OPTIONS
+        return C.byref(default_bvh_options(**kw)) if kw else None
+
     def import_sbvh(self, obj_id, path):
         """PolygonObject::importInternalAccelTree + sbvh::buildAsNestedTree's triangle offset."""
         hdr, mtrl_names, nodes = read_sbvh(path)
@@ -452,9 +461,10 @@ class SceneBuilder:
         ids = np.asarray(tri_ids, np.uint32)
         out = C.c_void_p(); cnt = C.c_uint32()
         bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
-        rc = lib.atns_build_blas(L.ptr(pos), L.ptr(tris), L.ptr(ids), len(ids), C.byref(out), C.byref(cnt), bmin, bmax)
+        rc = lib.atns_build_blas_opt(L.ptr(pos), L.ptr(tris), L.ptr(ids), len(ids), self._bvh_options(), C.byref(out), C.byref(cnt),
+                                     bmin, bmax, None)
         if rc != 0:
-            raise RuntimeError("atns_build_blas failed: %d" % rc)
+            raise RuntimeError("atns_build_blas_opt failed: %d" % rc)
         nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
         lib.atns_free(out)
         first = min(tri_ids)
@@ -539,6 +549,7 @@ class SceneBuilder:
         obj_bbox = {}
         bvh_lists = [None]          # [0] = TLAS
         blas_index = {}
+        bvh_stats = {}
         for oid, o in enumerate(self.objects):
             if o["type"] != L.OBJ_POLYGONS:
                 continue
@@ -568,9 +579,12 @@ class SceneBuilder:
                 out = C.c_void_p(); cnt = C.c_uint32()
                 bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
                 ids = np.asarray(tri_ids, np.uint32)
-                rc = lib.atns_build_blas(L.ptr(pos), L.ptr(tris), L.ptr(ids), num, C.byref(out), C.byref(cnt), bmin, bmax)
+                st = BvhStats()
+                rc = lib.atns_build_blas_opt(L.ptr(pos), L.ptr(tris), L.ptr(ids), num, self._bvh_options(), C.byref(out), C.byref(cnt),
+                                             bmin, bmax, C.byref(st))
                 if rc != 0:
-                    raise RuntimeError("atns_build_blas failed: %d" % rc)
+                    raise RuntimeError("atns_build_blas_opt failed: %d" % rc)
+                bvh_stats[oid] = dict(nodes=st.n_nodes, leaves=st.n_leaves, spatial_splits=st.n_spatial_splits, sah=st.sah_cost)
                 nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
                 lib.atns_free(out)
                 bmin, bmax = np.asarray(list(bmin), F32), np.asarray(list(bmax), F32)
@@ -660,6 +674,7 @@ class SceneBuilder:
         fs.keep = [objs, mtx, mats, lights, tris, pos, nml, bvh_lists, lists, texd, [t for _, t in self.textures], npr, sst]
         fs.lists = lists
         fs.blas_index = dict(blas_index)      # polygon object id -> its node list
+        fs.bvh_stats = bvh_stats              # polygon object id -> atns_bvh_stats of the tree built here
         fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lights, triangles=tris,
                          vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, textures=[t for _, t in self.textures])
         fs.names = dict(materials=[n for n, _ in self.materials], textures=[n for n, _ in self.textures])

@@ -75,7 +75,7 @@ def envmap_avg_illum(tex):
     return float((lum * s).sum() / (s.sum() * tex.shape[1]))
 
 
-def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True):
+def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True, bvh_options=None):
     """BASELINE config 3 stand-in: sponza_lod.obj (12,852 tris) with the reference-built
     sponza_lod.sbvh tree, GGX materials, synthetic IBL."""
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
@@ -91,6 +91,9 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
                                   roughness=0.4, metallic=0.1, specular=0.5, clearcoat=0.2)
         return b.add_material(name, mt, clr, albedo_map=alb, normal_map=nm)
 
+    cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)         # scenedefs.cpp:847-860
+    # own tree (use_sbvh=False): children nearer the viewer are threaded first
+    b.bvh_options = dict(order_point=cam["pos"]) if bvh_options is None else bvh_options
     objs = b.load_obj(os.path.join(asset_dir, "sponza_lod.obj"), create_mtrl=create_mtrl)
     if use_sbvh:
         b.import_sbvh(objs[0], os.path.join(asset_dir, "sponza_lod.sbvh"))
@@ -101,7 +104,6 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
         b.add_ibl(tid, avg_illum=envmap_avg_illum(env))
     else:
         b.set_background((1.0, 1.0, 1.0))
-    cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)         # scenedefs.cpp:847-860
     return b.build(), cam
 
 
@@ -257,6 +259,8 @@ def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
     geometry blob is absent; deterministic (no RNG).  `detail` scales the tessellation."""
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
     b = SceneBuilder()
+    cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
+    b.bvh_options = dict(order_point=cam["pos"])       # the hall's tree: children nearer the viewer are threaded first
 
     def tex(name):
         return b.load_image(os.path.join(asset_dir, name))
@@ -329,7 +333,6 @@ def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
     env = synthetic_envmap()
     tid = b.add_texture("synthetic_sky_2048x1024", env)
     b.add_ibl(tid, avg_illum=envmap_avg_illum(env))
-    cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
     return b.build(), cam
 
 

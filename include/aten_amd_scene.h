@@ -5,8 +5,9 @@
  *   aten::ThreadedBVH::build / setOrder       (src/libaten/accelerator/threaded_bvh.cpp:178-357)
  * produce: vectors of 48-byte threaded nodes (hit/miss links, one triangle per leaf).
  *
- * The tree TOPOLOGY is ours (binned SAH, optional spatial splits), the node FORMAT is the
- * reference's; closest-hit results do not depend on topology except for exact-t ties.
+ * The tree TOPOLOGY is ours (a split BVH: SAH object splits against spatial splits with triangle clipping and reference
+ * unsplitting, csrc/host/bvh_builder.cpp), the node FORMAT is the reference's; closest-hit results do not depend on
+ * topology except for exact-t ties.
  */
 #ifndef ATEN_AMD_SCENE_H_
 #define ATEN_AMD_SCENE_H_
@@ -17,6 +18,12 @@
 extern "C" {
 #endif
 
+/* Version of THIS header's entry points (libaten_amd_scene.so; atn_abi_version covers libaten_amd.so only).  Bumped when an
+ * existing signature or struct changes; a binding checks it once after loading.  2 = atns_obj_register / atns_obj_copy with
+ * counts and capacities, atns_build_blas_opt. */
+#define ATNS_ABI_VERSION 2u
+uint32_t atns_abi_version(void);
+
 /* Bottom-level tree over the triangles tri_ids[0..n_tris) of `tris` (global ids are written
  * into the leaves, like sbvh::convert's `ref.triid + m_offsetTriIdx`, sbvh.cpp:897).
  * Nodes come out in depth-first pre-order: an inner node's hit link is always index+1.
@@ -25,6 +32,38 @@ int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
                     const uint32_t* tri_ids, uint32_t n_tris,
                     atn_bvh_node** out_nodes, uint32_t* out_count,
                     float out_bbox_min[3], float out_bbox_max[3]);
+
+/* The knobs of the bottom-level builder.  atns_bvh_default_options fills in what atns_build_blas uses. */
+enum {
+    ATNS_ORDER_AS_SPLIT = 0,      /* lower side of the split plane first (what sbvh::onBuild does, sbvh.cpp:386-404) */
+    ATNS_ORDER_AREA = 1,          /* child with the larger surface area first */
+    ATNS_ORDER_AREA_SMALL = 2,    /* ... smaller ... */
+    ATNS_ORDER_COUNT = 3,         /* child with more references first */
+    ATNS_ORDER_COUNT_SMALL = 4,   /* ... fewer ... */
+    ATNS_ORDER_NEAR_POINT = 5     /* child whose box is nearer to order_point first: where most rays start (a viewer
+                                     position, the middle of a room); default point = area-weighted centroid of the mesh */
+};
+typedef struct atns_bvh_options {
+    int32_t spatial_splits;       /* 0 = object splits only */
+    float spatial_alpha;          /* look at a spatial split when overlap(children) / area(root) >= this (sbvh.cpp:232: 1e-5) */
+    int32_t object_bins;          /* bins of the binned object split (nodes of sweep_below references and more) */
+    int32_t spatial_bins;         /* bins of the chopped-reference spatial split */
+    int32_t sweep_below;          /* exact sweep over sorted centroids for nodes with fewer references than this */
+    int32_t child_order;          /* ATNS_ORDER_*: which child the fixed-order threaded walk enters first */
+    float max_refs_factor;        /* duplication budget: references <= this * triangles (then object splits only) */
+    float order_point[3];
+    int32_t order_point_given;    /* 0 = ignore order_point, use the centroid */
+} atns_bvh_options;
+typedef struct atns_bvh_stats {
+    uint32_t n_nodes, n_leaves, n_spatial_splits;
+    float sah_cost;               /* sum over nodes of area(node) / area(root): expected box tests of a random long ray */
+} atns_bvh_stats;
+void atns_bvh_default_options(atns_bvh_options* out);
+/* atns_build_blas with explicit options (NULL = defaults) and optional statistics. */
+int atns_build_blas_opt(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
+                        const uint32_t* tri_ids, uint32_t n_tris, const atns_bvh_options* options,
+                        atn_bvh_node** out_nodes, uint32_t* out_count,
+                        float out_bbox_min[3], float out_bbox_max[3], atns_bvh_stats* out_stats);
 
 /* Top-level tree over instances.  boxes: n * {min.xyz, max.xyz} (world space, already
  * transformed like aabb::transform in threaded_bvh.cpp:203-204); object_ids: transformable index

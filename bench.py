@@ -199,6 +199,9 @@ def run_workload(args, cfg, ctx):
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh (stand-in for missing sponza.obj)" % (W, H, spp, depth)
         if ex:
             workload += " EXPERIMENT " + "+".join(sorted(ex))
+    elif scene == "sponza_own_tree":
+        fs, cam = scenedefs.sponza_lod(use_sbvh=False)
+        workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, tree built by atns_build_blas (split BVH)" % (W, H, spp, depth)
     elif scene == "atrium":
         fs, cam = scenedefs.atrium()
         workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; synthetic Sponza-class scale-up, stand-in "
@@ -393,7 +396,7 @@ def run_workload(args, cfg, ctx):
     iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
     roof_ms = iso_ms if overlapped else avg_launch_ms
     avg_launch_s = max(roof_ms * 1e-3, 1e-12)
-    scene_tag = {"sponza": "sponza_lod", "cornell": "cornell", "atrium": "atrium"}[scene]
+    scene_tag = {"sponza": "sponza_lod", "sponza_own_tree": "sponza_lod own tree", "cornell": "cornell", "atrium": "atrium"}[scene]
     prof, stale, sha = profile_counters(scene_tag, W, H, spp, depth, svgf)
     pk = kernel_entry((prof,), dominant) if prof else None
     # The committed PMC record is of the UNSHARDED launch.  A rank of a world of N traces the rays of every N-th 8x8 tile: its
@@ -535,7 +538,7 @@ def run_workload(args, cfg, ctx):
     ray_segments = per_frame["closest_rays"] + per_frame["shadow_rays"]
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and cfg["cpu_baseline"]:
+    if rank == 0 and cfg["cpu_baseline"]:     # at any world size: the other ranks wait at the next collective (10 - 25 s)
         from oracle import orc     # the cpu_baseline leg is the only place bench.py touches oracle/
         # bounded sample of the same workload: the benchmarked frame itself (same scene / camera / seeds / size) when a
         # CPU frame takes seconds (1080p 1 spp: ~1.2 s with 16 threads); 1/6 linear resolution for the 4K 8-spp config,
@@ -571,6 +574,7 @@ def run_workload(args, cfg, ctx):
         budget = cfg.get("cpu_budget_s", 16.0)
         med, nfr = cpu_median(n_cpu, 5 if budget >= 16 else 3, budget)
         cpu_baseline = {"value": round(cw * ch * spp / 1e6 / med, 4), "unit": "Mrays/s", "cores": n_cpu, "logical_cpus": orc.lib().orc_num_procs(),
+                        "measured_at_world": world,
                         "kind": "port", "sample": ("the benchmarked frame itself: " if (cw, ch) == (W, H) else "reduced frame: ") + "%dx%d frames of the same scene/camera/seeds, %d frames, median; OpenMP parallel-for over rows like pathtracing.cpp:296-305, one thread per CPU the container may use (cgroup quota)" % (cw, ch, nfr),
                         "ms_per_frame_sample": round(1e3 * med, 2)}
         if cfg.get("cpu_8_threads", True):
@@ -593,6 +597,9 @@ def run_workload(args, cfg, ctx):
         dist.all_gather_object(devices, mine)
         dist_info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": devices,
                      "distinct_devices": len(set((d["pci_bus_id"], d["uuid"]) for d in devices))}
+        if dist_info["backend"] == "nccl" and dist_info["distinct_devices"] != world:
+            # one rank per GPU is the contract: RCCL ranks sharing a device would make every number below meaningless
+            raise SystemExit("bench.py: %d ranks drive %d distinct GPUs (%s)" % (world, dist_info["distinct_devices"], devices))
 
     # --verify-film: rank 0 renders the same K frames UNSHARDED once more and compares the film with the one the N ranks
     # assembled (byte for byte; the other ranks go on to the closing barrier)
@@ -646,7 +653,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed frames (default 200: a timed region of ~0.8 s; 20 for the 4K 8-spp config)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="sponza", choices=["sponza", "cornell", "atrium"])
+    ap.add_argument("--scene", default="sponza", choices=["sponza", "sponza_own_tree", "cornell", "atrium"])
     ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config shortcuts: c2 = Cornell 1080p 1spp 5-bounce, c3 = Sponza 1080p 1spp 5-bounce "
                          "(default), c4 = 4K 8spp 8-bounce Disney + textures on the procedural atrium stand-in, "
@@ -663,6 +670,8 @@ def main():
     ap.add_argument("--no-companion", action="store_true",
                     help="the default run (Sponza stand-in, 1 GPU) also times the 250 K-triangle procedural atrium at the same 1080p 1 spp "
                          "5-bounce protocol and reports it under `companion` (SURVEY 8(d): the stand-in AND a synthetic scale-up); this skips it")
+    ap.add_argument("--no-own-tree", action="store_true",
+                    help="the default run also times the headline frames through the tree of the repo's own BVH builder (`own_tree`); this skips it")
     ap.add_argument("--experiment", default="", help="traffic experiments on the sponza scene, not a benchmark configuration: "
                     "'notex' (no textures), 'noibl' (white background instead of the environment map), 'notex,noibl'")
     ap.add_argument("--dump", default=None, help="write the final frame (npy) here")
@@ -678,7 +687,9 @@ def main():
                          "several ranks SHARE a GPU (RCCL refuses that), which is how the tests run a world of two on a 1-GPU box")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is measured this many times; value = the median")
     ap.add_argument("--verify-film", action="store_true",
-                    help="after the timed region rank 0 renders the same K frames unsharded and reports film_equals_single_gpu")
+                    help="after the timed region rank 0 renders the same K frames unsharded and reports film_equals_single_gpu "
+                         "(on by default with more than one rank)")
+    ap.add_argument("--no-verify-film", action="store_true", help="skip that check with more than one rank")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL tile gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -723,7 +734,8 @@ def main():
     ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}
     cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
            "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
-           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "verify_film": args.verify_film}
+           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump,
+           "verify_film": args.verify_film or (world > 1 and not args.no_verify_film)}
     out = run_workload(args, cfg, ctx)
 
     # "sponza_lod for oracle-checked runs AND a synthetic scale-up for perf -- say which one every time".  The
@@ -740,6 +752,33 @@ def main():
             out["companion"] = {k: comp[k] for k in keep}
             out["companion"]["why"] = ("the headline stand-in (sponza_lod, 12 852 triangles) is cache-resident; this synthetic Sponza-class "
                                        "scale-up is the workload whose tree does not fit an XCD's L2")
+            # the same in short inside `config` (the driver's record keeps config / roofline / cpu_baseline, not extra keys)
+            out["config"]["companion"] = {"workload": "atrium %d triangles %dx%d %dspp %d-bounce" % (comp["config"]["triangles"], args.width, args.height, args.spp, args.depth),
+                                          "value": comp["value"], "unit": comp["unit"], "ms_per_step": comp["ms_per_step"],
+                                          "ms_per_frame_latency": comp["ms_per_frame_latency"],
+                                          "roofline_bound": comp["roofline"]["bound"], "roofline_frac": comp["roofline"]["frac"],
+                                          "cpu_baseline_value": (comp["cpu_baseline"] or {}).get("value")}
+    if default_line and not args.no_own_tree:
+        # the same headline frames through the tree of the repo's OWN builder (csrc/host/bvh_builder.cpp) instead of the
+        # reference-built sponza_lod.sbvh: what a caller who ingests the OBJ through atns_* gets
+        ocfg = dict(cfg, scene="sponza_own_tree", dump=None, cpu_baseline=False)
+        own = run_workload(args, ocfg, dict(ctx, use_dist=False))
+        if rank == 0 and own is not None:
+            out["own_tree"] = {k: own[k] for k in ("value", "unit", "ms_per_step", "ms_per_frame_latency", "work_per_frame", "kernel_ms_per_frame_isolated", "film_sha256")}
+            out["own_tree"]["workload"] = own["config"]["workload"]
+            out["own_tree"]["bvh_nodes"] = own["config"]["bvh_nodes"]
+            out["config"]["own_tree"] = {"value": own["value"], "ms_per_step": own["ms_per_step"],
+                                         "node_visits_vs_reference_tree": round((own["work_per_frame"]["closest_nodes"] + own["work_per_frame"]["shadow_nodes"])
+                                                                               / max(out["work_per_frame"]["closest_nodes"] + out["work_per_frame"]["shadow_nodes"], 1), 4)}
+    if rank == 0 and out is not None:
+        parts = ["%s: %.1f Mrays/s, %.3f ms/frame, roofline %s %s" % (out["config"]["workload"][:40], out["value"], out["ms_per_step"], out["roofline"]["bound"], out["roofline"]["frac"])]
+        if "companion" in out:
+            c = out["companion"]
+            parts.append("companion atrium: %.1f Mrays/s, %.3f ms/frame, roofline %s %s" % (c["value"], c["ms_per_step"], c["roofline"]["bound"], c["roofline"]["frac"]))
+        if "own_tree" in out:
+            parts.append("own-tree sponza_lod: %.1f Mrays/s, %.3f ms/frame" % (out["own_tree"]["value"], out["own_tree"]["ms_per_step"]))
+        out["summary"] = "; ".join(parts)        # last key: survives a reader that keeps only the tail of the line
+        print("[bench] " + out["summary"], file=sys.stderr, flush=True)
 
     if use_dist:
         # every rank drains its own buffers (RCCL's banner sits in the C library's) BEFORE rank 0 writes the JSON line

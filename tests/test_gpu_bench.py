@@ -68,6 +68,15 @@ def test_default_line_carries_roofline_companion_and_cpu_baseline():
             assert 0 < rf["frac"] <= 1.0 and set(rf["fractions"]) >= {"hbm", "l2", "l1", "valu"}
         cb = w["cpu_baseline"]
         assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    # the companion and the own-tree run in short inside `config` (the part of the line the driver's record keeps), and as the
+    # LAST key of the line
+    cc = d["config"]["companion"]
+    assert cc["value"] == d["companion"]["value"] and cc["ms_per_step"] == d["companion"]["ms_per_step"] and "roofline_frac" in cc
+    ot = d["own_tree"]
+    assert "atns_build_blas" in ot["workload"] and ot["value"] > 0
+    assert 0.8 < d["config"]["own_tree"]["node_visits_vs_reference_tree"] < 1.05
+    assert list(d)[-1] == "summary" and "companion atrium" in d["summary"] and "own-tree" in d["summary"]
+    assert "[bench] " + d["summary"] in p.stderr.decode()
 
 
 @pytest.mark.gpu
@@ -84,7 +93,9 @@ def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29573 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--no-cpu-baseline", "--repeats", "2", "--verify-film", "--dump", dump]
+           "--warmup", "1", "--repeats", "2", "--dump", dump] + (["--no-cpu-baseline"] if world != 2 else [])
+    # (no --verify-film: with more than one rank it is on by default; the world of two also carries the CPU baseline, which
+    #  rank 0 measures while the others wait -- the plain `bench.py --gpus N` line of the driver must be complete)
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
@@ -102,6 +113,12 @@ def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
     assert sum(x["tile_slots"] for x in di["devices"]) >= 1920 * 1080
     assert d["film_sha256"] == hashlib.sha256(film_plain.tobytes()).hexdigest()
     assert d["film_equals_single_gpu"] is True
+    assert d["config"]["frames_in_flight"] >= 1
+    if world == 2:
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["measured_at_world"] == 2
+    else:
+        assert d["cpu_baseline"] is None
     assert d["repeats"] == 2 and d["spread"] >= 1.0
     rf = d["roofline"]
     assert rf["kernel"] == "k_trace_fused" and rf["roofline_launch_ms"] > 0 and rf["counters_scaled_by"] == 1.0 / world

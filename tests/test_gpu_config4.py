@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from aten_amd.scene.camera import create_camera
+from conftest import parity_record
 from test_gpu_parity import frame_tolerance_report
 
 pytestmark = pytest.mark.gpu
@@ -124,6 +125,8 @@ def test_8spp_8bounce_vs_oracle_640x360(ctx, orc, atrium, brk):
         want = np.zeros((h, w, 4), np.float32)
         want[..., :3] = (acc / np.maximum(cnt, 1)[..., None]).astype(np.float32)
     frac, mean_err = frame_tolerance_report(got, want)
+    parity_record("C4 stand-in at oracle size: atrium 640x360 8spp 8-bounce Disney, %s" % ("break on terminate (CPU renderer's sample loop)" if brk else "all samples traced"),
+                  got, want)
     # one depth-8 sample is inside the band for ~95-97 % of the pixels; a pixel that averages 8 independent samples is
     # inside only if all eight are (0.95^8 = 0.66), while with the break most pixels stop after their first sample
     assert frac >= (0.90 if brk else 0.60), (brk, frac)
@@ -151,8 +154,13 @@ def test_companion_workload_1080p_vs_oracle(ctx, orc, atrium):
     for frame in (0, 5):
         ctx.reset()
         got = ctx.render(w, h, 5, 3, frame=frame)
-        want = orc.render(fs, c, seeds, w, h, 5, 3, frame=frame)
+        want, cnt = orc.render(fs, c, seeds, w, h, 5, 3, frame=frame, counters=True)
         frac, mean_err = frame_tolerance_report(got, want)
         assert frac >= 0.97, (frame, frac)
         assert mean_err <= 5e-3, (frame, mean_err)
+        ctx.reset()
+        ctx.render(w, h, 5, 3, frame=frame, count_stats=True, download=False)
+        m = parity_record("companion: atrium 1920x1080 1spp 5-bounce Disney + textures + IBL, frame %d" % frame, got, want,
+                          gpu_stats=ctx.stats(), oracle_counters=cnt)
+        assert m["nonfinite_pixels_got"] == m["nonfinite_pixels_want"]
 

@@ -1053,7 +1053,7 @@ public:
     {
         FrameParams fp{};
         fp.width = d.width; fp.height = d.height; fp.n_slots = (int32_t)n_slots;
-        fp.tiles_x = (d.width + 7) / 8; fp.tiles_y = (d.height + 7) / 8;
+        fp.tiles_x = (d.width + 7) / 8; fp.tiles_y = (d.height + 7) / 8; fp.tiles_x_rcp = udiv_rcp((uint32_t)fp.tiles_x);
         fp.rank = rank; fp.world = world;
         fp.max_depth = d.maxDepth;
         fp.rr_depth = d.russianRouletteDepth;

@@ -51,6 +51,7 @@ struct FrameParams {
     int32_t chunk_items;            // 1..kChunkItems queue entries per thread and chunk in k_shade: 4 keeps the queue atomics
                                     // rare on full frames, fewer give small launches enough blocks to fill the chip
     int32_t tiles_x, tiles_y;
+    uint32_t tiles_x_rcp;       // udiv_rcp(tiles_x): slot -> pixel divides by a scalar, without a hoisted vector-register reciprocal
     int32_t rank, world;        // screen-space shard: tile t belongs to rank t % world
     int32_t max_depth, rr_depth;
     int32_t sample;
@@ -68,9 +69,10 @@ ATN_DEV bool slot_to_pixel(const FrameParams& fp, uint32_t slot, int32_t& x, int
     const uint32_t in_tile = slot & 63u;
     const uint32_t tile = local_tile * (uint32_t)fp.world + (uint32_t)fp.rank;
     if (tile >= (uint32_t)(fp.tiles_x * fp.tiles_y)) return false;
-    const int32_t tx = (int32_t)(tile % (uint32_t)fp.tiles_x), ty = (int32_t)(tile / (uint32_t)fp.tiles_x);
-    x = tx * 8 + (int32_t)(in_tile & 7u);
-    y = ty * 8 + (int32_t)(in_tile >> 3);
+    uint32_t tx, ty;
+    udivmod(tile, (uint32_t)fp.tiles_x, fp.tiles_x_rcp, ty, tx);
+    x = (int32_t)tx * 8 + (int32_t)(in_tile & 7u);
+    y = (int32_t)ty * 8 + (int32_t)(in_tile >> 3);
     return x < fp.width && y < fp.height;
 }
 
@@ -95,7 +97,6 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
                            uint32_t* qB, uint32_t* cntB, uint32_t flagsB, EntryFn entry)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t totA = 0, totB = 0;
 #pragma unroll
     for (int k = 0; k < kChunkItems; k++) {
@@ -117,8 +118,8 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
     for (int k = 0; k < kChunkItems; k++) {
         const unsigned long long mA = __ballot((flagsA >> k) & 1u);
         const unsigned long long mB = __ballot((flagsB >> k) & 1u);
-        if ((flagsA >> k) & 1u) qA[offA + (uint32_t)__popcll(mA & lt)] = entry(k);
-        if ((flagsB >> k) & 1u) qB[offB + (uint32_t)__popcll(mB & lt)] = entry(k);
+        if ((flagsA >> k) & 1u) qA[offA + bits_below_lane(mA)] = entry(k);
+        if ((flagsB >> k) & 1u) qB[offB + bits_below_lane(mB)] = entry(k);
         offA += (uint32_t)__popcll(mA);
         offB += (uint32_t)__popcll(mB);
     }
@@ -291,7 +292,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
       const uint32_t n_valid = count - chunk < chunk_size ? count - chunk : chunk_size;
       {
           const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-          const unsigned long long lt = (1ull << lane) - 1ull;
           uint32_t hitmask = 0;
           __syncthreads();            // the previous chunk's append has read `part.perm`
 #pragma unroll 1
@@ -318,7 +318,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                   if (w < wave) { bh_w += part.wcount[k][w][0]; bm_w += part.wcount[k][w][1]; }
                   before_h += part.wcount[k][w][0]; before_m += part.wcount[k][w][1];
               }
-              if (valid) part.perm[hit ? bh_w + (uint32_t)__popcll(bh & lt) : total_hits + bm_w + (uint32_t)__popcll(bm & lt)] = q[j];
+              if (valid) part.perm[hit ? bh_w + bits_below_lane(bh) : total_hits + bm_w + bits_below_lane(bm)] = q[j];
           }
           __syncthreads();
       }
@@ -349,7 +349,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             const int32_t hit_objid = __float_as_int(is4.x);
             const float4 thr4 = pb.thr[slot];
             f3 throughput = mk3(thr4);
-            bool wrote_ray = false;
+            bool wrote_ray = false, thr_stored = false;
             f3 contrib_add = mk3(0.0F);         // contrib is read-modify-written only by the paths that add to it
             bool contrib_changed = false;
             // sampler state: GeneratePath's scramble (pathtracing_impl.h:75-81) from the pixel's seed
@@ -358,7 +358,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 int32_t px = 0, py = 0;
                 slot_to_pixel(fp, slot, px, py);
                 s4.w = (uint32_t)(py * fp.width + px);
-                const uint32_t rnd = pb.seeds[s4.w % fp.n_seeds];
+                const uint32_t rnd = pb.seeds[s4.w < fp.n_seeds ? s4.w : s4.w % here(fp.n_seeds)];    // (one seed per pixel is the rule)
                 const uint32_t fs = fp.frame + (uint32_t)fp.sample;
                 s4.x = fs % 256u;
                 s4.y = __float_as_uint(thr4.w);
@@ -374,9 +374,10 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 if (!(flags & F_TERMINATED)) {
                     f3 dir = ray_dir;
                     if (bounce == 0) {
-                        const int32_t ix = (int32_t)(s4.w % (uint32_t)fp.width), iy = (int32_t)(s4.w / (uint32_t)fp.width);
-                        const float s = (float)ix / (float)fp.width;
-                        const float t = (float)iy / (float)fp.height;
+                        int32_t ix = 0, iy = 0;
+                        slot_to_pixel(fp, slot, ix, iy);
+                        const float s = (float)ix / (float)here(fp.width);
+                        const float t = (float)iy / (float)here(fp.height);
                         f3 o;
                         pinhole_sample(cam, s, t, o, dir);
                     }
@@ -502,7 +503,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     const uint32_t nee_dim = smp.dim;
                     const f3 thr_in = throughput;
                     if (nee) {
-                        int32_t li = (int32_t)(cmj_next(smp) * (float)sc.n_lights);
+                        int32_t li = (int32_t)(cmj_next(smp) * (float)here(sc.n_lights));
                         li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
                         smp.dim += light_sample_draws(sc.lights[li], sc);
                     }
@@ -530,6 +531,9 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     else {
                         flags |= F_TERMINATED;
                     }
+                    // (the path's throughput and sampler position are final here: stored now, not carried across the NEE block)
+                    pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+                    thr_stored = true;
                     if (!(flags & F_TERMINATED)) {
                         pdfb = ms.pdf;
                         flags = (m.attrib & ATN_MTRL_ATTR_SINGULAR) ? (flags | F_SINGULAR) : (flags & ~F_SINGULAR);
@@ -547,22 +551,23 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     // ---- the NEE evaluation (see above); HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     if (nee && !(flags & F_TERMINATED)) {
                         Cmj sl; sl.idx = smp.idx; sl.dim = nee_dim; sl.scramble = smp.scramble;
-                        int32_t li = (int32_t)(cmj_next(sl) * (float)sc.n_lights);
+                        int32_t li = (int32_t)(cmj_next(sl) * (float)here(sc.n_lights));
                         li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
-                        const float lightSelectPdf = 1.0f / (float)sc.n_lights;
+                        const float lightSelectPdf = sc.inv_n_lights;       // 1.0f / (float)n_lights, divided once at upload
                         LightSample ls;
                         sample_light(ls, sc.lights[li], sc, rec.p, orienting_normal, sl);
                         f3 radiance;
                         if (radiance_nee<MS>(radiance, sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r)) {
+                            // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
+                            const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u));
+                            // the contribution first: `radiance` is dead before the shadow ray's geometry is worked out
+                            const f3 lightcontrib = (thr_in * radiance) * albedo;
+                            pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, lbits);     // (the light bits again: all finish() needs)
                             const f3 dirToLight = normalize(ls.dir);
                             const float distToLight = length(ls.pos - rec.p);
                             const f3 so = ray_offset(rec.p, orienting_normal);
-                            const f3 lightcontrib = (thr_in * radiance) * albedo;
-                            // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
-                            const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u));
                             pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
                             pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, lbits);
-                            pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, lbits);     // (the light bits again: all finish() needs)
                             push_shadow = true;
                         }
                     }
@@ -573,7 +578,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 // keep the flags for the sample epilogue
                 pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
             }
-            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+            if (!thr_stored) pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
             if (contrib_changed) {
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
@@ -849,7 +854,7 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(const float4* __restrict
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (uint32_t)(world * slots_per_rank)) return;
     FrameParams fp{};
-    fp.width = width; fp.height = height; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+    fp.width = width; fp.height = height; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y; fp.tiles_x_rcp = udiv_rcp((uint32_t)tiles_x);
     fp.world = world; fp.rank = (int32_t)(g / (uint32_t)slots_per_rank);
     const uint32_t slot = g % (uint32_t)slots_per_rank;
     int32_t x, y;

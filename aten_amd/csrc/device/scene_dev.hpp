@@ -106,6 +106,7 @@ struct DevScene {
     const uint32_t* texels8;            // packed r | g << 8 | b << 16 | a << 24
     const DevTexture* textures;
     int32_t n_lights;
+    float inv_n_lights;                 // 1.0f / (float)n_lights: the light pick's pdf, divided once (0 without lights)
     int32_t n_textures;
     int32_t n_materials;
     float bvh_hit_min;

@@ -1277,19 +1277,22 @@ ATN_DEV f3 uv_to_direction(float u, float v)
 // density used here is the true one, and the SAME function prices both the light sample and the BSDF-sampled miss.)
 ATN_DEV float ibl_texel_pdf(const DevScene& sc, float pdf_u, float pdf_v, int32_t y)
 {
-    const float v = (float)((double)y + 0.5) / (float)sc.ibl_h;
+    // (here(): this optional sampler's scalars are converted where they are used, not hoisted through all of k_shade)
+    const int32_t w = here(sc.ibl_w), h = here(sc.ibl_h);
+    const float v = (float)((double)y + 0.5) / (float)h;
     const float theta = kPi * v;
     const float pi2 = kPi * kPi;
-    return (pdf_u * pdf_v) * ((float)(sc.ibl_w * sc.ibl_h) / ((2.0F * pi2) * sinf(theta)));
+    return (pdf_u * pdf_v) * ((float)(w * h) / ((2.0F * pi2) * sinf(theta)));
 }
 ATN_DEV float ibl_direction_pdf(const DevScene& sc, const f3& dir)
 {
     float u, v;
     direction_to_uv(dir, u, v);
-    int32_t x = (int32_t)(u * (float)sc.ibl_w), y = (int32_t)(v * (float)sc.ibl_h);
-    x = x < 0 ? 0 : (x > sc.ibl_w - 1 ? sc.ibl_w - 1 : x);
-    y = y < 0 ? 0 : (y > sc.ibl_h - 1 ? sc.ibl_h - 1 : y);
-    const float* __restrict__ cu = sc.ibl_cdf_u + (size_t)y * sc.ibl_w;
+    const int32_t w = here(sc.ibl_w), h = here(sc.ibl_h);
+    int32_t x = (int32_t)(u * (float)w), y = (int32_t)(v * (float)h);
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    const float* __restrict__ cu = sc.ibl_cdf_u + (size_t)y * w;
     const float pu = x > 0 ? cu[x] - cu[x - 1] : cu[0];
     const float pv = y > 0 ? sc.ibl_cdf_v[y] - sc.ibl_cdf_v[y - 1] : sc.ibl_cdf_v[0];
     return ibl_texel_pdf(sc, pu, pv, y);
@@ -1378,10 +1381,11 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
         if (sc.ibl_importance) {
             // the table sampler, ImageBasedLight::sample(ctxt, org, nml, sampler), light/ibl.cpp:180-230
             float pdf_u, pdf_v;
-            const int32_t y = ibl_sample_cdf(r1, sc.ibl_cdf_v, sc.ibl_h, pdf_v);
-            const int32_t x = ibl_sample_cdf(r2, sc.ibl_cdf_u + (size_t)y * sc.ibl_w, sc.ibl_w, pdf_u);
-            const float u = (float)((double)x + 0.5) / (float)sc.ibl_w;
-            const float v = (float)((double)y + 0.5) / (float)sc.ibl_h;
+            const int32_t iw = here(sc.ibl_w), ih = here(sc.ibl_h);
+            const int32_t y = ibl_sample_cdf(r1, sc.ibl_cdf_v, ih, pdf_v);
+            const int32_t x = ibl_sample_cdf(r2, sc.ibl_cdf_u + (size_t)y * iw, iw, pdf_u);
+            const float u = (float)((double)x + 0.5) / (float)iw;
+            const float v = (float)((double)y + 0.5) / (float)ih;
             res.pdf = ibl_texel_pdf(sc, pdf_u, pdf_v, y);
             res.dir = uv_to_direction(u, v);
             const float4 lum = mul4(sc.multiplyer, sample_texture(sc, lp.envmapidx, u, v, make_float4(1, 1, 1, 1)));

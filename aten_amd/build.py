@@ -43,6 +43,22 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    """First line of `hipcc --version` that names the HIP / clang build (the GPU box runs the same image: same string);
+    '' when there is no hipcc (then the prebuilt library's own id is all there is to compare with)."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            out = subprocess.check_output([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], stderr=subprocess.STDOUT).decode()
+            _HIPCC_VERSION = " | ".join(l.strip() for l in out.splitlines() if l.startswith(("HIP version", "AMD clang version")))
+        except Exception:
+            _HIPCC_VERSION = ""
+    return _HIPCC_VERSION
+
+
 def kernel_sources_sha16():
     """Identity of the code the GPU runs: SHA-256 (first 16 hex digits) over the sources of libaten_amd.so, in path order.
     Compiled into the library (atn_build_id, with the extra compile flags) and recorded in profiles/*counters*.json when the PMC
@@ -56,14 +72,16 @@ def kernel_sources_sha16():
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
-    h.update(repr(HIP_UNITS).encode())      # the per-unit compiler flags are part of what the GPU runs
+    h.update(repr(HIP_UNITS).encode())      # the per-unit compiler flags are part of what the GPU runs ...
+    h.update(repr(HIP_FLAGS).encode())      # ... and so are the common ones (-O3, -ffp-contract=off, correctly rounded divide) ...
+    h.update(hipcc_version().encode())      # ... and the compiler that turned them into machine code
     return h.hexdigest()[:16]
 
 
 def build_id(extra_flags=()):
-    """What libaten_amd.so answers from atn_build_id(): the hash of the kernel sources + the extra flags it was compiled with
-    (none for the product build, whose per-unit flags -- HIP_UNITS -- are part of this hashed file's neighbour build.py and of
-    the sources' comments; tools/build_variants.sh passes its own)."""
+    """What libaten_amd.so answers from atn_build_id(): the hash of the kernel sources, the common and per-unit compiler flags
+    (HIP_FLAGS, HIP_UNITS) and the compiler's version string + the extra flags a variant build adds (none for the product
+    build; tools/build_variants.sh passes its own)."""
     return kernel_sources_sha16() + "|" + " ".join(sorted(extra_flags))
 
 

@@ -106,10 +106,9 @@ public:
     bool env_probe_streams = true;  // ATEN_AMD_PROBE_STREAMS=0: take the bank streams as the runtime hands them out
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
-    uint32_t env_min_batch = 200u * 1000u, env_trace_blocks = 0;
+    uint32_t env_trace_blocks = 0;
     int env_shade_waves = 0;    // ATEN_AMD_SHADE_WAVES=4|5 forces the k_shade_wn flavour (default: 5 when frames are in flight, else 4)
-    int env_shade_items = 0, env_flavour = -1, env_first_simple = 1;
-    uint32_t env_simple_mask = 0;       // experiment: bit b = launch b of a sample on the plain walk
+    int env_shade_items = 0, env_flavour = -1;
 
     // scene (HBM-resident after UpdateSceneData)
     DevBuf<float4> nodes, vtx_pos, vtx_nml, matrices, texels, carpaint, shade_tris;
@@ -181,7 +180,7 @@ public:
         hipEvent_t ev_read[3] = {};     // [scene set id]: the last frame of this bank that read that set has finished with the scene
         hipStream_t stream = nullptr, bstream[kMaxBatches] = {};
         hipEvent_t ev_fork = nullptr, ev_join[kMaxBatches] = {}, ev_gather = nullptr;
-        bool batch_streams_checked = false;
+        int batch_streams_checked = 0;
     };
     Bank spare[kMaxInFlight - 1];
     int frames_in_flight = 1, n_spare_ready = 0;
@@ -280,17 +279,23 @@ public:
         return ATN_OK;
     }
     // The batch streams a frame forks into when it is rendered in several batches (run_paths).  LAZY: probed the first time
-    // a frame of this bank really forks -- the probe costs milliseconds of spin kernels and, on a GPU shared with other
-    // processes, a spurious "clash" costs stream re-creations; most contexts (one batch: the refill walk, frames in flight)
-    // never fork.
-    bool batch_streams_checked = false;
-    int separate_batch_streams()
+    // a frame of this bank really forks into that many batches -- most contexts (one batch: the refill walk, frames in flight)
+    // never fork.  The probe times spin kernels against each other, so it runs on an IDLE device (quiesce: the other banks'
+    // frames would read as a clash and cost stream re-creations in the middle of a frame); the count of probed streams is
+    // recorded only when the probe succeeded, and a later, larger batch count probes the additional streams.
+    int batch_streams_checked = 0;      // bstream[0 .. n-1] of this bank are known to be pairwise concurrent
+    int separate_batch_streams(int nb)
     {
+        const int n = nb < 3 ? nb : 3;        // the size policy never uses more than two; three when forced
+        if (n <= batch_streams_checked || n < 2) return ATN_OK;
+        int rc = quiesce();
+        if (rc) return rc;
         hipStream_t* st[kMaxBatches];
-        const int n = n_batches < 3 ? n_batches : 3;        // the size policy never uses more than two; three when forced
         for (int i = 0; i < n; i++) st[i] = &bstream[i];
-        batch_streams_checked = true;
-        return n > 1 ? separate_streams(st, n, 1) : (int)ATN_OK;
+        rc = separate_streams(st, n, batch_streams_checked > 1 ? batch_streams_checked : 1);
+        if (rc) return rc;
+        batch_streams_checked = n;
+        return ATN_OK;
     }
 
     // the caller's side stream (atn_side_stream): concurrent with every bank stream if a queue is left
@@ -566,17 +571,15 @@ public:
         }
         ATN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         ATN_HIP(hipEventCreateWithFlags(&ev_gather, hipEventDisableTiming));
-        // experiment knobs (tools/variants.sh): read once here, never inside a frame
+        // environment switches (README.md "Environment variables": which are supported controls, which are experiment hooks);
+        // read once here, never inside a frame
         if (const char* e = std::getenv("ATEN_AMD_FUSE")) fuse_traces = e[0] != '0';
         if (const char* e = std::getenv("ATEN_AMD_SVGF_ATROUS4")) env_atrous4 = e[0] != '0';     // 0: the one-pixel-per-thread a-trous kernel
-        if (const char* e = std::getenv("ATEN_AMD_MIN_BATCH")) env_min_batch = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_TRACE_BLOCKS")) env_trace_blocks = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_SHADE_WAVES")) { const int v = std::atoi(e); if (v == 4 || v == 5) env_shade_waves = v; }   // else: by frames in flight
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
-        if (const char* e = std::getenv("ATEN_AMD_SIMPLE_MASK")) env_simple_mask = (uint32_t)std::atoi(e);
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_PROBE_STREAMS")) env_probe_streams = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ATEN_AMD_FIRST_SIMPLE")) env_first_simple = std::atoi(e);     // 0: primary rays on the refill walk too
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
         if (const char* e = std::getenv("ATEN_AMD_BATCHES")) {
@@ -1211,7 +1214,7 @@ public:
         int nb;
         if (batches_forced) {
             nb = n_batches;
-            const uint32_t min_batch = env_min_batch;
+            const uint32_t min_batch = 200u * 1000u;
             while (nb > 1 && n_slots / (uint32_t)nb < min_batch) nb--;
         }
         else {
@@ -1224,7 +1227,7 @@ public:
             if (nb > n_batches) nb = n_batches;
         }
         // the streams a frame's batches run on must not share a hardware queue (see streams_run_side_by_side)
-        if (nb > 1 && env_probe_streams && !batch_streams_checked) { int rc = separate_batch_streams(); if (rc) return rc; }
+        if (nb > batch_streams_checked && nb > 1 && env_probe_streams) { int rc = separate_batch_streams(nb); if (rc) return rc; }
         uint32_t per = (n_slots + (uint32_t)nb - 1u) / (uint32_t)nb;
         per = (per + kChunk - 1u) / kChunk * kChunk;        // whole 1024-slot chunks (16 screen tiles)
         ATN_HIP(hipMemsetAsync(counters.p, 0, (size_t)nb * 4 * counters_depth * 4, stream));
@@ -1272,7 +1275,7 @@ public:
                         const int32_t bs = b - 1, bc = b < d->maxDepth ? b : -1;
                         // the first launch holds only primary rays: coherent, they finish together, and the refill bookkeeping buys
                         // nothing (sponza_lod 4.33 -> 4.30 ms, atrium 4K 221 -> 219 ms)
-                        const bool refill_now = use_refill && !((env_simple_mask >> b) & 1u) && !(b == 0 && env_first_simple);
+                        const bool refill_now = use_refill && b != 0;     // (primary rays, coherent, take the plain walk: DESIGN.md section 7)
                         // (timed under "trace_closest" when it is a different kernel from the other launches: the roofline of
                         // k_trace_fused<true, .> is about those)
                         prof_begin(prof, (use_refill && !refill_now && b == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED, st);
@@ -1834,9 +1837,18 @@ int atn_bank_streams(atn_ctx* ctx, int32_t* swaps, int32_t* concurrent)
             for (int i = 0; i < r.frames_in_flight; i++)
                 for (int j = 0; j < i; j++) {
                     bool ok = true;
-                    if (!atn::streams_run_side_by_side(st[j], st[i], ok)) *concurrent = 0;
+                    if (!atn::streams_run_side_by_side(st[j], st[i], ok)) *concurrent &= ~1;
                     if (!ok) return r.fail(ATN_ERR_HIP, "stream probe failed");
                 }
+            // bit 1: the side stream, if it was handed out, runs beside every bank stream
+            if (r.side_stream) {
+                *concurrent |= 2;
+                for (int i = 0; i < r.frames_in_flight; i++) {
+                    bool ok = true;
+                    if (!atn::streams_run_side_by_side(st[i], r.side_stream, ok)) *concurrent &= ~2;
+                    if (!ok) return r.fail(ATN_ERR_HIP, "stream probe failed");
+                }
+            }
         }
         return (int)ATN_OK;
     });
@@ -2304,6 +2316,6 @@ uint32_t atn_sizeof_destination(void) { return (uint32_t)sizeof(atn_destination)
 #define ATN_BUILD_ID "unknown"
 #endif
 const char* atn_build_id(void) { return ATN_BUILD_ID; }
-uint32_t atn_abi_version(void) { return 3; }     // 3: atn_material_table takes the starting dimension, atn_compact3 dropped (r04); 2: NPR fields     // 2: atn_scene_desc grew the NPR fields (r02); atn_toon_param spelled out
+uint32_t atn_abi_version(void) { return 3; }     // 3: atn_material_table takes the starting dimension, atn_compact3 dropped (r04); 2: atn_scene_desc grew the NPR fields, atn_toon_param spelled out (r02)
 
 } // extern "C"

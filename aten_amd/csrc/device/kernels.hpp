@@ -96,7 +96,8 @@ template <class EntryFn>
 ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA,
                            uint32_t* qB, uint32_t* cntB, uint32_t flagsB, EntryFn entry)
 {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tid = here_v(threadIdx.x);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t totA = 0, totB = 0;
 #pragma unroll
     for (int k = 0; k < kChunkItems; k++) {
@@ -282,16 +283,19 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
     const uint32_t count = pb.q_count[bounce];
     const uint32_t* __restrict__ q = pb.queue[bounce & 1];
     uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
+#if !ATN_SHADE_PARTITION
     uint32_t nhits = 0;
+#endif
 
     const int items = fp.chunk_items;
     const uint32_t chunk_size = 256u * (uint32_t)items;
     for (uint32_t chunk = blockIdx.x * chunk_size; chunk < count; chunk += gridDim.x * chunk_size) {
-      uint32_t flags_next = 0, flags_shadow = 0;
+      uint32_t push_bits = 0;     // bit k: item k goes on to the next bounce; bit 16 + k: it has a shadow ray (one register, not two)
 #if ATN_SHADE_PARTITION
       const uint32_t n_valid = count - chunk < chunk_size ? count - chunk : chunk_size;
       {
-          const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+          const uint32_t tid = here_v(threadIdx.x);      // (the LDS addresses below are computed per chunk, not carried across it)
+          const uint32_t lane = tid & 63u, wave = tid >> 6;
           uint32_t hitmask = 0;
           __syncthreads();            // the previous chunk's append has read `part.perm`
 #pragma unroll 1
@@ -303,6 +307,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
               const unsigned long long bh = __ballot(hit), bm = __ballot(valid && !hit);
               if (lane == 0) { part.wcount[k][wave][0] = (uint32_t)__popcll(bh); part.wcount[k][wave][1] = (uint32_t)__popcll(bm); }
           }
+          if (pb.stats) wave_add_stat(&pb.stats[2], (uint32_t)__popc(hitmask));   // (counted frames only; per chunk, so that no counter lives across the shading)
           __syncthreads();
           uint32_t total_hits = 0;
           for (int k = 0; k < items; k++) for (uint32_t w = 0; w < 4; w++) total_hits += part.wcount[k][w][0];
@@ -404,7 +409,9 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             }
             else {
                 flags |= F_HIT;
+#if !ATN_SHADE_PARTITION
                 nhits++;
+#endif
                 // ---------------- shade
                 const int32_t tri_id = __float_as_int(is4.w);
                 HitRec rec;
@@ -556,8 +563,8 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         const float lightSelectPdf = sc.inv_n_lights;       // 1.0f / (float)n_lights, divided once at upload
                         LightSample ls;
                         sample_light(ls, sc.lights[li], sc, rec.p, orienting_normal, sl);
-                        f3 radiance;
-                        if (radiance_nee<MS>(radiance, sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r)) {
+                        push_shadow = radiance_nee_then<MS>(sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r, nullptr,
+                                                            [&](const f3& radiance) {
                             // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
                             const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u));
                             // the contribution first: `radiance` is dead before the shadow ray's geometry is worked out
@@ -568,8 +575,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                             const f3 so = ray_offset(rec.p, orienting_normal);
                             pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
                             pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, lbits);
-                            push_shadow = true;
-                        }
+                        });
                     }
                 }
             }
@@ -584,17 +590,18 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             }
         }
-        if (push_next) flags_next |= 1u << k;
-        if (push_shadow) flags_shadow |= 1u << k;
+        push_bits |= (push_next ? 1u << k : 0u) | (push_shadow ? 0x10000u << k : 0u);
       }
 #if ATN_SHADE_PARTITION
       auto entry_of = [&](int k) { return part.perm[(uint32_t)k * 256u + threadIdx.x]; };
 #else
       auto entry_of = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
 #endif
-      block_append2(sh, qn, &pb.q_count[bounce + 1], flags_next, pb.shadow_q, &pb.sh_count[bounce], flags_shadow, entry_of);
+      block_append2(sh, qn, &pb.q_count[bounce + 1], push_bits & 0xffffu, pb.shadow_q, &pb.sh_count[bounce], push_bits >> 16, entry_of);
     }
+#if !ATN_SHADE_PARTITION
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
+#endif
 }
 
 template <bool SVGF, int MS>

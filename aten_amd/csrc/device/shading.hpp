@@ -1472,11 +1472,12 @@ ATN_DEV uint32_t light_sample_draws(const atn_light_param& lp, const DevScene& s
     return t == ATN_OBJ_SPHERE ? 2u : (t == ATN_OBJ_POLYGONS ? 3u : 0u);
 }
 
-// ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95
-template <int MS = kMsCarPaint>
-ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
-                          float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F,
-                          float* weight_ptr = nullptr)
+// ComputeRadianceNEE, renderer/pathtracing/pathtracing_nee_impl.h:23-95.  `then(radiance)` runs where the reference returns a
+// value (k_shade stores the shadow job right there: the three floats never cross the join behind the validity test).
+template <int MS = kMsCarPaint, class Then>
+ATN_DEV bool radiance_nee_then(const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
+                               float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id, float pre_r,
+                               float* weight_ptr, Then&& then)
 {
     if (weight_ptr) *weight_ptr = 0.0F;
     const float cosShadow = dot(nml, ls.dir);
@@ -1493,11 +1494,18 @@ ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& n
         const float f = ls.pdf * light_select_prob;
         const float misW = is_singular ? 1.0f : f / (f + path_pdf);
         const float G = isInfinite ? cosShadow * cosLight : (cosShadow * cosLight) / dist2;
-        out = ((((misW * ev.bsdf) * ls.color) * G) / ls.pdf) / light_select_prob;
         if (weight_ptr) *weight_ptr = (misW / ls.pdf) / light_select_prob;      // pathtracing_nee_impl.h:87-89
+        then(((((misW * ev.bsdf) * ls.color) * G) / ls.pdf) / light_select_prob);
         return true;
     }
     return false;
+}
+template <int MS = kMsCarPaint>
+ATN_DEV bool radiance_nee(f3& out, const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
+                          float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id = 0, float pre_r = 0.0F,
+                          float* weight_ptr = nullptr)
+{
+    return radiance_nee_then<MS>(sc, wi, nml, m, hu, hv, light_select_prob, ls, mtrl_id, pre_r, weight_ptr, [&](const f3& r) { out = r; });
 }
 
 } // namespace atn

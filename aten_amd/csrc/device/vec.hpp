@@ -26,6 +26,7 @@ struct f3 { float x, y, z; };
 // main loop into a vector register that lives (at 5 waves per SIMD: spills) through everything else.  No instruction.
 ATN_DEV int32_t here(int32_t x) { asm volatile("" : "+s"(x)); return x; }
 ATN_DEV uint32_t here(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+ATN_DEV uint32_t here_v(uint32_t x) { asm volatile("" : "+v"(x)); return x; }     // the same for a per-lane value (threadIdx.x)
 // x / d and x % d for a uniform divisor with rcp = floor(2^32 / d) computed on the host (capped at 2^32 - 1 for d = 1): the
 // estimate mulhi(x, rcp) is the quotient or one less for every 32-bit x, so one correction step makes it exact.
 __host__ __device__ inline uint32_t udiv_rcp(uint32_t d) { return d <= 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / d); }

@@ -140,7 +140,8 @@ class PathTracing:
         """(streams replaced by the queue probe so far, every pair of bank streams measured to run side by side)"""
         sw, cc = C.c_int32(0), C.c_int32(0)
         self._check(self._l.atn_bank_streams(self._ctx, C.byref(sw), C.byref(cc)))
-        return sw.value, bool(cc.value)
+        self.side_stream_concurrent = bool(cc.value & 2)    # the side stream (if handed out) runs beside every bank stream
+        return sw.value, bool(cc.value & 1)
 
     def set_sampling_options(self, ibl_importance=False, tex_bilinear=False):
         self._check(self._l.atn_set_sampling_options(self._ctx, int(ibl_importance), int(tex_bilinear)))

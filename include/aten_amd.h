@@ -187,8 +187,9 @@ int atn_set_path_batches(atn_ctx* ctx, int32_t n);
 int atn_set_frames_in_flight(atn_ctx* ctx, int32_t n);
 /* Diagnostics of the above: HIP streams share a few hardware queues and two streams on one queue run one after the other, so
  * atn_set_frames_in_flight MEASURES which of its bank streams run side by side and replaces the ones that do not (DESIGN.md
- * section 8).  *swaps = streams replaced so far; *concurrent = 1 when every pair of the current bank streams was measured
- * to overlap (re-measured by this call), 0 otherwise (fewer hardware queues than frames in flight).  Either may be NULL. */
+ * section 8).  *swaps = streams replaced so far; *concurrent: bit 0 = every pair of the current bank streams was measured
+ * to overlap (re-measured by this call; 0 = fewer hardware queues than frames in flight), bit 1 = the side stream
+ * (atn_side_stream), if it was handed out, overlaps with every bank stream.  Either may be NULL. */
 int atn_bank_streams(atn_ctx* ctx, int32_t* swaps, int32_t* concurrent);
 /* A stream for the CALLER's own work beside the frames in flight (a tile exchange, a display copy): created on first use and
  * chosen -- by the same measurement -- to run side by side with every bank stream when a hardware queue is left for it

@@ -35,8 +35,11 @@ def test_force_gather_film_equals_plain_film(tmp_path):
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 0
         assert d["roofline"]["kernel"] == "k_trace_fused" and d["ms_per_frame_latency"] >= 0.9 * d["ms_per_step"]
         # the K-step region is timed `repeats` times, value is the median; the film's hash travels in the line
-        # (no upper bound on the spread: a 3-frame region is ~12 ms, one host hiccup in one of the five doubles it -- seen once in r04)
-        assert d["repeats"] == 5 and len(d["ms_per_step_repeats"]) == 5 and 1.0 <= d["spread"] < 100.0
+        # (a 3-frame region is ~12 ms and one host hiccup in one of the five doubles it -- seen once in r04 -- so the bound is on
+        #  the three middle repeats, which a single outlier cannot move: they agree within 1.5 x)
+        assert d["repeats"] == 5 and len(d["ms_per_step_repeats"]) == 5 and d["spread"] >= 1.0
+        mid = sorted(d["ms_per_step_repeats"])[1:4]
+        assert mid[2] <= 1.5 * mid[0], d["ms_per_step_repeats"]
         assert abs(d["ms_per_step"] - float(np.median(d["ms_per_step_repeats"]))) < 1e-3
         assert d["film_sha256"] == hashlib.sha256(film_plain.tobytes()).hexdigest()
     assert plain["dist"] is None

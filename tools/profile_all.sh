@@ -4,7 +4,7 @@
 # usage: tools/profile_all.sh <tag e.g. r03_d>
 TAG=${1:?tag}
 cd "$GRAFT_REPO_ROOT"
-bash tools/profile_round.sh $TAG c3_sponza1080p "sponza_lod 1920x1080 1spp 5-bounce" --no-companion
+bash tools/profile_round.sh $TAG c3_sponza1080p "sponza_lod 1920x1080 1spp 5-bounce" --no-companion --no-own-tree
 bash tools/profile_round.sh $TAG atrium1080p "atrium 1920x1080 1spp 5-bounce" --scene atrium
 bash tools/profile_round.sh $TAG c2_cornell1080p "cornell 1920x1080 1spp 5-bounce" --config c2
 bash tools/profile_round.sh $TAG c5_sponza1080p_svgf "sponza_lod 1920x1080 1spp 5-bounce svgf" --config c5

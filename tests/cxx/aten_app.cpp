@@ -119,6 +119,7 @@ int main(int argc, char** argv)
     const std::string out = argv[1];
     const int32_t W = std::atoi(argv[2]), H = std::atoi(argv[3]), frames = std::atoi(argv[4]);
 
+    if (atns_abi_version() != ATNS_ABI_VERSION) { std::fprintf(stderr, "libaten_amd_scene.so speaks ABI %u, this program %u\n", atns_abi_version(), ATNS_ABI_VERSION); return 2; }
     App a;
     const int white = a.add_material(ATN_MTRL_DIFFUSE, 0, 0.75F, 0.75F, 0.75F);
     const int red = a.add_material(ATN_MTRL_DIFFUSE, 0, 0.75F, 0.2F, 0.2F);

@@ -384,7 +384,7 @@ private:
             SpatialSplit sp;
             spatial_split_find(refs, bb, sp);
             if (sp.axis >= 0 && sp.cost < ob.cost) {
-                if (spatial_split_apply(refs, sp, left, right, lb, rb)) {
+                if (spatial_split_apply(refs, sp, left, right, lb, rb) && n_refs_live_ + left.size() + right.size() - n <= ref_budget_) {
                     done = true;
                     n_spatial++;
                     n_refs_live_ += left.size() + right.size() - n;
@@ -572,6 +572,10 @@ int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t
         }
         Options o;
         o.spatial = false;
+        // (no viewer hint at this entry point: children nearer to the middle of the instances are threaded first)
+        Box all = empty_box();
+        for (const Ref& r : refs) all.grow(r.box);
+        for (int k = 0; k < 3; k++) o.order_point[k] = all.centre(k);
         Builder b(o, nullptr);
         b.run(refs);
         atn_bvh_node* nodes = emit(b.nodes);

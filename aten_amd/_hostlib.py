@@ -15,11 +15,12 @@ class BvhOptions(C.Structure):          # atns_bvh_options
     _fields_ = [("spatial_splits", C.c_int32), ("spatial_alpha", C.c_float), ("object_bins", C.c_int32),
                 ("spatial_bins", C.c_int32), ("sweep_below", C.c_int32), ("child_order", C.c_int32),
                 ("max_refs_factor", C.c_float), ("order_point", C.c_float * 3),
-                ("order_point_given", C.c_int32)]
+                ("order_point_given", C.c_int32), ("reinsert_iterations", C.c_int32), ("reinsert_batch", C.c_float)]
 
 
 class BvhStats(C.Structure):            # atns_bvh_stats
-    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_spatial_splits", C.c_uint32), ("sah_cost", C.c_float)]
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_spatial_splits", C.c_uint32), ("n_reinsertions", C.c_uint32),
+                ("sah_cost", C.c_float)]
 
 
 def default_bvh_options(**kw):

@@ -103,6 +103,8 @@ struct Options {
     float max_refs_factor = 4.0f;   // duplication budget: references <= factor * primitives
     float order_point[3] = { 0, 0, 0 };
     bool order_point_given = false; // else: the area-weighted centroid of the triangles
+    int reinsert_iterations = 100;  // rounds of the insertion-based optimisation (0 = off), each over the worst `reinsert_batch` of the inner nodes
+    float reinsert_batch = 0.1f;
 };
 
 class Builder {
@@ -327,34 +329,6 @@ private:
         return !left.empty() && !right.empty() && left.size() < refs.size() && right.size() < refs.size();
     }
 
-    // ---- which child the fixed-order walk enters first ---------------------------------------------------------------
-    bool right_first(const Box& lb, uint32_t ln, const Box& rb, uint32_t rn) const
-    {
-        switch (opt.child_order) {
-        case ATNS_ORDER_AREA: return rb.half_area() > lb.half_area();
-        case ATNS_ORDER_AREA_SMALL: return rb.half_area() < lb.half_area();
-        case ATNS_ORDER_COUNT: return rn > ln;
-        case ATNS_ORDER_COUNT_SMALL: return rn < ln;
-        case ATNS_ORDER_NEAR_POINT: {
-            float dl = 0, dr = 0;
-            for (int k = 0; k < 3; k++) {
-                const float p = opt.order_point[k];
-                const float a = std::max(std::max(lb.mn[k] - p, p - lb.mx[k]), 0.f);
-                const float b = std::max(std::max(rb.mn[k] - p, p - rb.mx[k]), 0.f);
-                dl += a * a; dr += b * b;
-            }
-            if (dl != dr) return dr < dl;
-            float cl = 0, cr = 0;
-            for (int k = 0; k < 3; k++) {
-                const float a = lb.centre(k) - opt.order_point[k], b = rb.centre(k) - opt.order_point[k];
-                cl += a * a; cr += b * b;
-            }
-            return cr < cl;
-        }
-        default: return false;
-        }
-    }
-
     void build(std::vector<Ref> refs, const Box& bb)
     {
         const uint32_t self = (uint32_t)nodes.size();
@@ -398,7 +372,6 @@ private:
         }
         std::vector<Ref>().swap(refs);
 
-        if (right_first(lb, (uint32_t)left.size(), rb, (uint32_t)right.size())) { left.swap(right); std::swap(lb, rb); }
         build(std::move(left), lb);
         build(std::move(right), rb);
         nodes[self].end = (uint32_t)nodes.size();
@@ -421,6 +394,253 @@ private:
 };
 
 
+
+// ---- post passes on the finished tree -----------------------------------------------------------------------------------
+// (1) Insertion-based optimisation (Bittner, Hapala, Havran 2013): the top-down build is greedy -- a split is chosen by the
+//     areas of ITS two children and never revisited.  Afterwards, nodes whose box is large for what their children need
+//     (inefficiency = area^3 / (mean child area * smallest child area)) are taken out of the tree, two subtrees at a time, and each
+//     subtree is re-inserted where it adds the least area: a branch-and-bound search over "become the sibling of X" for every X,
+//     cost = area(X u subtree) + the growth of X's ancestors.  The sum of node areas / root area -- the expected number of box
+//     tests of a random ray, `sah_cost` -- only goes down.  Works on split-BVH trees as on any other: references are leaves.
+// (2) Which child the fixed-order walk enters first (`child_order`), decided from the final boxes, and the nodes laid out in
+//     depth-first pre-order of that choice.
+class Restructure {
+public:
+    Restructure(const std::vector<BuildNode>& pre, const Options& o) : opt(o)
+    {
+        const uint32_t n = (uint32_t)pre.size();
+        t.resize(n);
+        for (uint32_t i = 0; i < n; i++) { t[i].box = pre[i].box; t[i].prim = pre[i].prim; t[i].parent = -1; t[i].left = t[i].right = -1; t[i].leaves = 1; }
+        for (uint32_t i = 0; i < n; i++) {
+            if (pre[i].prim >= 0) continue;
+            const uint32_t a = i + 1, b = pre[a].end;
+            t[i].left = (int32_t)a; t[i].right = (int32_t)b; t[a].parent = (int32_t)i; t[b].parent = (int32_t)i;
+        }
+        root = 0;
+    }
+
+    double area_sum() const
+    {
+        double s = 0;
+        for (const X& x : t) s += (double)x.box.half_area();
+        return s;
+    }
+
+    // returns the number of re-insertions that were kept
+    uint64_t optimise(int iterations, float batch_fraction)
+    {
+        const uint32_t n = (uint32_t)t.size();
+        if (n < 16 || iterations <= 0) return 0;
+        uint64_t moved = 0;
+        std::vector<std::pair<float, int32_t>> cand;
+        uint64_t rng = 0x9e3779b97f4a7c15ull;
+        double last = area_sum();
+        for (int it = 0; it < iterations; it++) {
+            cand.clear();
+            const bool random_round = (it % 4) == 3;       // every fourth round: a random sample (the metric alone keeps picking the same nodes)
+            for (uint32_t i = 0; i < n; i++) {
+                const X& x = t[i];
+                if (x.left < 0 || (int32_t)i == root || x.parent == root) continue;
+                float key;
+                if (random_round) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; key = (float)(rng >> 40); }
+                else {
+                    const float a = x.box.half_area(), al = t[x.left].box.half_area(), ar = t[x.right].box.half_area();
+                    key = a * (a / std::max(0.5f * (al + ar), 1e-30f)) * (a / std::max(std::min(al, ar), 1e-30f));
+                }
+                cand.emplace_back(key, (int32_t)i);
+            }
+            size_t k = std::max<size_t>(1, (size_t)((double)cand.size() * batch_fraction));
+            if (k > cand.size()) k = cand.size();
+            std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), [](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) {
+                return a.first > b.first || (a.first == b.first && a.second < b.second);
+            });
+            for (size_t c = 0; c < k; c++) moved += reinsert_children_of(cand[c].second);
+            // stop when a whole cycle (three rounds by the metric, one random) gained less than 0.02 %
+            if ((it % 4) == 3) {
+                const double now = area_sum();
+                if (last - now < 2e-4 * last) break;
+                last = now;
+            }
+        }
+        return moved;
+    }
+
+    // pre-order emission with the child-order rule
+    std::vector<BuildNode> emit()
+    {
+        count_leaves();
+        std::vector<BuildNode> out;
+        out.reserve(t.size());
+        std::vector<int32_t> stack;
+        std::vector<uint32_t> new_of(t.size(), 0), size_of(t.size(), 1);
+        // subtree sizes, bottom-up by an explicit post-order
+        {
+            std::vector<int32_t> order; order.reserve(t.size());
+            stack.push_back(root);
+            while (!stack.empty()) { const int32_t i = stack.back(); stack.pop_back(); order.push_back(i); if (t[i].left >= 0) { stack.push_back(t[i].left); stack.push_back(t[i].right); } }
+            for (size_t k = order.size(); k-- > 0;) { const int32_t i = order[k]; if (t[i].left >= 0) size_of[i] = 1 + size_of[t[i].left] + size_of[t[i].right]; }
+        }
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const int32_t i = stack.back(); stack.pop_back();
+            BuildNode bn; bn.box = t[i].box; bn.prim = t[i].prim; bn.end = (uint32_t)out.size() + size_of[i];
+            out.push_back(bn);
+            if (t[i].left >= 0) {
+                int32_t a = t[i].left, b = t[i].right;
+                if (right_first(t[a].box, t[a].leaves, t[b].box, t[b].leaves)) std::swap(a, b);
+                stack.push_back(b); stack.push_back(a);
+            }
+        }
+        return out;
+    }
+
+private:
+    struct X { Box box; int32_t parent, left, right, prim; uint32_t leaves; };
+    struct Item { float induced; int32_t node; };
+    mutable std::vector<Item> heap_;
+    std::vector<X> t;
+    int32_t root = 0;
+    Options opt;
+
+    void count_leaves()
+    {
+        std::vector<int32_t> order, stack;
+        stack.push_back(root);
+        while (!stack.empty()) { const int32_t i = stack.back(); stack.pop_back(); order.push_back(i); if (t[i].left >= 0) { stack.push_back(t[i].left); stack.push_back(t[i].right); } }
+        for (size_t k = order.size(); k-- > 0;) { const int32_t i = order[k]; t[i].leaves = t[i].left >= 0 ? t[t[i].left].leaves + t[t[i].right].leaves : 1u; }
+    }
+
+    bool right_first(const Box& lb, uint32_t ln, const Box& rb, uint32_t rn) const
+    {
+        switch (opt.child_order) {
+        case ATNS_ORDER_AREA: return rb.half_area() > lb.half_area();
+        case ATNS_ORDER_AREA_SMALL: return rb.half_area() < lb.half_area();
+        case ATNS_ORDER_COUNT: return rn > ln;
+        case ATNS_ORDER_COUNT_SMALL: return rn < ln;
+        case ATNS_ORDER_NEAR_POINT: {
+            float dl = 0, dr = 0;
+            for (int k = 0; k < 3; k++) {
+                const float p = opt.order_point[k];
+                const float a = std::max(std::max(lb.mn[k] - p, p - lb.mx[k]), 0.f);
+                const float b = std::max(std::max(rb.mn[k] - p, p - rb.mx[k]), 0.f);
+                dl += a * a; dr += b * b;
+            }
+            if (dl != dr) return dr < dl;
+            float cl = 0, cr = 0;
+            for (int k = 0; k < 3; k++) {
+                const float a = lb.centre(k) - opt.order_point[k], b = rb.centre(k) - opt.order_point[k];
+                cl += a * a; cr += b * b;
+            }
+            return cr < cl;
+        }
+        default: return false;      // ATNS_ORDER_AS_SPLIT: as built
+        }
+    }
+
+    double delta_ = 0;      // area added to the tree by the operation in progress (sum over the boxes it changed)
+    void refit_from(int32_t i)
+    {
+        while (i >= 0) {
+            Box u = t[t[i].left].box; u.grow(t[t[i].right].box);
+            const float before = t[i].box.half_area(), after = u.half_area();
+            const bool same = std::memcmp(&u, &t[i].box, sizeof(Box)) == 0;
+            t[i].box = u;
+            if (same) break;        // nothing above changes either
+            delta_ += (double)after - (double)before;
+            i = t[i].parent;
+        }
+    }
+
+    // the node X next to which the detached subtree `sub` costs the least: area(X u sub) + growth of X's ancestors
+    int32_t best_sibling(const Box& sub) const
+    {
+        auto worse = [](const Item& a, const Item& b) { return a.induced > b.induced; };
+        std::vector<Item>& heap = heap_;
+        heap.clear();
+        heap.push_back(Item{ 0.f, root });
+        const float sub_area = sub.half_area();
+        float best = kInf; int32_t best_node = root;
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            const Item it = heap.back(); heap.pop_back();
+            if (it.induced + sub_area >= best) break;           // every remaining candidate costs at least this much
+            const X& x = t[it.node];
+            Box u = x.box; u.grow(sub);
+            const float direct = u.half_area();
+            const float total = it.induced + direct;
+            if (total < best) { best = total; best_node = it.node; }
+            const float below = total - x.box.half_area();      // what the children inherit: this node grows to u
+            if (x.left >= 0 && below + sub_area < best) {
+                heap.push_back(Item{ below, x.left }); std::push_heap(heap.begin(), heap.end(), worse);
+                heap.push_back(Item{ below, x.right }); std::push_heap(heap.begin(), heap.end(), worse);
+            }
+        }
+        return best_node;
+    }
+
+    // `sub` (detached, parent = -1) becomes the sibling of x under the free node `fresh`
+    void attach(int32_t sub, int32_t x, int32_t fresh)
+    {
+        const int32_t p = t[x].parent;
+        t[fresh].left = x; t[fresh].right = sub; t[fresh].parent = p; t[fresh].prim = -1;
+        if (p >= 0) { if (t[p].left == x) t[p].left = fresh; else t[p].right = fresh; }
+        else root = fresh;
+        t[x].parent = fresh; t[sub].parent = fresh;
+        // the fresh node's box is whatever it held in its previous place: set it here (an "unchanged" box must not stop the
+        // refit below it -- its NEW parent has not seen `sub` yet), then refit upwards
+        Box u = t[x].box; u.grow(t[sub].box);
+        delta_ += (double)u.half_area() - (double)t[fresh].box.half_area();
+        t[fresh].box = u;
+        refit_from(p);
+    }
+
+    // the inverse of attach: `sub`'s sibling takes the place of their parent, which is free again
+    void detach(int32_t sub)
+    {
+        const int32_t f = t[sub].parent;
+        const int32_t x = t[f].left == sub ? t[f].right : t[f].left;
+        const int32_t gp = t[f].parent;
+        if (gp >= 0) { if (t[gp].left == f) t[gp].left = x; else t[gp].right = x; }
+        else root = x;
+        t[x].parent = gp;
+        t[sub].parent = -1;
+        refit_from(gp);
+    }
+
+    // take node n and its parent out of the tree, re-insert n's two children one by one where each adds the least area;
+    // 1 if the tree got cheaper -- else the operation is undone (two greedy insertions need not beat what was there)
+    uint64_t reinsert_children_of(int32_t n)
+    {
+        if (t[n].left < 0 || n == root) return 0;
+        const int32_t p = t[n].parent;
+        if (p < 0 || p == root) return 0;
+        const int32_t g = t[p].parent;
+        const int32_t s = t[p].left == n ? t[p].right : t[p].left;
+        const int32_t l0 = t[n].left, r0 = t[n].right;
+        const bool n_was_left = t[p].left == n, p_was_left = t[g].left == p;
+        const Box box_n = t[n].box, box_p = t[p].box;
+        delta_ = 0;
+        // detach: the sibling takes the parent's place
+        if (p_was_left) t[g].left = s; else t[g].right = s;
+        t[s].parent = g;
+        refit_from(g);
+        t[l0].parent = -1; t[r0].parent = -1;
+        int32_t l = l0, r = r0;
+        if (t[r].box.half_area() > t[l].box.half_area()) std::swap(l, r);      // the larger one first
+        attach(l, best_sibling(t[l].box), p);
+        attach(r, best_sibling(t[r].box), n);
+        if (delta_ < 0) return 1;
+        // undo: both out again (the tree is then exactly what it was after the first detach), then the old arrangement
+        detach(r); detach(l);
+        t[n].left = l0; t[n].right = r0; t[n].parent = p; t[l0].parent = n; t[r0].parent = n; t[n].box = box_n;
+        t[p].left = n_was_left ? n : s; t[p].right = n_was_left ? s : n; t[p].parent = g; t[p].box = box_p;
+        const int32_t gs = t[s].parent;     // == g
+        if (t[gs].left == s) t[gs].left = p; else t[gs].right = p;
+        t[s].parent = p;
+        refit_from(g);
+        return 0;
+    }
+};
 
 atn_bvh_node* emit(const std::vector<BuildNode>& bn)
 {
@@ -450,6 +670,8 @@ Options options_from(const atns_bvh_options* o)
     if (o->sweep_below >= 0) r.sweep_below = (uint32_t)o->sweep_below;
     if (o->child_order >= 0 && o->child_order <= ATNS_ORDER_NEAR_POINT) r.child_order = o->child_order;
     r.order_point_given = o->order_point_given != 0;
+    if (o->reinsert_iterations >= 0) r.reinsert_iterations = std::min(o->reinsert_iterations, 1000);
+    if (o->reinsert_batch > 0.f && o->reinsert_batch <= 1.f) r.reinsert_batch = o->reinsert_batch;
     if (o->max_refs_factor >= 1.f) r.max_refs_factor = o->max_refs_factor;
     for (int k = 0; k < 3; k++) r.order_point[k] = o->order_point[k];
     return r;
@@ -490,6 +712,12 @@ int build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris, const ui
     }
     Builder b(opt, geo.data());
     b.run(refs);
+    uint64_t moved = 0;
+    {
+        Restructure rs(b.nodes, opt);
+        moved = rs.optimise(opt.reinsert_iterations, opt.reinsert_batch);
+        b.nodes = rs.emit();
+    }
     atn_bvh_node* nodes = emit(b.nodes);
     if (!nodes) return -3;
     for (size_t i = 0; i < b.nodes.size(); i++) {
@@ -509,6 +737,7 @@ int build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris, const ui
         stats->n_nodes = (uint32_t)b.nodes.size();
         stats->n_leaves = (uint32_t)b.n_refs_out;
         stats->n_spatial_splits = (uint32_t)b.n_spatial;
+        stats->n_reinsertions = (uint32_t)std::min<uint64_t>(moved, 0xffffffffu);
         double sah = 0;
         const double ra = std::max((double)b.nodes[0].box.half_area(), 1e-30);
         for (const BuildNode& nd : b.nodes) sah += (double)nd.box.half_area() / ra;
@@ -536,6 +765,8 @@ void atns_bvh_default_options(atns_bvh_options* o)
     o->max_refs_factor = d.max_refs_factor;
     for (int k = 0; k < 3; k++) o->order_point[k] = d.order_point[k];
     o->order_point_given = d.order_point_given ? 1 : 0;
+    o->reinsert_iterations = d.reinsert_iterations;
+    o->reinsert_batch = d.reinsert_batch;
 }
 
 int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
@@ -578,6 +809,11 @@ int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t
         for (int k = 0; k < 3; k++) o.order_point[k] = all.centre(k);
         Builder b(o, nullptr);
         b.run(refs);
+        {
+            Restructure rs(b.nodes, o);
+            rs.optimise(o.reinsert_iterations, o.reinsert_batch);
+            b.nodes = rs.emit();
+        }
         atn_bvh_node* nodes = emit(b.nodes);
         if (!nodes) return -3;
         for (size_t i = 0; i < b.nodes.size(); i++) {

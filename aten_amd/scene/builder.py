@@ -584,7 +584,7 @@ class SceneBuilder:
                                              bmin, bmax, C.byref(st))
                 if rc != 0:
                     raise RuntimeError("atns_build_blas_opt failed: %d" % rc)
-                bvh_stats[oid] = dict(nodes=st.n_nodes, leaves=st.n_leaves, spatial_splits=st.n_spatial_splits, sah=st.sah_cost)
+                bvh_stats[oid] = dict(nodes=st.n_nodes, leaves=st.n_leaves, spatial_splits=st.n_spatial_splits, reinsertions=st.n_reinsertions, sah=st.sah_cost)
                 nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
                 lib.atns_free(out)
                 bmin, bmax = np.asarray(list(bmin), F32), np.asarray(list(bmax), F32)

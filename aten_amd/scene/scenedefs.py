@@ -252,7 +252,7 @@ def _icosphere(level):
     return np.asarray(v, np.float64), np.asarray(f, np.int64)
 
 
-def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
+def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0, bvh_options=None):
     """Procedural colonnaded hall, ~250 k unique triangles (+ 6 instances of a 20 k-triangle statue), Disney
     materials with the Sponza albedo / normal-map textures, IBL + one polygon area light.  Stand-in for
     BASELINE config 4 "Crytek Sponza 4K 8spp 8-bounce Disney + textures" (≈262 k triangles), whose
@@ -260,7 +260,8 @@ def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0):
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
     b = SceneBuilder()
     cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
-    b.bvh_options = dict(order_point=cam["pos"])       # the hall's tree: children nearer the viewer are threaded first
+    # the trees built here: children nearer the viewer are threaded first
+    b.bvh_options = dict(order_point=cam["pos"]) if bvh_options is None else bvh_options
 
     def tex(name):
         return b.load_image(os.path.join(asset_dir, name))

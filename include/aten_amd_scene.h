@@ -53,9 +53,13 @@ typedef struct atns_bvh_options {
     float max_refs_factor;        /* duplication budget: references <= this * triangles (then object splits only) */
     float order_point[3];
     int32_t order_point_given;    /* 0 = ignore order_point, use the centroid */
+    int32_t reinsert_iterations;  /* rounds of the insertion-based optimisation after the build (0 = off): nodes whose box is
+                                     large for what their children need are taken out and their subtrees re-inserted where
+                                     they add the least area */
+    float reinsert_batch;         /* share of the inner nodes a round works on */
 } atns_bvh_options;
 typedef struct atns_bvh_stats {
-    uint32_t n_nodes, n_leaves, n_spatial_splits;
+    uint32_t n_nodes, n_leaves, n_spatial_splits, n_reinsertions;
     float sah_cost;               /* sum over nodes of area(node) / area(root): expected box tests of a random long ray */
 } atns_bvh_stats;
 void atns_bvh_default_options(atns_bvh_options* out);

@@ -71,9 +71,13 @@ def test_split_tree_structure(sponza_mesh):
             assert np.all(nodes["boxmin"][ch] >= nodes["boxmin"][i]) and np.all(nodes["boxmax"][ch] <= nodes["boxmax"][i])
     assert np.allclose(bmin, pos[:, :3][tris["idx"]].reshape(-1, 3).min(0)) and np.allclose(bmax, pos[:, :3][tris["idx"]].reshape(-1, 3).max(0))
 
-    plain, st0, _, _ = _build(pos, tris, ids, spatial_splits=0)
+    # the insertion-based optimisation after the build only ever lowers the sum of node areas, and keeps all of the above
+    raw, st_raw, _, _ = _build(pos, tris, ids, reinsert_iterations=0)
+    assert st_raw.n_reinsertions == 0 and st.n_reinsertions > 1000 and len(raw) == cnt
+    assert st.sah_cost < 0.97 * st_raw.sah_cost
+    plain, st0, _, _ = _build(pos, tris, ids, spatial_splits=0, reinsert_iterations=0)
     assert len(plain) == 2 * n - 1 and st0.n_spatial_splits == 0
-    assert st.sah_cost < 0.9 * st0.sah_cost                             # what the spatial splits are for
+    assert st_raw.sah_cost < 0.9 * st0.sah_cost                         # what the spatial splits are for (both without re-insertion)
     capped, st1, _, _ = _build(pos, tris, ids, max_refs_factor=1.1)
     assert (capped["f0"] >= 0).sum() <= 1.1 * n + 64
 
@@ -121,7 +125,7 @@ def test_own_tree_costs_no_more_than_the_reference_tree(orc):
     vr, tr, rays_r = _visits(orc, ref, cam, w, h)
     vo, to, rays_o = _visits(orc, own, cam, w, h)
     assert rays_r == rays_o
-    assert vo <= 1.0 * vr and to <= 1.0 * tr, (vo / vr, to / tr)
+    assert vo <= 0.95 * vr and to <= 0.95 * tr, (vo / vr, to / tr)
     # without the viewer hint (children ordered towards the mesh's centroid) and from another place in the building
     nohint, _ = scenedefs.sponza_lod(use_sbvh=False, bvh_options={})
     for scene_cam in (cam, dict(pos=(-4.0, 0.6, -0.5), at=(1.0, 2.0, 0.2), vfov=60.0)):

@@ -21,7 +21,7 @@ SYMBOLS = [
     "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
     "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_stream", "atn_synchronize",
     "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_kernel_times",
-    "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples", "atn_cmj_batch", "atn_get_random", "atn_random_count",
+    "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples", "atn_cmj_batch", "atn_ray_offset", "atn_get_random", "atn_random_count",
     "atn_material_table", "atn_material_eval", "atn_compact", "atn_compact2", "atn_sizeof_scene_desc", "atn_sizeof_destination",
     "atn_abi_version", "atn_build_id",
     "atn_download_path_cost", "atn_update_geometry", "atn_scene_device_arrays", "atn_lbvh_rebuild_list", "atn_lbvh_build",
@@ -103,6 +103,7 @@ def lib():
         l.atn_trace_closest.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, vp, vp]
         l.atn_cmj_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
         l.atn_cmj_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_int32, vp]
+        l.atn_ray_offset.argtypes = [vp, C.c_uint32, vp, vp, vp]
         l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.atn_material_eval.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp]
         l.atn_compact.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]

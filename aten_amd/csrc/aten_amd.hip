@@ -2208,6 +2208,23 @@ int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_
     return ATN_OK;
 }
 
+int atn_ray_offset(atn_ctx* ctx, uint32_t n, const float* origins, const float* normals, float* out_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (n == 0 || !origins || !normals || !out_host) return r.fail(ATN_ERR_INVALID_ARG, "bad ray offset batch");
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<float> o, nm, out;
+    C_HIP(r, o.resize(3 * (size_t)n)); C_HIP(r, nm.resize(3 * (size_t)n)); C_HIP(r, out.resize(3 * (size_t)n));
+    C_HIP(r, hipMemcpyAsync(o.p, origins, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(nm.p, normals, 12 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    hipLaunchKernelGGL(atn::k_ray_offset, dim3((n + 255) / 256), dim3(256), 0, r.stream, n, (const float*)o.p, (const float*)nm.p, out.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, 12 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
                        const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval)

@@ -928,6 +928,14 @@ __global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim
     }
 }
 
+__global__ void __launch_bounds__(256) k_ray_offset(uint32_t n, const float* __restrict__ o, const float* __restrict__ nrm, float* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const f3 r = ray_offset(mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]), mk3(nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2]));
+    out[3 * k] = r.x; out[3 * k + 1] = r.y; out[3 * k + 2] = r.z;
+}
+
 // one thread per (index, dimension, scramble) triple: `draws` successive nextSample()
 __global__ void __launch_bounds__(256) k_cmj_batch(uint32_t n, const uint32_t* __restrict__ index, const uint32_t* __restrict__ dim,
                                                    const uint32_t* __restrict__ scramble, int draws, float* __restrict__ out)

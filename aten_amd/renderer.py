@@ -286,6 +286,12 @@ class PathTracing:
                                           scramble.ctypes.data, draws, out.ctypes.data))
         return out
 
+    def ray_offset(self, origins, normals):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3); n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        out = np.zeros_like(o)
+        self._check(self._l.atn_ray_offset(self._ctx, len(o), o.ctypes.data, n.ctypes.data, out.ctypes.data))
+        return out
+
     def material_table(self, mtrl_id, nrm, wi, index, scramble, uv, dimension=None):
         n = len(nrm)
         dim = np.ascontiguousarray(np.broadcast_to(np.asarray(dimension, np.uint32), (n,))) if dimension is not None else None

@@ -301,6 +301,19 @@ def run_workload(args, cfg, ctx):
     for _ in range(repeats):
         r.reset()
         region_s.append(timed(steps))
+    # --repeats 0 ... no: a SHORT region (the driver's 20 steps are 70 ms) is repeated until the timed regions add up to
+    # `--min-timed-seconds` of GPU work (default 2 s, at most 64 repeats): a steadier median, and a GPU that an outside
+    # sampler can see busy.  Every rank takes the same decision (the first region's duration is the max over ranks).
+    if args.min_timed_seconds > 0 and region_s[0] > 0:
+        want = int(min(64, np.ceil(args.min_timed_seconds / max(region_s[0], 1e-6))))
+        if use_dist:
+            tw = torch.tensor([want], dtype=torch.int64, device=dev)
+            dist.broadcast(tw, 0)
+            want = int(tw.item())
+        while len(region_s) < want:
+            r.reset()
+            region_s.append(timed(steps))
+        repeats = len(region_s)
     elapsed = float(np.median(region_s))
     host_enqueue_ms = 1e3 * host_enqueue[0] / steps
     # the film the timed frames produced (K progressive frames from a reset film): its hash goes into the line, so that the
@@ -685,7 +698,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the one-rank-per-GPU mode; nccl (= RCCL) is what is measured, gloo lets "
                          "several ranks SHARE a GPU (RCCL refuses that), which is how the tests run a world of two on a 1-GPU box")
-    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is measured this many times; value = the median")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is measured (at least) this many times; value = the median")
+    ap.add_argument("--min-timed-seconds", type=float, default=2.0,
+                    help="repeat the K-step region until the regions add up to this much time (0 = exactly --repeats); at most 64 repeats")
     ap.add_argument("--verify-film", action="store_true",
                     help="after the timed region rank 0 renders the same K frames unsharded and reports film_equals_single_gpu "
                          "(on by default with more than one rank)")

@@ -304,6 +304,9 @@ int atn_cmj_samples(atn_ctx* ctx, uint32_t index, uint32_t dimension, uint32_t s
  * (src/libaten/sampler/cmj.h:21-37); out_host[k * draws + d]. */
 int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble,
                   int32_t draws, float* out_host);
+/* ray::Offset (src/libaten/math/ray.h:26-74: "A Fast and Robust Method for Avoiding Self-Intersection", Ray Tracing Gems ch. 6)
+ * as the kernels compute it for every next ray and shadow ray: n origins (xyz) and normals (xyz) -> n offset origins. */
+int atn_ray_offset(atn_ctx* ctx, uint32_t n, const float* origins, const float* normals, float* out_host);
 /* material::sampleMaterial / samplePDF / sampleBSDF tables (src/libaten/material/material_impl.h:24-206).
  * Case i samples with CMJ::init(index[i], dimension[i], scramble[i]) (dimension == NULL: 0 -- note that CMJ's pattern seed is
  * dimension * scramble, cmj.h:118-123, so the draw of dimension 0 ignores the scramble).

@@ -16,7 +16,7 @@ def run_bench(extra, tmp_path, name):
     dump = str(tmp_path / (name + ".npy"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-companion", "--dump", dump] + extra,
+                        "--no-cpu-baseline", "--no-companion", "--no-own-tree", "--min-timed-seconds", "0", "--dump", dump] + extra,
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
@@ -59,6 +59,8 @@ def test_default_line_carries_roofline_companion_and_cpu_baseline():
               "dtype", "data", "config", "roofline", "cpu_baseline", "companion", "ms_per_frame_latency"):
         assert k in d, k
     assert "sponza_lod" in d["config"]["workload"] and "atrium" in d["companion"]["config"]["workload"]
+    # a 4-step region is ~15 ms: it is repeated until the timed regions add up to ~2 s (at most 64 times)
+    assert d["repeats"] == 64 and len(d["ms_per_step_repeats"]) == 64
     for w in (d, d["companion"]):
         rf = w["roofline"]
         assert rf["bound"] in ("hbm", "l2", "l1", "valu") and rf["avg_launch_ms"] > 0
@@ -96,7 +98,7 @@ def test_ranks_sharing_the_gpu_render_the_single_rank_film(tmp_path, world):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29573 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--repeats", "2", "--dump", dump] + (["--no-cpu-baseline"] if world != 2 else [])
+           "--warmup", "1", "--repeats", "2", "--min-timed-seconds", "0", "--dump", dump] + (["--no-cpu-baseline"] if world != 2 else [])
     # (no --verify-film: with more than one rank it is on by default; the world of two also carries the CPU baseline, which
     #  rank 0 measures while the others wait -- the plain `bench.py --gpus N` line of the driver must be complete)
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)

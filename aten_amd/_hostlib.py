@@ -55,6 +55,9 @@ def hostlib():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(BvhStats)]
         lib.atns_build_blas_opt.restype = C.c_int
+        lib.atns_optimize_nodes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(BvhOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                            C.POINTER(BvhStats)]
+        lib.atns_optimize_nodes.restype = C.c_int
         lib.atns_build_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -677,6 +677,71 @@ Options options_from(const atns_bvh_options* o)
     return r;
 }
 
+// A threaded list somebody else built (an imported .sbvh): the same boxes and leaves, re-arranged by the two post passes.
+int optimise_nodes(const atn_bvh_node* in, uint32_t count, const atns_bvh_options* user, atn_bvh_node** out_nodes, uint32_t* out_count,
+                   atns_bvh_stats* stats)
+{
+    if (!in || !out_nodes || !out_count || count == 0) return -1;
+    // the threaded list as a pre-order array: follow the hit links (every node once), a node's subtree ends where its miss link points
+    // -- or, for a leaf, at the next node
+    std::vector<uint32_t> order; order.reserve(count);
+    std::vector<int32_t> pos_of(count, -1);
+    {
+        int32_t id = 0;
+        while (id >= 0) {
+            if ((uint32_t)id >= count || pos_of[id] >= 0 || order.size() >= count) return -4;      // not a threaded tree
+            pos_of[id] = (int32_t)order.size();
+            order.push_back((uint32_t)id);
+            id = (int32_t)in[id].hit;
+        }
+        if (order.size() != count) return -4;
+    }
+    std::vector<BuildNode> pre(count);
+    for (uint32_t k = 0; k < count; k++) {
+        const atn_bvh_node& n = in[order[k]];
+        for (int a = 0; a < 3; a++) { pre[k].box.mn[a] = n.boxmin[a]; pre[k].box.mx[a] = n.boxmax[a]; }
+        const bool leaf = n.f0 >= 0.f || n.f1 >= 0.f;
+        pre[k].prim = leaf ? (int32_t)k : -1;       // payload = position in `order` (the leaf's four payload floats are copied from there)
+        const int32_t m = (int32_t)n.miss;
+        if (leaf) pre[k].end = k + 1;
+        else {
+            if (m >= (int32_t)count || (m >= 0 && pos_of[m] <= (int32_t)k)) return -4;
+            pre[k].end = m < 0 ? count : (uint32_t)pos_of[m];
+        }
+    }
+    // a binary tree in pre-order: every inner node has exactly two children, the second where the first one's subtree ends
+    for (uint32_t k = 0; k < count; k++) {
+        if (pre[k].prim >= 0) continue;
+        if (k + 1 >= count || pre[k + 1].end >= pre[k].end) return -4;
+        const uint32_t b = pre[k + 1].end;
+        if (pre[b].end != pre[k].end) return -4;
+    }
+    Options opt = options_from(user);
+    if (opt.child_order == ATNS_ORDER_NEAR_POINT && !opt.order_point_given)
+        for (int a = 0; a < 3; a++) opt.order_point[a] = pre[0].box.centre(a);
+    Restructure rs(pre, opt);
+    const uint64_t moved = rs.optimise(opt.reinsert_iterations, opt.reinsert_batch);
+    const std::vector<BuildNode> fin = rs.emit();
+    atn_bvh_node* nodes = emit(fin);
+    if (!nodes) return -3;
+    uint32_t leaves = 0;
+    for (size_t i = 0; i < fin.size(); i++) {
+        if (fin[i].prim < 0) continue;
+        const atn_bvh_node& src = in[order[fin[i].prim]];
+        nodes[i].f0 = src.f0; nodes[i].f1 = src.f1; nodes[i].f2 = src.f2; nodes[i].f3 = src.f3;
+        leaves++;
+    }
+    *out_nodes = nodes; *out_count = (uint32_t)fin.size();
+    if (stats) {
+        stats->n_nodes = (uint32_t)fin.size(); stats->n_leaves = leaves; stats->n_spatial_splits = 0;
+        stats->n_reinsertions = (uint32_t)std::min<uint64_t>(moved, 0xffffffffu);
+        double sah = 0; const double ra = std::max((double)fin[0].box.half_area(), 1e-30);
+        for (const BuildNode& nd : fin) sah += (double)nd.box.half_area() / ra;
+        stats->sah_cost = (float)sah;
+    }
+    return 0;
+}
+
 int build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris, const uint32_t* tri_ids, uint32_t n_tris,
                const atns_bvh_options* user, atn_bvh_node** out_nodes, uint32_t* out_count, float* out_bbox_min, float* out_bbox_max,
                atns_bvh_stats* stats)
@@ -785,6 +850,14 @@ int atns_build_blas_opt(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
                         float out_bbox_min[3], float out_bbox_max[3], atns_bvh_stats* out_stats)
 {
     try { return build_blas(vtx_pos, tris, tri_ids, n_tris, options, out_nodes, out_count, out_bbox_min, out_bbox_max, out_stats); }
+    catch (const std::bad_alloc&) { return -3; }
+    catch (...) { return -5; }
+}
+
+int atns_optimize_nodes(const atn_bvh_node* nodes, uint32_t count, const atns_bvh_options* options,
+                         atn_bvh_node** out_nodes, uint32_t* out_count, atns_bvh_stats* out_stats)
+{
+    try { return optimise_nodes(nodes, count, options, out_nodes, out_count, out_stats); }
     catch (const std::bad_alloc&) { return -3; }
     catch (...) { return -5; }
 }

@@ -438,9 +438,12 @@ class SceneBuilder:
         kw = self.bvh_options if self.bvh_options is not None else DEFAULT_BVH_OPTIONS
         return C.byref(default_bvh_options(**kw)) if kw else None
 
-    def import_sbvh(self, obj_id, path):
-        """PolygonObject::importInternalAccelTree + sbvh::buildAsNestedTree's triangle offset."""
+    def import_sbvh(self, obj_id, path, optimize=False):
+        """PolygonObject::importInternalAccelTree + sbvh::buildAsNestedTree's triangle offset.  optimize: the imported tree goes
+        through the builder's post passes first (atns_optimize_nodes: same boxes and leaves, re-arranged; `bvh_options` apply)."""
         hdr, mtrl_names, nodes = read_sbvh(path)
+        if optimize:
+            nodes = optimize_nodes(nodes, self._bvh_options())
         self.blas[obj_id] = ("imported", nodes, hdr)
 
     def export_sbvh(self, obj_id, path, lib=None):
@@ -679,6 +682,19 @@ class SceneBuilder:
                          vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, textures=[t for _, t in self.textures])
         fs.names = dict(materials=[n for n, _ in self.materials], textures=[n for n, _ in self.textures])
         return fs
+
+
+def optimize_nodes(nodes, options=None):
+    """atns_optimize_nodes on a numpy node array; options: None or ctypes.byref(BvhOptions)."""
+    lib = hostlib()
+    nodes = np.ascontiguousarray(nodes)
+    out = C.c_void_p(); cnt = C.c_uint32(); st = BvhStats()
+    rc = lib.atns_optimize_nodes(nodes.ctypes.data, len(nodes), options, C.byref(out), C.byref(cnt), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("atns_optimize_nodes failed: %d" % rc)
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
+    lib.atns_free(out)
+    return res
 
 
 def _resolve_case(path):

@@ -75,7 +75,7 @@ def envmap_avg_illum(tex):
     return float((lum * s).sum() / (s.sum() * tex.shape[1]))
 
 
-def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True, bvh_options=None):
+def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True, bvh_options=None, optimize_sbvh=False):
     """BASELINE config 3 stand-in: sponza_lod.obj (12,852 tris) with the reference-built
     sponza_lod.sbvh tree, GGX materials, synthetic IBL."""
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
@@ -96,7 +96,7 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
     b.bvh_options = dict(order_point=cam["pos"]) if bvh_options is None else bvh_options
     objs = b.load_obj(os.path.join(asset_dir, "sponza_lod.obj"), create_mtrl=create_mtrl)
     if use_sbvh:
-        b.import_sbvh(objs[0], os.path.join(asset_dir, "sponza_lod.sbvh"))
+        b.import_sbvh(objs[0], os.path.join(asset_dir, "sponza_lod.sbvh"), optimize=optimize_sbvh)
     b.create_instance(objs[0])
     if ibl:
         env = synthetic_envmap()

@@ -202,6 +202,9 @@ def run_workload(args, cfg, ctx):
     elif scene == "sponza_own_tree":
         fs, cam = scenedefs.sponza_lod(use_sbvh=False)
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, tree built by atns_build_blas (split BVH)" % (W, H, spp, depth)
+    elif scene == "sponza_ref_tree_opt":
+        fs, cam = scenedefs.sponza_lod(use_sbvh=True, optimize_sbvh=True)
+        workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh through atns_optimize_nodes" % (W, H, spp, depth)
     elif scene == "atrium":
         fs, cam = scenedefs.atrium()
         workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; synthetic Sponza-class scale-up, stand-in "
@@ -409,7 +412,8 @@ def run_workload(args, cfg, ctx):
     iso_ms = (ktimes_excl[tkey][0] / ktimes_excl[tkey][1]) if ktimes_excl[tkey][1] else avg_launch_ms
     roof_ms = iso_ms if overlapped else avg_launch_ms
     avg_launch_s = max(roof_ms * 1e-3, 1e-12)
-    scene_tag = {"sponza": "sponza_lod", "sponza_own_tree": "sponza_lod own tree", "cornell": "cornell", "atrium": "atrium"}[scene]
+    scene_tag = {"sponza": "sponza_lod", "sponza_own_tree": "sponza_lod own tree", "sponza_ref_tree_opt": "sponza_lod reference tree optimised",
+                 "cornell": "cornell", "atrium": "atrium"}[scene]
     prof, stale, sha = profile_counters(scene_tag, W, H, spp, depth, svgf)
     pk = kernel_entry((prof,), dominant) if prof else None
     # The committed PMC record is of the UNSHARDED launch.  A rank of a world of N traces the rays of every N-th 8x8 tile: its
@@ -666,7 +670,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed frames (default 200: a timed region of ~0.8 s; 20 for the 4K 8-spp config)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="sponza", choices=["sponza", "sponza_own_tree", "cornell", "atrium"])
+    ap.add_argument("--scene", default="sponza", choices=["sponza", "sponza_own_tree", "sponza_ref_tree_opt", "cornell", "atrium"])
     ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config shortcuts: c2 = Cornell 1080p 1spp 5-bounce, c3 = Sponza 1080p 1spp 5-bounce "
                          "(default), c4 = 4K 8spp 8-bounce Disney + textures on the procedural atrium stand-in, "
@@ -774,17 +778,19 @@ def main():
                                           "roofline_bound": comp["roofline"]["bound"], "roofline_frac": comp["roofline"]["frac"],
                                           "cpu_baseline_value": (comp["cpu_baseline"] or {}).get("value")}
     if default_line and not args.no_own_tree:
-        # the same headline frames through the tree of the repo's OWN builder (csrc/host/bvh_builder.cpp) instead of the
-        # reference-built sponza_lod.sbvh: what a caller who ingests the OBJ through atns_* gets
-        ocfg = dict(cfg, scene="sponza_own_tree", dump=None, cpu_baseline=False)
-        own = run_workload(args, ocfg, dict(ctx, use_dist=False))
-        if rank == 0 and own is not None:
-            out["own_tree"] = {k: own[k] for k in ("value", "unit", "ms_per_step", "ms_per_frame_latency", "work_per_frame", "kernel_ms_per_frame_isolated", "film_sha256")}
-            out["own_tree"]["workload"] = own["config"]["workload"]
-            out["own_tree"]["bvh_nodes"] = own["config"]["bvh_nodes"]
-            out["config"]["own_tree"] = {"value": own["value"], "ms_per_step": own["ms_per_step"],
-                                         "node_visits_vs_reference_tree": round((own["work_per_frame"]["closest_nodes"] + own["work_per_frame"]["shadow_nodes"])
-                                                                               / max(out["work_per_frame"]["closest_nodes"] + out["work_per_frame"]["shadow_nodes"], 1), 4)}
+        # the same headline frames through (a) the tree of the repo's OWN builder (csrc/host/bvh_builder.cpp) instead of the
+        # reference-built sponza_lod.sbvh -- what a caller who ingests the OBJ through atns_* gets -- and (b) the reference-built
+        # tree after the builder's post passes (atns_optimize_nodes: same boxes and leaves, re-arranged and re-threaded)
+        ref_visits = max(out["work_per_frame"]["closest_nodes"] + out["work_per_frame"]["shadow_nodes"], 1) if rank == 0 else 1
+        for key, sc in (("own_tree", "sponza_own_tree"), ("reference_tree_optimized", "sponza_ref_tree_opt")):
+            ocfg = dict(cfg, scene=sc, dump=None, cpu_baseline=False)
+            own = run_workload(args, ocfg, dict(ctx, use_dist=False))
+            if rank == 0 and own is not None:
+                out[key] = {k: own[k] for k in ("value", "unit", "ms_per_step", "ms_per_frame_latency", "work_per_frame", "kernel_ms_per_frame_isolated", "film_sha256")}
+                out[key]["workload"] = own["config"]["workload"]
+                out[key]["bvh_nodes"] = own["config"]["bvh_nodes"]
+                out["config"][key] = {"value": own["value"], "ms_per_step": own["ms_per_step"],
+                                      "node_visits_vs_reference_tree": round((own["work_per_frame"]["closest_nodes"] + own["work_per_frame"]["shadow_nodes"]) / ref_visits, 4)}
     if rank == 0 and out is not None:
         parts = ["%s: %.1f Mrays/s, %.3f ms/frame, roofline %s %s" % (out["config"]["workload"][:40], out["value"], out["ms_per_step"], out["roofline"]["bound"], out["roofline"]["frac"])]
         if "companion" in out:
@@ -792,6 +798,8 @@ def main():
             parts.append("companion atrium: %.1f Mrays/s, %.3f ms/frame, roofline %s %s" % (c["value"], c["ms_per_step"], c["roofline"]["bound"], c["roofline"]["frac"]))
         if "own_tree" in out:
             parts.append("own-tree sponza_lod: %.1f Mrays/s, %.3f ms/frame" % (out["own_tree"]["value"], out["own_tree"]["ms_per_step"]))
+        if "reference_tree_optimized" in out:
+            parts.append("reference tree through atns_optimize_nodes: %.1f Mrays/s, %.3f ms/frame" % (out["reference_tree_optimized"]["value"], out["reference_tree_optimized"]["ms_per_step"]))
         out["summary"] = "; ".join(parts)        # last key: survives a reader that keeps only the tail of the line
         print("[bench] " + out["summary"], file=sys.stderr, flush=True)
 

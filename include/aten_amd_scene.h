@@ -69,6 +69,14 @@ int atns_build_blas_opt(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
                         atn_bvh_node** out_nodes, uint32_t* out_count,
                         float out_bbox_min[3], float out_bbox_max[3], atns_bvh_stats* out_stats);
 
+/* The two post passes of the builder -- insertion-based optimisation, then the child order -- on a threaded list somebody else
+ * built (a bottom-level tree imported from a reference-written .sbvh): the same boxes and the same leaves (their four payload
+ * floats are carried over; the voxel-LOD payload of inner nodes, never read on this path, is dropped), re-arranged and
+ * re-threaded in depth-first pre-order.  options: child_order / order_point / reinsert_* are used (NULL = defaults; without
+ * order_point the middle of the root box).  Returns 0, -1 (null / empty), -3 (memory), -4 (`nodes` is not a threaded binary tree). */
+int atns_optimize_nodes(const atn_bvh_node* nodes, uint32_t count, const atns_bvh_options* options,
+                        atn_bvh_node** out_nodes, uint32_t* out_count, atns_bvh_stats* out_stats);
+
 /* Top-level tree over instances.  boxes: n * {min.xyz, max.xyz} (world space, already
  * transformed like aabb::transform in threaded_bvh.cpp:203-204); object_ids: transformable index
  * of each instance; blas_list_ids: index of the instance's node list (>= 1), or -1 for "no

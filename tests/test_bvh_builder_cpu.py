@@ -219,3 +219,36 @@ def test_builder_on_hostile_meshes(orc, name):
     assert (hit == (want < np.finfo(np.float32).max)).mean() >= floor
     if n >= 20:
         assert hit.mean() > 0.3
+
+
+def test_post_passes_on_an_imported_tree(orc):
+    """atns_optimize_nodes on the reference-written sponza_lod.sbvh: the same leaves (payload floats carried over) and the same
+    hits, a valid pre-order threaded list, fewer node visits than the file's own arrangement; lists that are not threaded binary
+    trees are refused."""
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.builder import read_sbvh, optimize_nodes
+    from aten_amd._hostlib import hostlib, default_bvh_options
+    hdr, _, nodes = read_sbvh(os.path.join(ROOT, "assets", "sponza", "sponza_lod.sbvh"))
+    out = optimize_nodes(nodes, C.byref(default_bvh_options(order_point=(0.0, 1.0, 3.0))))
+    n = len(nodes)
+    assert len(out) == n and hostlib().atns_validate_nodes(out.ctypes.data, n) == 19000
+    leaf_in, leaf_out = nodes["f0"] >= 0, out["f0"] >= 0
+    key = lambda a, m: sorted(map(tuple, np.stack([a["f1"][m], a["boxmin"][m][:, 0], a["boxmax"][m][:, 2]], 1).tolist()))
+    assert key(nodes, leaf_in) == key(out, leaf_out)                       # the same references: triangle id and box
+    idx = np.arange(n)
+    assert np.all(out["hit"][~leaf_out] == idx[~leaf_out] + 1)             # pre-order
+    assert np.all(out["f2"][~leaf_out] == -1.0)                            # voxel payload of inner nodes dropped
+    assert np.allclose(out["boxmin"][0], nodes["boxmin"][0]) and np.allclose(out["boxmax"][0], nodes["boxmax"][0])
+    ref, cam = scenedefs.sponza_lod(use_sbvh=True)
+    opt, _ = scenedefs.sponza_lod(use_sbvh=True, optimize_sbvh=True)
+    vr, tr, rays_r = _visits(orc, ref, cam, 160, 90)
+    vo, to, rays_o = _visits(orc, opt, cam, 160, 90)
+    assert rays_r == rays_o and vo <= 0.96 * vr and to <= tr, (vo / vr, to / tr)
+    # not a tree: a link that points backwards / a cycle / an inner node without a second child
+    lib = hostlib()
+    bad = nodes.copy(); bad["hit"][5] = 2.0
+    o = C.c_void_p(); c = C.c_uint32()
+    assert lib.atns_optimize_nodes(bad.ctypes.data, n, None, C.byref(o), C.byref(c), None) == -4
+    bad = nodes.copy(); bad["miss"][0] = 1.0
+    assert lib.atns_optimize_nodes(bad.ctypes.data, n, None, C.byref(o), C.byref(c), None) == -4
+    assert lib.atns_optimize_nodes(None, n, None, C.byref(o), C.byref(c), None) == -1

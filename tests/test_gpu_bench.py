@@ -79,7 +79,10 @@ def test_default_line_carries_roofline_companion_and_cpu_baseline():
     assert cc["value"] == d["companion"]["value"] and cc["ms_per_step"] == d["companion"]["ms_per_step"] and "roofline_frac" in cc
     ot = d["own_tree"]
     assert "atns_build_blas" in ot["workload"] and ot["value"] > 0
-    assert 0.8 < d["config"]["own_tree"]["node_visits_vs_reference_tree"] < 1.05
+    assert 0.8 < d["config"]["own_tree"]["node_visits_vs_reference_tree"] < 1.0
+    ro = d["reference_tree_optimized"]
+    assert "atns_optimize_nodes" in ro["workload"] and ro["bvh_nodes"] == d["config"]["bvh_nodes"]
+    assert 0.8 < d["config"]["reference_tree_optimized"]["node_visits_vs_reference_tree"] < 1.0
     assert list(d)[-1] == "summary" and "companion atrium" in d["summary"] and "own-tree" in d["summary"]
     assert "[bench] " + d["summary"] in p.stderr.decode()
 

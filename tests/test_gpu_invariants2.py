@@ -7,7 +7,8 @@
   * next-event estimation with a punctual light, alone and next to the polygon lamp (light pick probability, `dist2 = 1` for singular
     lights, the light's own 1 / d^2: pointlight.h:40-58, pathtracing_nee_impl.h:23-95): closed forms;
   * Russian roulette (pathtracing_impl.h:680-698): switching it on changes every path after the third bounce and must not change
-    the image's expectation;
+    the image's expectation -- where there is no listed light; with one, the reference loses the light sample of the vertex at
+    which roulette ends the path (pathtracing_impl.h:362), a deviation pinned by its measured size;
   * normal maps (material_impl.h:208-230): a map that encodes "no perturbation" leaves the image where it was.
 """
 import numpy as np
@@ -143,15 +144,9 @@ def test_point_light_next_to_the_polygon_lamp(gpu):
     assert np.all(np.abs(got - unbiased) > 0.01 * unbiased)                      # ... and the product has it, like the reference
 
 
-# ---------------------------------------------------------------------------------------------- Russian roulette keeps the expectation
-def test_russian_roulette_does_not_change_the_expectation(gpu):
-    """Cornell box, 5 bounces: with rr_depth = 1 every path is subject to roulette from its third segment on (survival probability
-    max3(throughput), survivors divided by it), with rr_depth = 5 none is.  1 024 frames of 48 x 48 each way: the image means agree
-    within 1.5 % (their Monte-Carlo error is ~0.3 %), and so do the means of its left, middle and right thirds."""
-    from aten_amd.scene import scenedefs
+# ---------------------------------------------------------------------------------------------- Russian roulette and the expectation
+def _rr_means(gpu, fs, cam, W, H, frames):
     from aten_amd.scene.camera import create_camera
-    fs, cam = scenedefs.cornell_box()
-    W = H = 48
     gpu.UpdateSceneData(fs)
     gpu.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], W, H))
     gpu.initSampler(W, H, 0)
@@ -159,16 +154,43 @@ def test_russian_roulette_does_not_change_the_expectation(gpu):
     means = {}
     for rr in (1, 5):
         gpu.reset()
-        for f in range(1024):
-            img = gpu.render(W, H, 5, rr, frame=f, progressive=True, download=(f == 1023))
-        assert np.all(img[..., 3] == 1024)
+        for f in range(frames):
+            img = gpu.render(W, H, 5, rr, frame=f, progressive=True, download=(f == frames - 1))
+        assert np.all(img[..., 3] == frames)
         means[rr] = img[..., :3].astype(np.float64)
-    a, b = means[1], means[5]
+    return means[1], means[5]
+
+
+def test_russian_roulette_keeps_the_expectation_without_listed_lights(gpu):
+    """sponza_lod, all Lambert, lit by a constant background only (no entry in the light list: next-event estimation has nothing to
+    sample), 5 bounces: with rr_depth = 1 every path is subject to roulette from its third segment on (survival probability
+    max3(throughput), survivors divided by it: pathtracing_impl.h:680-698, :735), with rr_depth = 5 none is.  1 024 frames of 64 x 36
+    each way: the image means agree within 1.5 % (their Monte-Carlo error is ~0.3 %), and so do the means of the image's thirds."""
+    from aten_amd.scene import scenedefs
+    fs, cam = scenedefs.sponza_lod(ibl=False, mtype=L.MTRL_DIFFUSE)
+    a, b = _rr_means(gpu, fs, cam, 64, 36, 1024)
     assert abs(a.mean() - b.mean()) <= 0.015 * b.mean(), (a.mean(), b.mean())
-    for s in (slice(0, 16), slice(16, 32), slice(32, 48)):
-        assert abs(a[:, s].mean() - b[:, s].mean()) <= 0.03 * b[:, s].mean()
+    for s in (slice(0, 21), slice(21, 42), slice(42, 64)):
+        assert abs(a[:, s].mean() - b[:, s].mean()) <= 0.025 * b[:, s].mean(), (s, a[:, s].mean(), b[:, s].mean())
     # and roulette really ran: the two accumulations are different images
-    assert np.abs(a - b).max() > 1e-3
+    assert np.abs(a - b).max() > 1e-3 * b.mean()
+
+
+def test_russian_roulette_drops_the_vertex_light_sample_like_the_reference(gpu):
+    """With a listed light the reference's roulette is NOT expectation-preserving, and the product has to have the same deviation:
+    the vertex's shadow ray is filled BEFORE ComputeRussianProbability sets is_terminated (pathtracing.cpp:200-216,
+    pathtracing_impl.cu:193-214), and HitShadowRay returns at once for a terminated path (pathtracing_impl.h:362-364) -- so the light
+    sample of the vertex at which roulette ends a path is lost with probability 1 - max3(throughput) and nothing makes up for it.
+    Cornell box, 5 bounces, 1 024 frames of 48 x 48: rr_depth = 1 comes out ~2 % darker than rr_depth = 5 overall and ~9 % darker in
+    the thirds next to the red and green walls (max3 of the albedo 0.50 / 0.36: low survival), hardly at all in the middle (white
+    and the specular box: 0.58 / 0.7); pinned as intervals around the measured 0.981 / 0.908 / 0.992 / 0.916."""
+    from aten_amd.scene import scenedefs
+    fs, cam = scenedefs.cornell_box()
+    a, b = _rr_means(gpu, fs, cam, 48, 48, 1024)
+    r = a.mean() / b.mean()
+    assert 0.970 <= r <= 0.990, r
+    left, mid, right = (a[:, s].mean() / b[:, s].mean() for s in (slice(0, 16), slice(16, 32), slice(32, 48)))
+    assert 0.88 <= left <= 0.935 and 0.89 <= right <= 0.94 and 0.975 <= mid <= 1.005, (left, mid, right)
 
 
 # ---------------------------------------------------------------------------------------------- a flat normal map changes nothing

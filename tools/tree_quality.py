@@ -69,8 +69,12 @@ if __name__ == "__main__":
         s_own, _ = scenedefs.sponza_lod(use_sbvh=False)
         a, ap = report("reference sponza_lod.sbvh", s_ref, cam, w, h)
         b, bp = report("own builder", s_own, cam, w, h)
+        s_opt, _ = scenedefs.sponza_lod(use_sbvh=True, optimize_sbvh=True)
+        c, cp = report("reference tree, post passes", s_opt, cam, w, h)
         print("ratio own/ref: visits %.3f  primary %.3f  tri tests %.3f" % (b["nodes"] / a["nodes"], bp["nodes"] / ap["nodes"],
                                                                          b["tris"] / a["tris"]))
+        print("ratio (reference tree through atns_optimize_nodes)/ref: visits %.3f  primary %.3f  tri tests %.3f" % (
+            c["nodes"] / a["nodes"], cp["nodes"] / ap["nodes"], c["tris"] / a["tris"]))
     elif which == "lbvh":
         b, oid, cam = scenedefs.deformable_room(0.7)
         lbvh_vs_sah("deformable room blob", b.build(), oid, cam, w, h)

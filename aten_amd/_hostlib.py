@@ -6,7 +6,7 @@ from . import build
 
 _lib = None
 
-ATNS_ABI_VERSION = 3        # include/aten_amd_scene.h
+ATNS_ABI_VERSION = 2        # include/aten_amd_scene.h
 
 ORDER_AS_SPLIT, ORDER_AREA, ORDER_AREA_SMALL, ORDER_COUNT, ORDER_COUNT_SMALL, ORDER_NEAR_POINT = range(6)
 
@@ -15,8 +15,7 @@ class BvhOptions(C.Structure):          # atns_bvh_options
     _fields_ = [("spatial_splits", C.c_int32), ("spatial_alpha", C.c_float), ("object_bins", C.c_int32),
                 ("spatial_bins", C.c_int32), ("sweep_below", C.c_int32), ("child_order", C.c_int32),
                 ("max_refs_factor", C.c_float), ("order_point", C.c_float * 3),
-                ("order_point_given", C.c_int32), ("reinsert_iterations", C.c_int32), ("reinsert_batch", C.c_float),
-                ("direction_axes", C.c_int32), ("direction_tolerance", C.c_float)]
+                ("order_point_given", C.c_int32), ("reinsert_iterations", C.c_int32), ("reinsert_batch", C.c_float)]
 
 
 class BvhStats(C.Structure):            # atns_bvh_stats

@@ -124,7 +124,6 @@ public:
     DevScene scene{};
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
-    std::vector<uint32_t> list_dir_word;    // HostSceneImage::list_dir_word: direction lists' segment bytes | axes mask
     uint32_t top_base = 0, n_host_matrices = 0;
     std::vector<atn_mat4> host_matrices;    // the caller's matrices as last uploaded
     std::vector<uint32_t> list_base, list_bytes, list_tri_leaves, list_inner;   // region of every list in the node image
@@ -675,7 +674,7 @@ public:
             int orc = apply_sampling_options();
             if (orc) return orc;
         }
-        list_root_link = img.list_root_link; list_dir_word = img.list_dir_word;
+        list_root_link = img.list_root_link;
         list_base = img.list_root; list_bytes = img.list_bytes; list_tri_leaves = img.list_tri_leaves; list_inner = img.list_inner;
         n_scene_tris = s->n_triangles; n_scene_vtx = s->n_vertices; n_scene_mtrls = s->n_materials;
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
@@ -757,7 +756,6 @@ public:
         c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
         c.matrices = n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr);
         c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
-        c.list_dir_word = list_dir_word.size() == list_root_link.size() ? list_dir_word.data() : nullptr;
         const size_t top_bytes = lay.order.size() * (size_t)kInnerBytes;
         std::vector<float4> rec(top_bytes / 16 + 1, make_float4(0, 0, 0, 0));
         int32_t root = kLinkEnd;

@@ -23,10 +23,7 @@ namespace atn {
 //                     flags bit 0 (kTlasIdentity): W2L is bit for bit the identity matrix, so the ray inside this instance is the SAME
 //                     for every such instance -- mat4::applyRay(I, ray), which is not the world ray: the direction is re-normalised --
 //                     and the plain walk over an LDS copy computes it once per ray (DevScene::ident_row, traverse.hpp)
-//                     q1 = {meshid, top hit link, top miss link, direction word}
-//                     direction word (0 = a plain list): bytes of ONE segment of the instance's direction list | its axes mask
-//                     (atn_bvh_list.direction_axes, include/aten_layout.h): the segments lie back to back, all of the same size, and a
-//                     ray enters the one its direction inside the instance selects -- root link + segment * bytes (direction_root)
+//                     q1 = {meshid, top hit link, top miss link, 0}
 //   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
 //              path); an inner record whose hit link IS its miss link.
 constexpr int32_t kLinkEnd = -1;
@@ -130,7 +127,6 @@ struct DevScene {
     // The top layer is ONE leaf (a scene = one instance: sponza, the atrium): its record, so that a walk can start INSIDE the nested
     // tree (walk_start) instead of standing on the leaf through its first burst.  root_direct = 0: walks start at root_link.
     int32_t root_direct, root_objid, root_meshid, root_w2l, root_blas, root_flags;
-    uint32_t root_dir;                  // that leaf's direction word (TLAS leaf record, above)
     float root_m[12];                   // rows 0..2 of that instance's W2L (root_w2l >= 0): kernel arguments, i.e. scalar registers -- no loads at a refill
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)

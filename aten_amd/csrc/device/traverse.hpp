@@ -181,17 +181,6 @@ struct Walk {
     int32_t node, objid, meshid, top_hit, top_miss;
 };
 
-// Direction lists (atn_bvh_list.direction_axes, include/aten_layout.h: an extension, the reference's lists are plain): the instance's
-// bottom-level list is stored as 2^popcount(axes) segments back to back -- the same tree threaded in different child orders --
-// and a ray enters the segment that the signs of its direction INSIDE the instance select (ATN_DIRECTION_SEGMENT's rule).  dir_word = bytes of one segment | axes mask; 0 = a plain list.
-ATN_DEV int32_t direction_root(int32_t root, uint32_t dir_word, const f3& d)
-{
-    const uint32_t sx = dir_word & 1u, sy = (dir_word >> 1) & 1u, sz = (dir_word >> 2) & 1u;
-    const uint32_t bx = d.x > 0.0F ? sx : 0u, by = d.y > 0.0F ? sy : 0u, bz = d.z > 0.0F ? sz : 0u;
-    const uint32_t seg = bx | (by << sx) | (bz << (sx + sy));
-    return root + (int32_t)(seg * (dir_word & ~15u));
-}
-
 // IDENT (the plain walk over an LDS copy of a small scene): instances whose W2L is bit for bit the identity matrix (TLAS-leaf flag
 // kTlasIdentity, set at upload) all see the SAME local ray -- mat4::applyRay(I, ray): the origin through the matrix product, the
 // direction re-normalised, NOT the world ray -- so it is computed here once per ray, with every lane of the wave taking part, instead
@@ -226,8 +215,7 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
             slab_setup(w.ray, w.wray.org, w.wray.dir);
         }
         w.lray = w.ray;
-        w.node = sc.root_dir ? direction_root(sc.root_blas, sc.root_dir, w.ray.dir) : sc.root_blas;     // (wave-uniform test)
-        w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+        w.node = sc.root_blas; w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         return;
     }
     slab_setup(w.wray, mk3(a), mk3(b));
@@ -366,8 +354,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
                 w.ray = w.wray;
             }
             is_hit = true;
-            // BLAS root link (never kLinkEnd: empty lists are rejected at upload), of the segment this ray's direction selects
-            w.node = direction_root(__float_as_int(q0.z), __float_as_uint(q1.w), w.ray.dir);
+            w.node = __float_as_int(q0.z);      // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
             ended = false;
         }
     }
@@ -438,7 +425,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
                 w.ray = w.wray;
             }
             is_hit = true;
-            w.node = direction_root(__float_as_int(q0.z), __float_as_uint(q1.w), w.ray.dir);      // BLAS root link
+            w.node = __float_as_int(q0.z);      // BLAS root link
         }
         if (w.node == kLinkEnd) {
             // leave the bottom layer (top_* are kLinkEnd inside the top layer)
@@ -559,7 +546,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     w.ray = w.wray;
                 }
                 is_hit = true;
-                w.node = direction_root(__float_as_int(q0.z), __float_as_uint(q1.w), w.ray.dir);      // BLAS root link
+                w.node = __float_as_int(q0.z);      // BLAS root link
             }
             if (w.node == kLinkEnd) {
                 // leave the bottom layer (top_* are kLinkEnd inside the top layer)

@@ -103,9 +103,6 @@ struct Options {
     float max_refs_factor = 4.0f;   // duplication budget: references <= factor * primitives
     float order_point[3] = { 0, 0, 0 };
     bool order_point_given = false; // else: the area-weighted centroid of the triangles
-    int direction_axes = 0;         // mask of axes whose ray-direction sign selects a segment (atn_bvh_list.direction_axes); 0 = one list
-    float direction_tolerance = 0.0f;
-    int seg_sign[3] = { 0, 0, 0 };  // the segment being emitted: +1 / -1 on the masked axes (rays travel that way), 0 elsewhere
     int reinsert_iterations = 100;  // rounds of the insertion-based optimisation (0 = off), each over the worst `reinsert_batch` of the inner nodes
     float reinsert_batch = 0.1f;
 };
@@ -468,16 +465,6 @@ public:
         return moved;
     }
 
-    // which segment of a direction list the next emit() writes (bit j of `segment` = the sign of the j-th masked axis)
-    void set_segment(int axes_mask, uint32_t segment)
-    {
-        int bit = 0;
-        for (int k = 0; k < 3; k++) {
-            opt.seg_sign[k] = 0;
-            if (axes_mask & (1 << k)) { opt.seg_sign[k] = ((segment >> bit) & 1u) ? 1 : -1; bit++; }
-        }
-    }
-
     // pre-order emission with the child-order rule
     std::vector<BuildNode> emit()
     {
@@ -500,7 +487,7 @@ public:
             out.push_back(bn);
             if (t[i].left >= 0) {
                 int32_t a = t[i].left, b = t[i].right;
-                if (right_first(t[i].box, t[a].box, t[a].leaves, t[b].box, t[b].leaves)) std::swap(a, b);
+                if (right_first(t[a].box, t[a].leaves, t[b].box, t[b].leaves)) std::swap(a, b);
                 stack.push_back(b); stack.push_back(a);
             }
         }
@@ -523,19 +510,8 @@ private:
         for (size_t k = order.size(); k-- > 0;) { const int32_t i = order[k]; t[i].leaves = t[i].left >= 0 ? t[t[i].left].leaves + t[t[i].right].leaves : 1u; }
     }
 
-    // A segment for rays of known direction signs: the child whose FRONT (the faces such a ray enters through) lies further
-    // back along the travel direction comes second -- unless the two fronts are within `direction_tolerance` of the node's own
-    // extent of each other (children cut apart along another axis), where the single-list rule decides.
-    bool right_first(const Box& pb, const Box& lb, uint32_t ln, const Box& rb, uint32_t rn) const
+    bool right_first(const Box& lb, uint32_t ln, const Box& rb, uint32_t rn) const
     {
-        if (opt.seg_sign[0] || opt.seg_sign[1] || opt.seg_sign[2]) {
-            float el = 0, er = 0, ext = 0;
-            for (int k = 0; k < 3; k++) {
-                if (opt.seg_sign[k] > 0) { el += lb.mn[k]; er += rb.mn[k]; ext += pb.mx[k] - pb.mn[k]; }
-                else if (opt.seg_sign[k] < 0) { el -= lb.mx[k]; er -= rb.mx[k]; ext += pb.mx[k] - pb.mn[k]; }
-            }
-            if (std::fabs(el - er) > opt.direction_tolerance * ext) return er < el;
-        }
         switch (opt.child_order) {
         case ATNS_ORDER_AREA: return rb.half_area() > lb.half_area();
         case ATNS_ORDER_AREA_SMALL: return rb.half_area() < lb.half_area();
@@ -698,35 +674,7 @@ Options options_from(const atns_bvh_options* o)
     if (o->reinsert_batch > 0.f && o->reinsert_batch <= 1.f) r.reinsert_batch = o->reinsert_batch;
     if (o->max_refs_factor >= 1.f) r.max_refs_factor = o->max_refs_factor;
     for (int k = 0; k < 3; k++) r.order_point[k] = o->order_point[k];
-    if (o->direction_axes > 0 && o->direction_axes <= 7) r.direction_axes = o->direction_axes;
-    if (o->direction_tolerance >= 0.f) r.direction_tolerance = o->direction_tolerance;
     return r;
-}
-
-// The finished tree as a threaded list -- or, with direction_axes, as ATN_DIRECTION_SEGMENTS(mask) of them back to back, each in
-// the pre-order of ITS child order (links are indices inside the segment).  payload(node, prim) fills a leaf's four floats.
-template <class Payload>
-atn_bvh_node* emit_lists(Restructure& rs, const Options& opt, uint32_t& n_per_list, uint32_t& n_lists, std::vector<BuildNode>& first, Payload payload)
-{
-    n_lists = opt.direction_axes ? ATN_DIRECTION_SEGMENTS((uint32_t)opt.direction_axes) : 1u;
-    atn_bvh_node* out = nullptr;
-    for (uint32_t sgm = 0; sgm < n_lists; sgm++) {
-        if (opt.direction_axes) rs.set_segment(opt.direction_axes, sgm);
-        std::vector<BuildNode> fin = rs.emit();
-        if (sgm == 0) {
-            n_per_list = (uint32_t)fin.size();
-            if ((uint64_t)n_per_list * n_lists >= (1ull << 24)) return nullptr;     // links are floats: exact below 2^24
-            out = (atn_bvh_node*)std::malloc(sizeof(atn_bvh_node) * std::max<size_t>((size_t)n_per_list * n_lists, 1));
-            if (!out) return nullptr;
-        }
-        atn_bvh_node* one = emit(fin);
-        if (!one) { std::free(out); return nullptr; }
-        for (uint32_t i = 0; i < n_per_list; i++) { if (fin[i].prim >= 0) payload(one[i], fin[i].prim); }
-        std::memcpy(out + (size_t)sgm * n_per_list, one, sizeof(atn_bvh_node) * n_per_list);
-        std::free(one);
-        if (sgm == 0) first.swap(fin);
-    }
-    return out;
 }
 
 // A threaded list somebody else built (an imported .sbvh): the same boxes and leaves, re-arranged by the two post passes.
@@ -773,18 +721,19 @@ int optimise_nodes(const atn_bvh_node* in, uint32_t count, const atns_bvh_option
         for (int a = 0; a < 3; a++) opt.order_point[a] = pre[0].box.centre(a);
     Restructure rs(pre, opt);
     const uint64_t moved = rs.optimise(opt.reinsert_iterations, opt.reinsert_batch);
-    std::vector<BuildNode> fin;
-    uint32_t n_per_list = 0, n_lists = 1;
-    atn_bvh_node* nodes = emit_lists(rs, opt, n_per_list, n_lists, fin, [&](atn_bvh_node& o, int32_t prim) {
-        const atn_bvh_node& src = in[order[prim]];
-        o.f0 = src.f0; o.f1 = src.f1; o.f2 = src.f2; o.f3 = src.f3;
-    });
+    const std::vector<BuildNode> fin = rs.emit();
+    atn_bvh_node* nodes = emit(fin);
     if (!nodes) return -3;
     uint32_t leaves = 0;
-    for (const BuildNode& nd : fin) leaves += nd.prim >= 0 ? 1u : 0u;
-    *out_nodes = nodes; *out_count = n_per_list * n_lists;
+    for (size_t i = 0; i < fin.size(); i++) {
+        if (fin[i].prim < 0) continue;
+        const atn_bvh_node& src = in[order[fin[i].prim]];
+        nodes[i].f0 = src.f0; nodes[i].f1 = src.f1; nodes[i].f2 = src.f2; nodes[i].f3 = src.f3;
+        leaves++;
+    }
+    *out_nodes = nodes; *out_count = (uint32_t)fin.size();
     if (stats) {
-        stats->n_nodes = n_per_list * n_lists; stats->n_leaves = leaves; stats->n_spatial_splits = 0;
+        stats->n_nodes = (uint32_t)fin.size(); stats->n_leaves = leaves; stats->n_spatial_splits = 0;
         stats->n_reinsertions = (uint32_t)std::min<uint64_t>(moved, 0xffffffffu);
         double sah = 0; const double ra = std::max((double)fin[0].box.half_area(), 1e-30);
         for (const BuildNode& nd : fin) sah += (double)nd.box.half_area() / ra;
@@ -829,26 +778,28 @@ int build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris, const ui
     Builder b(opt, geo.data());
     b.run(refs);
     uint64_t moved = 0;
-    uint32_t n_per_list = 0, n_lists = 1;
-    atn_bvh_node* nodes = nullptr;
     {
         Restructure rs(b.nodes, opt);
         moved = rs.optimise(opt.reinsert_iterations, opt.reinsert_batch);
-        nodes = emit_lists(rs, opt, n_per_list, n_lists, b.nodes, [&](atn_bvh_node& o, int32_t prim) {
-            o.f0 = 1.0f;                                        // isleaf
-            o.f1 = (float)tri_ids[prim];                        // triid
-            o.f2 = -1.0f;                                       // AT_DISABLE_VOXEL
-            o.f3 = -1.0f;
-        });
+        b.nodes = rs.emit();
     }
+    atn_bvh_node* nodes = emit(b.nodes);
     if (!nodes) return -3;
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        if (b.nodes[i].prim >= 0) {
+            nodes[i].f0 = 1.0f;                                 // isleaf
+            nodes[i].f1 = (float)tri_ids[b.nodes[i].prim];      // triid
+            nodes[i].f2 = -1.0f;                                // AT_DISABLE_VOXEL
+            nodes[i].f3 = -1.0f;
+        }
+    }
     *out_nodes = nodes;
-    *out_count = n_per_list * n_lists;
+    *out_count = (uint32_t)b.nodes.size();
     if (out_bbox_min && out_bbox_max) {
         for (int k = 0; k < 3; k++) { out_bbox_min[k] = b.nodes[0].box.mn[k]; out_bbox_max[k] = b.nodes[0].box.mx[k]; }
     }
     if (stats) {
-        stats->n_nodes = n_per_list * n_lists;
+        stats->n_nodes = (uint32_t)b.nodes.size();
         stats->n_leaves = (uint32_t)b.n_refs_out;
         stats->n_spatial_splits = (uint32_t)b.n_spatial;
         stats->n_reinsertions = (uint32_t)std::min<uint64_t>(moved, 0xffffffffu);
@@ -881,8 +832,6 @@ void atns_bvh_default_options(atns_bvh_options* o)
     o->order_point_given = d.order_point_given ? 1 : 0;
     o->reinsert_iterations = d.reinsert_iterations;
     o->reinsert_batch = d.reinsert_batch;
-    o->direction_axes = d.direction_axes;
-    o->direction_tolerance = d.direction_tolerance;
 }
 
 int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,

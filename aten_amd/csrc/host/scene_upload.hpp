@@ -16,7 +16,6 @@ struct HostSceneImage {
     std::vector<uint32_t> list_root;    // byte offset of each list's first record
     std::vector<int32_t> list_root_link; // typed link of each list's root
     std::vector<uint32_t> list_bytes;   // bytes of each list's contiguous region starting at list_root
-    std::vector<uint32_t> list_dir_word; // direction lists (atn_bvh_list.direction_axes): bytes of ONE segment | the axes mask; 0 = a plain list
     std::vector<uint32_t> list_tri_leaves, list_inner;  // record counts of each list
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
@@ -119,7 +118,6 @@ struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
     const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0, n_vertices = 0;
     const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
-    const uint32_t* list_dir_word = nullptr;        // HostSceneImage::list_dir_word (null: plain lists only)
     const atn_mat4* matrices = nullptr;     // the matrices the TLAS leaves' rows index (null: identity instances are not recognised)
     mutable int32_t ident_row = -1;         // out: w2l_row of an instance whose W2L is bit for bit the identity
 };
@@ -136,7 +134,7 @@ inline bool is_exact_identity(const atn_mat4& m)
 inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias, const atn_mat4* matrices = nullptr, uint32_t n_matrices = 0)
 {
     for (float& v : p.root_m) v = 0.0F;
-    p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0; p.root_dir = 0;
+    p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0;
     if (p.root_link == kLinkEnd || p.root_link >= 0 || (p.root_link & kLinkTypeMask) != kLinkTlasBit) return;
     const uint32_t off = (uint32_t)p.root_link & kLinkOffsetMask;
     if (off < bias) return;
@@ -146,7 +144,6 @@ inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias, co
     p.root_direct = 1;
     p.root_objid = f2i(q[0].x); p.root_w2l = f2i(q[0].y); p.root_blas = f2i(q[0].z); p.root_flags = f2i(q[0].w);
     p.root_meshid = f2i(q[1].x);
-    p.root_dir = (uint32_t)f2i(q[1].w);
     if (p.root_w2l >= 0) {
         const uint32_t mi = (uint32_t)p.root_w2l / 4u;
         if (!matrices || mi >= n_matrices) { p.root_direct = 0; return; }      // (no host copy of the matrices: walks start at root_link)
@@ -197,7 +194,7 @@ inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, c
             int32_t flags = 0;
             if (w2l_row >= 0 && c.matrices && is_exact_identity(c.matrices[obj.mtx_id + 1])) { flags |= kTlasIdentity; if (c.ident_row < 0) c.ident_row = w2l_row; }
             q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), i2f(flags));
-            q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), i2f((int32_t)(c.list_dir_word ? c.list_dir_word[exid] : 0u)));
+            q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), 0.0F);
             counts[2]++;
             break;
         }
@@ -262,48 +259,28 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     std::string range_err;
     if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
 
-    // lay[k][g]: segment g of list k (a plain list is one segment; a direction list -- atn_bvh_list.direction_axes -- holds
-    // ATN_DIRECTION_SEGMENTS(mask) complete threaded lists of the same tree back to back, links local to the segment)
-    std::vector<std::vector<ListLayout>> lay(nl);
-    std::vector<uint32_t> seg_nodes(nl, 0);
+    std::vector<ListLayout> lay(nl);
     uint64_t total_nodes = 0;
     for (uint32_t k = 0; k < nl; k++) {
-        const uint32_t axes = s->bvh_lists[k].direction_axes;
-        if (axes > 7u || (k == 0 && axes)) { err = "direction_axes: a mask of three axes, bottom-level lists only"; return false; }
-        const uint32_t n_seg = ATN_DIRECTION_SEGMENTS(axes);
-        if (s->bvh_lists[k].count % n_seg) { err = "direction list: node count is not a multiple of its segments"; return false; }
-        seg_nodes[k] = s->bvh_lists[k].count / n_seg;
-        lay[k].resize(n_seg);
-        for (uint32_t g = 0; g < n_seg; g++) {
-            if (!analyse_list(lay[k][g], s->bvh_lists[k].nodes + (size_t)g * seg_nodes[k], seg_nodes[k], k == 0, err)) return false;
-            total_nodes += lay[k][g].order.size();
-        }
+        if (!analyse_list(lay[k], s->bvh_lists[k].nodes, s->bvh_lists[k].count, k == 0, err)) return false;
+        total_nodes += lay[k].order.size();
     }
     uint64_t off = 0;
     img.list_root.assign(nl, 0);
-    img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0); img.list_dir_word.assign(nl, 0);
+    img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0);
     for (uint32_t kk = 1; kk <= nl; kk++) {
         const uint32_t k = kk % nl;         // 1, 2, ..., nl-1, 0
         img.list_root[k] = (uint32_t)off;
-        uint32_t seg_bytes = 0;
-        for (uint32_t g = 0; g < lay[k].size(); g++) {
-            ListLayout& L = lay[k][g];
-            const uint64_t seg_start = off;
-            for (uint32_t j = 0; j < L.order.size(); j++) {
-                if (L.kind[j] == KIND_TRI) img.list_tri_leaves[k]++;
-                else if (L.kind[j] == KIND_INNER) img.list_inner[k]++;
-            }
-            for (uint32_t j = 0; j < L.order.size(); j++) {
-                if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
-                L.offset[j] = (uint32_t)off;
-                off += record_bytes(L.kind[j]);
-            }
-            // the walk finds segment g at root + g * seg_bytes: every segment must be the same tree (same record kinds)
-            if (g == 0) seg_bytes = (uint32_t)(off - seg_start);
-            else if ((uint32_t)(off - seg_start) != seg_bytes || L.kind.empty() || L.kind[0] != lay[k][0].kind[0]) { err = "direction list: segments differ in their records"; return false; }
+        for (uint32_t j = 0; j < lay[k].order.size(); j++) {
+            if (lay[k].kind[j] == KIND_TRI) img.list_tri_leaves[k]++;
+            else if (lay[k].kind[j] == KIND_INNER) img.list_inner[k]++;
+        }
+        for (uint32_t j = 0; j < lay[k].order.size(); j++) {
+            if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
+            lay[k].offset[j] = (uint32_t)off;
+            off += record_bytes(lay[k].kind[j]);
         }
         img.list_bytes[k] = (uint32_t)(off - img.list_root[k]);
-        if (lay[k].size() > 1) img.list_dir_word[k] = seg_bytes | s->bvh_lists[k].direction_axes;      // (seg_bytes is a multiple of 16)
     }
     if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
     img.nodes.assign((size_t)(off / 16), make_float4(0, 0, 0, 0));
@@ -318,12 +295,9 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     for (uint32_t kk = 1; kk <= nl; kk++) {
         const uint32_t k = kk % nl;
         c.list_root_link = img.list_root_link.data();
-        c.list_dir_word = img.list_dir_word.data();
-        for (uint32_t g = 0; g < lay[k].size(); g++) {
-            int32_t root = kLinkEnd;
-            if (!emit_list(reinterpret_cast<char*>(img.nodes.data()), lay[k][g], s->bvh_lists[k].nodes + (size_t)g * seg_nodes[k], c, root, counts, err)) return false;
-            if (g == 0) img.list_root_link[k] = root;
-        }
+        int32_t root = kLinkEnd;
+        if (!emit_list(reinterpret_cast<char*>(img.nodes.data()), lay[k], s->bvh_lists[k].nodes, c, root, counts, err)) return false;
+        img.list_root_link[k] = root;
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
     img.params.node_bytes = (uint32_t)off;

@@ -125,7 +125,7 @@ class TextureDesc(C.Structure):
 
 
 class BvhList(C.Structure):
-    _fields_ = [("nodes", C.c_void_p), ("count", C.c_uint32), ("direction_axes", C.c_uint32)]
+    _fields_ = [("nodes", C.c_void_p), ("count", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

@@ -49,9 +49,8 @@ class FlatScene:
 
     @staticmethod
     def from_arrays(objects, matrices, materials, lights, triangles, vtx_pos, vtx_nml, bvh_lists, config=None,
-                    scene_bbox=None, textures=(), bvh_list_axes=None):
-        """Wrap flat arrays somebody else produced (e.g. a C++ application's dump) in an atn_scene_desc.
-        bvh_list_axes: atn_bvh_list.direction_axes per list (None = plain lists)."""
+                    scene_bbox=None, textures=()):
+        """Wrap flat arrays somebody else produced (e.g. a C++ application's dump) in an atn_scene_desc."""
         fs = FlatScene()
         objs = np.ascontiguousarray(objects, L.OBJECT_PARAM); mats = np.ascontiguousarray(materials, L.MATERIAL_PARAM)
         lts = np.ascontiguousarray(lights, L.LIGHT_PARAM); tris = np.ascontiguousarray(triangles, L.TRIANGLE_PARAM)
@@ -59,11 +58,9 @@ class FlatScene:
         pos = np.ascontiguousarray(vtx_pos, F32).reshape(-1, 4); nml = np.ascontiguousarray(vtx_nml, F32).reshape(-1, 4)
         nodes = [np.ascontiguousarray(n, L.BVH_NODE) for n in bvh_lists]
         lists = (L.BvhList * len(nodes))()
-        axes = [0] * len(nodes) if bvh_list_axes is None else [int(a) for a in bvh_list_axes]
         for i, n in enumerate(nodes):
             lists[i].nodes = n.ctypes.data
             lists[i].count = len(n)
-            lists[i].direction_axes = axes[i]
         tex = [np.ascontiguousarray(t, F32) for t in textures]
         texd = (L.TextureDesc * max(1, len(tex)))()
         for i, t in enumerate(tex):
@@ -87,17 +84,15 @@ class FlatScene:
         fs.keep = [objs, mtx, mats, lts, tris, pos, nml, nodes, lists, texd, tex]
         fs.lists = lists
         fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lts, triangles=tris, vtx_pos=pos, vtx_nml=nml,
-                         bvh_lists=nodes, bvh_list_axes=axes, textures=tex)
+                         bvh_lists=nodes, textures=tex)
         return fs
 
-    def replace_bvh_list(self, k, nodes, direction_axes=0):
+    def replace_bvh_list(self, k, nodes):
         """Swap node list k (e.g. for a tree built elsewhere over the same triangles)."""
         nodes = np.ascontiguousarray(nodes, L.BVH_NODE)
         self.arrays["bvh_lists"][k] = nodes
-        self.arrays["bvh_list_axes"][k] = int(direction_axes)
         self.lists[k].nodes = nodes.ctypes.data
         self.lists[k].count = len(nodes)
-        self.lists[k].direction_axes = int(direction_axes)
 
 
 class SceneBuilder:
@@ -443,19 +438,13 @@ class SceneBuilder:
         kw = self.bvh_options if self.bvh_options is not None else DEFAULT_BVH_OPTIONS
         return C.byref(default_bvh_options(**kw)) if kw else None
 
-    def _bvh_direction_axes(self):
-        kw = self.bvh_options if self.bvh_options is not None else DEFAULT_BVH_OPTIONS
-        return int(kw.get("direction_axes", 0)) if kw else 0
-
     def import_sbvh(self, obj_id, path, optimize=False):
         """PolygonObject::importInternalAccelTree + sbvh::buildAsNestedTree's triangle offset.  optimize: the imported tree goes
         through the builder's post passes first (atns_optimize_nodes: same boxes and leaves, re-arranged; `bvh_options` apply)."""
         hdr, mtrl_names, nodes = read_sbvh(path)
-        axes = 0
         if optimize:
             nodes = optimize_nodes(nodes, self._bvh_options())
-            axes = self._bvh_direction_axes()
-        self.blas[obj_id] = ("imported", nodes, hdr, axes)
+        self.blas[obj_id] = ("imported", nodes, hdr)
 
     def export_sbvh(self, obj_id, path, lib=None):
         """sbvh::exportTree for one polygon object (accelerator/sbvh.cpp:1237-1338): the object's BLAS (the imported one,
@@ -464,8 +453,7 @@ class SceneBuilder:
         spec = self.blas.get(obj_id)
         if spec is not None and spec[0] == "imported":
             hdr = spec[2]
-            n_seg = 1 << bin(spec[3]).count("1")        # a direction list: the file holds its first segment (one plain list)
-            return write_sbvh(path, spec[1][:len(spec[1]) // n_seg], hdr["boxmin"], hdr["boxmax"], hdr["maxDepth"], None, hdr["version"])
+            return write_sbvh(path, spec[1], hdr["boxmin"], hdr["boxmax"], hdr["maxDepth"], None, hdr["version"])
         o = self.objects[obj_id]
         if o["type"] != L.OBJ_POLYGONS:
             raise ValueError("only polygon objects carry a bottom-level tree")
@@ -482,7 +470,6 @@ class SceneBuilder:
             raise RuntimeError("atns_build_blas_opt failed: %d" % rc)
         nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
         lib.atns_free(out)
-        nodes = nodes[:len(nodes) >> bin(self._bvh_direction_axes()).count("1")]      # a direction list: its first segment
         first = min(tri_ids)
         leaf = nodes["f0"] >= 0
         nodes["f1"][leaf] -= F32(first)         # the file holds object-local ids; import adds the offset back
@@ -564,7 +551,6 @@ class SceneBuilder:
         objs["sphere_mtrl_id"] = -1
         obj_bbox = {}
         bvh_lists = [None]          # [0] = TLAS
-        bvh_axes = [0]              # atn_bvh_list.direction_axes of each list
         blas_index = {}
         bvh_stats = {}
         for oid, o in enumerate(self.objects):
@@ -592,9 +578,7 @@ class SceneBuilder:
                 nodes["f1"][leaf] += F32(first)     # sbvh::buildAsNestedTree, sbvh.cpp:109-128
                 hdr = spec[2]
                 bmin, bmax = np.asarray(hdr["boxmin"], F32), np.asarray(hdr["boxmax"], F32)
-                axes = spec[3]
             else:
-                axes = self._bvh_direction_axes()
                 out = C.c_void_p(); cnt = C.c_uint32()
                 bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
                 ids = np.asarray(tri_ids, np.uint32)
@@ -609,7 +593,6 @@ class SceneBuilder:
                 bmin, bmax = np.asarray(list(bmin), F32), np.asarray(list(bmax), F32)
             obj_bbox[oid] = (bmin, bmax)
             bvh_lists.append(nodes)
-            bvh_axes.append(axes)
             blas_index[oid] = len(bvh_lists) - 1
 
         inst = []
@@ -666,7 +649,6 @@ class SceneBuilder:
         for i, n in enumerate(bvh_lists):
             lists[i].nodes = n.ctypes.data
             lists[i].count = len(n)
-            lists[i].direction_axes = bvh_axes[i]
         texd = (L.TextureDesc * max(1, len(self.textures)))()
         for i, (_, t) in enumerate(self.textures):
             texd[i].texels = t.ctypes.data
@@ -697,7 +679,7 @@ class SceneBuilder:
         fs.blas_index = dict(blas_index)      # polygon object id -> its node list
         fs.bvh_stats = bvh_stats              # polygon object id -> atns_bvh_stats of the tree built here
         fs.arrays = dict(objects=objs, matrices=mtx, materials=mats, lights=lights, triangles=tris,
-                         vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, bvh_list_axes=bvh_axes, textures=[t for _, t in self.textures])
+                         vtx_pos=pos, vtx_nml=nml, bvh_lists=bvh_lists, textures=[t for _, t in self.textures])
         fs.names = dict(materials=[n for n, _ in self.materials], textures=[n for n, _ in self.textures])
         return fs
 

@@ -75,23 +75,7 @@ def envmap_avg_illum(tex):
     return float((lum * s).sum() / (s.sum() * tex.shape[1]))
 
 
-# atns_bvh_options.direction_axes of the trees scenedefs builds itself (sponza_lod(use_sbvh=False) / optimize_sbvh, atrium) when the
-# caller passes neither bvh_options nor direction_axes: a mask of axes, 0 = one list per tree (include/aten_layout.h, atn_bvh_list)
-DEFAULT_DIRECTION_AXES = 0
-
-
-def _own_tree_options(cam, bvh_options, direction_axes):
-    if bvh_options is not None:
-        return bvh_options
-    axes = DEFAULT_DIRECTION_AXES if direction_axes is None else int(direction_axes)
-    o = dict(order_point=cam["pos"])        # the trees built here: children nearer the viewer are threaded first
-    if axes:
-        o["direction_axes"] = axes
-    return o
-
-
-def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True, bvh_options=None, optimize_sbvh=False,
-               direction_axes=None):
+def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textures=True, bvh_options=None, optimize_sbvh=False):
     """BASELINE config 3 stand-in: sponza_lod.obj (12,852 tris) with the reference-built
     sponza_lod.sbvh tree, GGX materials, synthetic IBL."""
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
@@ -109,7 +93,7 @@ def sponza_lod(asset_dir=None, mtype=L.MTRL_GGX, ibl=True, use_sbvh=True, textur
 
     cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)         # scenedefs.cpp:847-860
     # own tree (use_sbvh=False): children nearer the viewer are threaded first
-    b.bvh_options = _own_tree_options(cam, bvh_options, direction_axes)
+    b.bvh_options = dict(order_point=cam["pos"]) if bvh_options is None else bvh_options
     objs = b.load_obj(os.path.join(asset_dir, "sponza_lod.obj"), create_mtrl=create_mtrl)
     if use_sbvh:
         b.import_sbvh(objs[0], os.path.join(asset_dir, "sponza_lod.sbvh"), optimize=optimize_sbvh)
@@ -268,7 +252,7 @@ def _icosphere(level):
     return np.asarray(v, np.float64), np.asarray(f, np.int64)
 
 
-def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0, bvh_options=None, direction_axes=None):
+def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0, bvh_options=None):
     """Procedural colonnaded hall, ~250 k unique triangles (+ 6 instances of a 20 k-triangle statue), Disney
     materials with the Sponza albedo / normal-map textures, IBL + one polygon area light.  Stand-in for
     BASELINE config 4 "Crytek Sponza 4K 8spp 8-bounce Disney + textures" (≈262 k triangles), whose
@@ -276,7 +260,8 @@ def atrium(asset_dir=None, mtype=L.MTRL_DISNEY, detail=1.0, bvh_options=None, di
     asset_dir = asset_dir or os.path.join(ASSETS, "sponza")
     b = SceneBuilder()
     cam = dict(pos=(-7.0, 1.7, 0.6), at=(0.0, 1.5, 0.0), vfov=45.0)
-    b.bvh_options = _own_tree_options(cam, bvh_options, direction_axes)
+    # the trees built here: children nearer the viewer are threaded first
+    b.bvh_options = dict(order_point=cam["pos"]) if bvh_options is None else bvh_options
 
     def tex(name):
         return b.load_image(os.path.join(asset_dir, name))

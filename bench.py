@@ -200,13 +200,13 @@ def run_workload(args, cfg, ctx):
         if ex:
             workload += " EXPERIMENT " + "+".join(sorted(ex))
     elif scene == "sponza_own_tree":
-        fs, cam = scenedefs.sponza_lod(use_sbvh=False, direction_axes=args.direction_axes)
+        fs, cam = scenedefs.sponza_lod(use_sbvh=False)
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, tree built by atns_build_blas (split BVH)" % (W, H, spp, depth)
     elif scene == "sponza_ref_tree_opt":
-        fs, cam = scenedefs.sponza_lod(use_sbvh=True, optimize_sbvh=True, direction_axes=args.direction_axes)
+        fs, cam = scenedefs.sponza_lod(use_sbvh=True, optimize_sbvh=True)
         workload = "sponza_lod %dx%d %dspp %d-bounce GGX+IBL, reference-built sponza_lod.sbvh through atns_optimize_nodes" % (W, H, spp, depth)
     elif scene == "atrium":
-        fs, cam = scenedefs.atrium(direction_axes=args.direction_axes)
+        fs, cam = scenedefs.atrium()
         workload = ("procedural atrium (%d triangles, Disney + Sponza textures + IBL + area light; synthetic Sponza-class scale-up, stand-in "
                     "for the missing Crytek Sponza blob) %dx%d %dspp %d-bounce%s" % (len(fs.arrays["triangles"]), W, H, spp, depth,
                                                                                  " all samples traced" if cfg["all_samples"] else ""))
@@ -652,8 +652,7 @@ def run_workload(args, cfg, ctx):
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
                        "frames_in_flight": in_flight,
-                       "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"])),
-                       "bvh_direction_axes": [int(a) for a in fs.arrays.get("bvh_list_axes", [])][1:]},
+                       "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"]))},
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / steps), 2),
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},
             "kernel_ms_per_frame": kernel_ms_per_frame,
@@ -688,9 +687,6 @@ def main():
     ap.add_argument("--no-companion", action="store_true",
                     help="the default run (Sponza stand-in, 1 GPU) also times the 250 K-triangle procedural atrium at the same 1080p 1 spp "
                          "5-bounce protocol and reports it under `companion` (SURVEY 8(d): the stand-in AND a synthetic scale-up); this skips it")
-    ap.add_argument("--direction-axes", type=int, default=None,
-                    help="atns_bvh_options.direction_axes of the trees the bench builds itself (own-tree sponza_lod, the optimised reference "
-                         "tree, the atrium): a mask of axes, 0 = one list; default = scenedefs.DEFAULT_DIRECTION_AXES")
     ap.add_argument("--no-own-tree", action="store_true",
                     help="the default run also times the headline frames through the tree of the repo's own BVH builder (`own_tree`); this skips it")
     ap.add_argument("--experiment", default="", help="traffic experiments on the sponza scene, not a benchmark configuration: "

@@ -20,8 +20,8 @@ extern "C" {
 
 /* Version of THIS header's entry points (libaten_amd_scene.so; atn_abi_version covers libaten_amd.so only).  Bumped when an
  * existing signature or struct changes; a binding checks it once after loading.  2 = atns_obj_register / atns_obj_copy with
- * counts and capacities, atns_build_blas_opt.  3 = atns_bvh_options.direction_axes / direction_tolerance. */
-#define ATNS_ABI_VERSION 3u
+ * counts and capacities, atns_build_blas_opt. */
+#define ATNS_ABI_VERSION 2u
 uint32_t atns_abi_version(void);
 
 /* Bottom-level tree over the triangles tri_ids[0..n_tris) of `tris` (global ids are written
@@ -57,12 +57,6 @@ typedef struct atns_bvh_options {
                                      large for what their children need are taken out and their subtrees re-inserted where
                                      they add the least area */
     float reinsert_batch;         /* share of the inner nodes a round works on */
-    int32_t direction_axes;       /* 0 = one list.  A mask of axes (bit 0 = x, 1 = y, 2 = z): the output holds 2^popcount SEGMENTS,
-                                     each a complete threaded list of the same tree, for the rays whose direction has the segment's
-                                     signs on those axes (atn_bvh_list.direction_axes, aten_layout.h): the child whose front face such
-                                     a ray reaches first comes first; where the two fronts are within direction_tolerance of the
-                                     node's extent of each other, child_order decides as in a single list */
-    float direction_tolerance;
 } atns_bvh_options;
 typedef struct atns_bvh_stats {
     uint32_t n_nodes, n_leaves, n_spatial_splits, n_reinsertions;

@@ -216,27 +216,12 @@ typedef struct atn_texture_desc {
     int32_t height;
 } atn_texture_desc;
 
-/* ---- one BVH node list: scene.getAccel()->getNodes()[k] (src/libaten/accelerator/sbvh.h:167-170)
- *
- * direction_axes (bottom-level lists only; 0 = the reference's form: ONE threaded list of `count` nodes).  An extension the
- * reference does not have: a threaded list is walked in one fixed order by every ray, and how much of a node's second child
- * a hit in the first one cuts away depends on whether the first child is the one the ray reaches first.  With
- * direction_axes = a mask of axes (bit 0 = x, 1 = y, 2 = z) the list holds K = 2^popcount(mask) SEGMENTS of count / K nodes
- * each, every segment a complete threaded list of the SAME tree (same boxes, same leaves; links are indices inside the
- * segment) that differs in which child comes first, and a ray walks the segment its own direction selects:
- *     bit_a = (dir[a] > 0.0f) for the ray INSIDE the instance (after mat4::applyRay, threaded_bvh_traverser.h:149-160),
- *     segment = the bits of the masked axes, packed in increasing axis order (mask 0b101: segment = bit_x | bit_z << 1).
- * csrc/host/bvh_builder.cpp (atns_bvh_options.direction_axes) writes such lists; ATN_DIRECTION_SEGMENT is the rule. */
+/* ---- one BVH node list: scene.getAccel()->getNodes()[k] (src/libaten/accelerator/sbvh.h:167-170) */
 typedef struct atn_bvh_list {
     const atn_bvh_node* nodes;
     uint32_t count;
-    uint32_t direction_axes;
+    uint32_t _pad;
 } atn_bvh_list;
-#define ATN_DIRECTION_SEGMENTS(mask) (1u << ((((mask) >> 0) & 1u) + (((mask) >> 1) & 1u) + (((mask) >> 2) & 1u)))
-#define ATN_DIRECTION_SEGMENT(mask, dx, dy, dz) \
-    (  (((mask) & 1u) ? ((dx) > 0.0f ? 1u : 0u) : 0u) \
-     | (((mask) & 2u) ? ((dy) > 0.0f ? 1u : 0u) << ((mask) & 1u) : 0u) \
-     | (((mask) & 4u) ? ((dz) > 0.0f ? 1u : 0u) << (((mask) & 1u) + (((mask) >> 1) & 1u)) : 0u))
 
 /*
  * The whole scene as idaten::Renderer::UpdateSceneData receives it

@@ -114,16 +114,6 @@ struct Scene {
     v4 GetPositionAsVec4(uint32_t i) const { const auto& p = d->vtx_pos[i]; return v4(p.x, p.y, p.z, p.w); }
     v4 GetNormalAsVec4(uint32_t i) const { const auto& p = d->vtx_nml[i]; return v4(p.x, p.y, p.z, p.w); }
     const atn_bvh_node* GetBvhNodes(uint32_t list) const { return d->bvh_lists[list].nodes; }
-    // The product's direction lists (atn_bvh_list.direction_axes, include/aten_layout.h -- not in the reference, whose lists all
-    // have direction_axes = 0): the segment of list `list` that a ray of direction `dir` (inside the instance) walks.
-    const atn_bvh_node* GetBvhNodesFor(uint32_t list, const v3& dir) const
-    {
-        const atn_bvh_list& l = d->bvh_lists[list];
-        const uint32_t mask = l.direction_axes & 7u;
-        if (!mask) return l.nodes;
-        const uint32_t per = l.count / ATN_DIRECTION_SEGMENTS(mask);
-        return l.nodes + (size_t)ATN_DIRECTION_SEGMENT(mask, dir.x, dir.y, dir.z) * per;
-    }
     const atn_scene_rendering_config& cfg() const { return d->config; }
     // context::GetNprTargetLight (scene/host_scene_context.cpp:70-74)
     const atn_light_param& GetNprTargetLight(uint32_t i) const { return d->npr_target_lights[i]; }
@@ -286,7 +276,7 @@ inline bool TraverseClosest(Isect& isect, const Scene& ctxt, const Ray r, float 
                 }
                 uint32_t bits = (uint32_t)float_as_int(node.f2);
                 int32_t exid = ATN_EXID_MAIN(bits);     // enable_lod is false on this path
-                node_list = ctxt.GetBvhNodesFor(exid, transformed_ray.dir);
+                node_list = ctxt.GetBvhNodes(exid);
                 objid = static_cast<int32_t>(node.f0);
                 meshid = static_cast<int32_t>(node.f3);
                 top_layer_hit = static_cast<int32_t>(node.hit);

@@ -161,7 +161,7 @@ int main(int argc, char** argv)
     }
 
     std::vector<atn_bvh_list> lists(a.lists.size());
-    for (size_t k = 0; k < a.lists.size(); k++) { lists[k].nodes = a.lists[k].data(); lists[k].count = (uint32_t)a.lists[k].size(); lists[k].direction_axes = 0; }
+    for (size_t k = 0; k < a.lists.size(); k++) { lists[k].nodes = a.lists[k].data(); lists[k].count = (uint32_t)a.lists[k].size(); lists[k]._pad = 0; }
     atn_scene_desc d;
     std::memset(&d, 0, sizeof(d));
     d.objects = a.objs.data(); d.n_objects = (uint32_t)a.objs.size();

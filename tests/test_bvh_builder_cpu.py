@@ -34,9 +34,9 @@ def sponza_mesh():
 
 def test_scene_library_reports_its_abi_version():
     from aten_amd._hostlib import hostlib, ATNS_ABI_VERSION
-    assert hostlib().atns_abi_version() == ATNS_ABI_VERSION == 3
+    assert hostlib().atns_abi_version() == ATNS_ABI_VERSION == 2
     hdr = open(os.path.join(ROOT, "include", "aten_amd_scene.h")).read()
-    assert "#define ATNS_ABI_VERSION 3u" in hdr
+    assert "#define ATNS_ABI_VERSION 2u" in hdr
 
 
 def test_split_tree_structure(sponza_mesh):
@@ -252,47 +252,3 @@ def test_post_passes_on_an_imported_tree(orc):
     bad = nodes.copy(); bad["miss"][0] = 1.0
     assert lib.atns_optimize_nodes(bad.ctypes.data, n, None, C.byref(o), C.byref(c), None) == -4
     assert lib.atns_optimize_nodes(None, n, None, C.byref(o), C.byref(c), None) == -1
-
-
-def test_direction_lists(orc):
-    """atns_bvh_options.direction_axes: the output holds 2^popcount segments, each a complete threaded list (links inside the segment,
-    pre-order) of the SAME tree -- the same boxes and leaves, another child order; a ray walks the segment its direction selects
-    (atn_bvh_list.direction_axes; the oracle applies ATN_DIRECTION_SEGMENT's rule).  Incoherent rays find the same hits as in the
-    single list (an exact-t tie on a shared edge may name the other triangle) with fewer node visits; a list whose segments
-    are not the same tree is refused by the validator of the upload (checked on the GPU side) -- here: the count rule."""
-    from aten_amd.scene import scenedefs
-    from aten_amd._hostlib import hostlib
-    base, cam = scenedefs.sponza_lod(use_sbvh=False)
-    n1 = len(base.arrays["bvh_lists"][1])
-    rng = np.random.default_rng(17)
-    prim = orc.generate_paths(orc.create_camera(cam["pos"], cam["at"], cam["vfov"], 160, 90), orc.init_sampler(160, 90, 0), 160, 90, 0, 0)
-    hit0, _ = orc.trace_closest(base, prim)
-    ok = hit0["objid"] >= 0
-    rays = np.zeros(int(ok.sum()), prim.dtype)
-    rays["org"] = prim["org"][ok] + prim["dir"][ok] * (hit0["t"][ok, None] * np.float32(0.999))
-    d = rng.normal(size=(len(rays), 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-    rays["dir"] = d.astype(np.float32)
-    want, st0 = orc.trace_closest(base, rays)
-    for axes, bound in ((1, 0.98), (5, 0.94), (7, 0.90)):
-        fs, _ = scenedefs.sponza_lod(use_sbvh=False, bvh_options=dict(order_point=cam["pos"], direction_axes=axes))
-        nodes = fs.arrays["bvh_lists"][1]
-        k = 1 << bin(axes).count("1")
-        assert fs.arrays["bvh_list_axes"] == [0, axes] and fs.lists[1].direction_axes == axes and len(nodes) == k * n1
-        segs = nodes.reshape(k, n1)
-        ref_leaves = None
-        for g in range(k):
-            sg = np.ascontiguousarray(segs[g])
-            assert hostlib().atns_validate_nodes(sg.ctypes.data, n1) == (n1 + 1) // 2
-            inner = sg["f0"] < 0
-            assert np.all(sg["hit"][inner] == np.arange(n1)[inner] + 1)
-            boxes = sorted(map(tuple, np.concatenate([sg["boxmin"], sg["boxmax"], sg["f1"][:, None]], 1).tolist()))
-            if ref_leaves is None:
-                ref_leaves = boxes
-                assert np.array_equal(sg["boxmin"][0], base.arrays["bvh_lists"][1]["boxmin"][0])
-            else:
-                assert boxes == ref_leaves                       # the same nodes, only arranged differently
-        assert any(not np.array_equal(segs[0]["f1"], segs[g]["f1"]) for g in range(1, k))
-        got, st = orc.trace_closest(fs, rays)
-        same = (got["tri_id"] == want["tri_id"])
-        assert same.mean() > 0.9995 and np.allclose(got["t"], want["t"], rtol=1e-6, atol=0) and np.array_equal(got["objid"], want["objid"])
-        assert st[0] <= bound * st0[0], (axes, st[0] / st0[0])

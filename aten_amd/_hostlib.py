@@ -58,6 +58,8 @@ def hostlib():
         lib.atns_optimize_nodes.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(BvhOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                             C.POINTER(BvhStats)]
         lib.atns_optimize_nodes.restype = C.c_int
+        lib.atns_anyhit_twin.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.atns_anyhit_twin.restype = C.c_int
         lib.atns_build_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -105,6 +105,7 @@ public:
     bool fuse_traces = true;    // shadow(b) + closest(b+1) in one launch (k_trace_fused); ATEN_AMD_FUSE=0 disables (experiments)
     bool env_probe_streams = true;  // ATEN_AMD_PROBE_STREAMS=0: take the bank streams as the runtime hands them out
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
+    int env_anyhit_twin = 1;    // ATEN_AMD_ANYHIT_TWIN: 0 = no any-hit twins, 1 = where the model says they pay (scene_upload.hpp, kTwinPays), 2 = wherever possible
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_trace_blocks = 0;
     int env_shade_waves = 0;    // ATEN_AMD_SHADE_WAVES=4|5 forces the k_shade_wn flavour (default: 5 when frames are in flight, else 4)
@@ -124,6 +125,8 @@ public:
     DevScene scene{};
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
+    std::vector<int32_t> list_twin_delta;   // HostSceneImage::list_twin_delta: where each list's any-hit twin starts (0 = none)
+    std::vector<HostSceneImage::TlasRef> tlas_refs;     // the top layer's TLAS-leaf records and the lists they enter
     uint32_t top_base = 0, n_host_matrices = 0;
     std::vector<atn_mat4> host_matrices;    // the caller's matrices as last uploaded
     std::vector<uint32_t> list_base, list_bytes, list_tri_leaves, list_inner;   // region of every list in the node image
@@ -579,6 +582,7 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_SHADE_WAVES")) { const int v = std::atoi(e); if (v == 4 || v == 5) env_shade_waves = v; }   // else: by frames in flight
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("ATEN_AMD_PROBE_STREAMS")) env_probe_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -632,7 +636,8 @@ public:
         drop_alt_set(); cur_set = 0; scene_in_place = false; frame_since_update = true;
         HostSceneImage img;
         std::string err;
-        if (!build_host_image(img, s, err)) return fail(ATN_ERR_UNSUPPORTED, err);
+        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));   // (read per upload: tests switch it)
+        if (!build_host_image(img, s, err, env_anyhit_twin)) return fail(ATN_ERR_UNSUPPORTED, err);
         ATN_HIP(nodes.upload(img.nodes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));
@@ -674,7 +679,7 @@ public:
             int orc = apply_sampling_options();
             if (orc) return orc;
         }
-        list_root_link = img.list_root_link;
+        list_root_link = img.list_root_link; list_twin_delta = img.list_twin_delta; tlas_refs = img.tlas_refs;
         list_base = img.list_root; list_bytes = img.list_bytes; list_tri_leaves = img.list_tri_leaves; list_inner = img.list_inner;
         n_scene_tris = s->n_triangles; n_scene_vtx = s->n_vertices; n_scene_mtrls = s->n_materials;
         top_base = img.list_root[0];        // byte offset of the top layer's first record (the image's tail)
@@ -756,6 +761,9 @@ public:
         c.objects = objs; c.n_objects = n_objs; c.n_matrices = n_mtxs ? n_mtxs : n_host_matrices;
         c.matrices = n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr);
         c.list_root_link = list_root_link.data(); c.n_lists = (uint32_t)list_root_link.size();
+        c.list_twin_delta = list_twin_delta.size() == list_root_link.size() ? list_twin_delta.data() : nullptr;
+        std::vector<HostSceneImage::TlasRef> new_refs;
+        c.tlas_refs = &new_refs;
         const size_t top_bytes = lay.order.size() * (size_t)kInnerBytes;
         std::vector<float4> rec(top_bytes / 16 + 1, make_float4(0, 0, 0, 0));
         int32_t root = kLinkEnd;
@@ -795,6 +803,7 @@ public:
         if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; host_matrices.assign(mtxs, mtxs + n_mtxs); }
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
+        tlas_refs.swap(new_refs);
         scene.root_link = root;
         fill_root_direct(scene, rec.data(), top_base, n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr), n_mtxs ? n_mtxs : n_host_matrices);
         scene.node_bytes = (uint32_t)(top_base + top_bytes);
@@ -945,7 +954,22 @@ public:
         if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
-        { int r = begin_scene_update(0); if (r) return r; }
+        // The list's any-hit twin (scene_upload.hpp) is a threading of the tree that is about to be replaced: it is switched off --
+        // the twin word of every TLAS leaf that enters this list becomes 0 -- and stays off until the next full upload.
+        const bool drop_twin = list < list_twin_delta.size() && list_twin_delta[list] != 0;
+        size_t n_patch = 0;
+        if (drop_twin) for (const auto& r : tlas_refs) n_patch += r.list == list ? 1 : 0;
+        { int r = begin_scene_update(64 * n_patch + 64); if (r) return r; }
+        if (drop_twin) {
+            const int32_t zero = 0;
+            for (const auto& ref : tlas_refs) {
+                if (ref.list != list) continue;
+                { int r = stage_copy(reinterpret_cast<char*>(nodes.p) + ref.offset + 28u, &zero, 4); if (r) return r; }
+                log_range(SB_NODES, ref.offset + 16u, 16);
+            }
+            list_twin_delta[list] = 0;
+            if (scene.root_direct && (scene.root_blas & (int32_t)kLinkOffsetMask) == (int32_t)list_base[list]) scene.root_twin = 0;
+        }
         // a caller may have written the scene arrays in place (atn_scene_device_arrays): refresh this mesh's shading records
         { int r = repack_shade_tris(tri_offset, n); if (r) return r; }
         { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list], upd); if (r) return r; }

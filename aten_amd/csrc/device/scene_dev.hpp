@@ -23,7 +23,10 @@ namespace atn {
 //                     flags bit 0 (kTlasIdentity): W2L is bit for bit the identity matrix, so the ray inside this instance is the SAME
 //                     for every such instance -- mat4::applyRay(I, ray), which is not the world ray: the direction is re-normalised --
 //                     and the plain walk over an LDS copy computes it once per ray (DevScene::ident_row, traverse.hpp)
-//                     q1 = {meshid, top hit link, top miss link, 0}
+//                     q1 = {meshid, top hit link, top miss link, twin}
+//                     twin (0 = none): byte distance from the BLAS root record to the root of the list's ANY-HIT TWIN -- the same
+//                     tree threaded in the child order an any-hit walk is expected to finish sooner in (host/anyhit_twin.hpp; an
+//                     any-hit walk's answer does not depend on the order).  Shadow rays enter there, closest-hit rays never.
 //   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
 //              path); an inner record whose hit link IS its miss link.
 constexpr int32_t kLinkEnd = -1;
@@ -127,6 +130,7 @@ struct DevScene {
     // The top layer is ONE leaf (a scene = one instance: sponza, the atrium): its record, so that a walk can start INSIDE the nested
     // tree (walk_start) instead of standing on the leaf through its first burst.  root_direct = 0: walks start at root_link.
     int32_t root_direct, root_objid, root_meshid, root_w2l, root_blas, root_flags;
+    int32_t root_twin;                  // that leaf's twin word (TLAS leaf record, above)
     float root_m[12];                   // rows 0..2 of that instance's W2L (root_w2l >= 0): kernel arguments, i.e. scalar registers -- no loads at a refill
     // optional samplers, off by default (they leave the parity path of aten::PathTracing; atn_set_sampling_options):
     const float* ibl_cdf_v;             // ImageBasedLight::preCompute's tables of the environment map (light/ibl.cpp:10-118)

@@ -215,7 +215,8 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
             slab_setup(w.ray, w.wray.org, w.wray.dir);
         }
         w.lray = w.ray;
-        w.node = sc.root_blas; w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
+        w.node = sc.root_blas + (stop_t == kInf ? sc.root_twin : 0);        // any-hit rays walk the list's twin (scene_dev.hpp)
+        w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         return;
     }
     slab_setup(w.wray, mk3(a), mk3(b));
@@ -354,7 +355,8 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
                 w.ray = w.wray;
             }
             is_hit = true;
-            w.node = __float_as_int(q0.z);      // BLAS root link (never kLinkEnd: empty lists are rejected at upload)
+            // BLAS root link (never kLinkEnd: empty lists are rejected at upload); any-hit rays (stop_t = +inf, Job::fetch): the root of the list's twin
+            w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);
             ended = false;
         }
     }
@@ -425,7 +427,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
                 w.ray = w.wray;
             }
             is_hit = true;
-            w.node = __float_as_int(q0.z);      // BLAS root link
+            w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);      // BLAS root link (any-hit rays: the twin's)
         }
         if (w.node == kLinkEnd) {
             // leave the bottom layer (top_* are kLinkEnd inside the top layer)
@@ -546,7 +548,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     w.ray = w.wray;
                 }
                 is_hit = true;
-                w.node = __float_as_int(q0.z);      // BLAS root link
+                w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);      // BLAS root link (any-hit rays: the twin's)
             }
             if (w.node == kLinkEnd) {
                 // leave the bottom layer (top_* are kLinkEnd inside the top layer)

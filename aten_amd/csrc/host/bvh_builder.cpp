@@ -29,6 +29,7 @@
 //   * TLAS leaf  : f0 = instance object id, f1 = -1, f2 = exid bit-field punned to float,
 //                  f3 = mesh id, hit == miss == next (src/libaten/accelerator/threaded_bvh.cpp:212-246,266-279)
 #include "../../../include/aten_amd_scene.h"
+#include "anyhit_twin.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -909,6 +910,24 @@ int atns_build_tlas(const float* boxes, const int32_t* object_ids, const int32_t
         }
         *out_nodes = nodes;
         *out_count = (uint32_t)b.nodes.size();
+        return 0;
+    }
+    catch (const std::bad_alloc&) { return -3; }
+    catch (...) { return -5; }
+}
+
+int atns_anyhit_twin(const atn_bvh_node* nodes, uint32_t count, atn_bvh_node** out_nodes, double* out_cost_as_given, double* out_cost_twin)
+{
+    if (!nodes || !out_nodes) return -1;
+    try {
+        atn::AnyhitTwin tw;
+        if (!atn::make_anyhit_twin(nodes, count, tw)) return -4;
+        atn_bvh_node* o = (atn_bvh_node*)std::malloc(sizeof(atn_bvh_node) * tw.nodes.size());
+        if (!o) return -3;
+        std::memcpy(o, tw.nodes.data(), sizeof(atn_bvh_node) * tw.nodes.size());
+        *out_nodes = o;
+        if (out_cost_as_given) *out_cost_as_given = tw.cost_as_given;
+        if (out_cost_twin) *out_cost_twin = tw.cost_twin;
         return 0;
     }
     catch (const std::bad_alloc&) { return -3; }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../device/scene_dev.hpp"
+#include "anyhit_twin.hpp"
 
 namespace atn {
 
@@ -16,6 +17,9 @@ struct HostSceneImage {
     std::vector<uint32_t> list_root;    // byte offset of each list's first record
     std::vector<int32_t> list_root_link; // typed link of each list's root
     std::vector<uint32_t> list_bytes;   // bytes of each list's contiguous region starting at list_root
+    std::vector<int32_t> list_twin_delta; // byte distance from a bottom-level list's root record to the root of its any-hit twin (anyhit_twin.hpp), 0 = none
+    struct TlasRef { uint32_t offset, list; };
+    std::vector<TlasRef> tlas_refs;     // every TLAS-leaf record (byte offset) and the list it enters: where a twin is switched off later (LBVH rebuild)
     std::vector<uint32_t> list_tri_leaves, list_inner;  // record counts of each list
     std::vector<atn_triangle_param> tris;
     std::vector<float4> vtx_pos, vtx_nml;
@@ -118,6 +122,8 @@ struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
     const atn_triangle_param* tris = nullptr; const atn_vec4* vtx_pos = nullptr; uint32_t n_triangles = 0, n_vertices = 0;
     const int32_t* list_root_link = nullptr; uint32_t n_lists = 0;     // typed link of list k's root; kLinkEnd = empty list
+    const int32_t* list_twin_delta = nullptr;       // HostSceneImage::list_twin_delta (null: no twins)
+    std::vector<HostSceneImage::TlasRef>* tlas_refs = nullptr;     // out (optional)
     const atn_mat4* matrices = nullptr;     // the matrices the TLAS leaves' rows index (null: identity instances are not recognised)
     mutable int32_t ident_row = -1;         // out: w2l_row of an instance whose W2L is bit for bit the identity
 };
@@ -134,7 +140,7 @@ inline bool is_exact_identity(const atn_mat4& m)
 inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias, const atn_mat4* matrices = nullptr, uint32_t n_matrices = 0)
 {
     for (float& v : p.root_m) v = 0.0F;
-    p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0;
+    p.root_direct = 0; p.root_objid = -1; p.root_meshid = -1; p.root_w2l = -1; p.root_blas = kLinkEnd; p.root_flags = 0; p.root_twin = 0;
     if (p.root_link == kLinkEnd || p.root_link >= 0 || (p.root_link & kLinkTypeMask) != kLinkTlasBit) return;
     const uint32_t off = (uint32_t)p.root_link & kLinkOffsetMask;
     if (off < bias) return;
@@ -144,6 +150,7 @@ inline void fill_root_direct(DevScene& p, const float4* image, uint32_t bias, co
     p.root_direct = 1;
     p.root_objid = f2i(q[0].x); p.root_w2l = f2i(q[0].y); p.root_blas = f2i(q[0].z); p.root_flags = f2i(q[0].w);
     p.root_meshid = f2i(q[1].x);
+    p.root_twin = f2i(q[1].w);
     if (p.root_w2l >= 0) {
         const uint32_t mi = (uint32_t)p.root_w2l / 4u;
         if (!matrices || mi >= n_matrices) { p.root_direct = 0; return; }      // (no host copy of the matrices: walks start at root_link)
@@ -194,7 +201,8 @@ inline bool emit_list(char* img, const ListLayout& L, const atn_bvh_node* src, c
             int32_t flags = 0;
             if (w2l_row >= 0 && c.matrices && is_exact_identity(c.matrices[obj.mtx_id + 1])) { flags |= kTlasIdentity; if (c.ident_row < 0) c.ident_row = w2l_row; }
             q[0] = make_float4(i2f(objid), i2f(w2l_row), i2f(c.list_root_link[exid]), i2f(flags));
-            q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), 0.0F);
+            q[1] = make_float4(i2f((int32_t)nd.f3), i2f(h), i2f(m), i2f(c.list_twin_delta ? c.list_twin_delta[exid] : 0));
+            if (c.tlas_refs) c.tlas_refs->push_back({ L.offset[j], (uint32_t)exid });
             counts[2]++;
             break;
         }
@@ -252,22 +260,34 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
 //  * every list in walk order (locality; the links are explicit, so correctness does not depend on it)
 //  * the top layer comes last so that update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it
 //    without moving the others; top-layer records are all kInnerBytes long.
-inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err)
+// anyhit_twins: 0 = none; 1 = for the bottom-level lists whose twin the surface-area model expects to cost an any-hit walk at most
+// kTwinPays of what the list as given costs it (the second copy takes cache: measured +3 % per frame where it saves no visits, -5 %
+// where it saves a quarter of them, profiles/r05_variants_direction_lists.txt); 2 = for every list that can have one.
+constexpr double kTwinPays = 0.95;
+inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err, int anyhit_twins = 0)
 {
     if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
     const uint32_t nl = s->n_bvh_lists;
     std::string range_err;
     if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
 
-    std::vector<ListLayout> lay(nl);
+    std::vector<ListLayout> lay(nl), twin_lay(nl);
+    std::vector<std::vector<atn_bvh_node>> twin(nl);    // the any-hit twin of list k as a threaded list of its own (empty: none)
     uint64_t total_nodes = 0;
     for (uint32_t k = 0; k < nl; k++) {
         if (!analyse_list(lay[k], s->bvh_lists[k].nodes, s->bvh_lists[k].count, k == 0, err)) return false;
         total_nodes += lay[k].order.size();
+        if (k == 0 || !anyhit_twins || lay[k].order.size() != s->bvh_lists[k].count) continue;
+        AnyhitTwin tw;
+        if (!make_anyhit_twin(s->bvh_lists[k].nodes, s->bvh_lists[k].count, tw)) continue;
+        if (anyhit_twins == 1 && !(tw.cost_twin <= kTwinPays * tw.cost_as_given)) continue;
+        std::string twin_err;
+        if (!analyse_list(twin_lay[k], tw.nodes.data(), (uint32_t)tw.nodes.size(), false, twin_err)) continue;
+        twin[k].swap(tw.nodes);
     }
     uint64_t off = 0;
     img.list_root.assign(nl, 0);
-    img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0);
+    img.list_bytes.assign(nl, 0); img.list_tri_leaves.assign(nl, 0); img.list_inner.assign(nl, 0); img.list_twin_delta.assign(nl, 0);
     for (uint32_t kk = 1; kk <= nl; kk++) {
         const uint32_t k = kk % nl;         // 1, 2, ..., nl-1, 0
         img.list_root[k] = (uint32_t)off;
@@ -281,6 +301,13 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             off += record_bytes(lay[k].kind[j]);
         }
         img.list_bytes[k] = (uint32_t)(off - img.list_root[k]);
+        if (!twin[k].empty()) {
+            // the twin's records follow the list's own (not part of list_bytes: the list's region is what an LBVH rebuild rewrites);
+            // both roots are the same record kind, so the twin's typed root link is the list's plus the distance
+            if (twin_lay[k].kind[0] != lay[k].kind[0] || off + (uint64_t)img.list_bytes[k] >= (1ull << 31)) { twin[k].clear(); continue; }
+            img.list_twin_delta[k] = (int32_t)(off - img.list_root[k]);
+            for (uint32_t j = 0; j < twin_lay[k].order.size(); j++) { twin_lay[k].offset[j] = (uint32_t)off; off += record_bytes(twin_lay[k].kind[j]); }
+        }
     }
     if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
     img.nodes.assign((size_t)(off / 16), make_float4(0, 0, 0, 0));
@@ -292,12 +319,21 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     c.tris = s->triangles; c.vtx_pos = s->vtx_pos; c.n_triangles = s->n_triangles; c.n_vertices = s->n_vertices;
     c.n_lists = nl;
     uint64_t counts[3] = { 0, 0, 0 };
+    img.tlas_refs.clear();
     for (uint32_t kk = 1; kk <= nl; kk++) {
         const uint32_t k = kk % nl;
         c.list_root_link = img.list_root_link.data();
+        c.list_twin_delta = img.list_twin_delta.data();
+        c.tlas_refs = &img.tlas_refs;
         int32_t root = kLinkEnd;
         if (!emit_list(reinterpret_cast<char*>(img.nodes.data()), lay[k], s->bvh_lists[k].nodes, c, root, counts, err)) return false;
         img.list_root_link[k] = root;
+        if (!twin[k].empty()) {
+            int32_t twin_root = kLinkEnd;
+            uint64_t twin_counts[3] = { 0, 0, 0 };      // (not part of the scene's record statistics)
+            if (!emit_list(reinterpret_cast<char*>(img.nodes.data()), twin_lay[k], twin[k].data(), c, twin_root, twin_counts, err)) return false;
+            if (twin_root != root + img.list_twin_delta[k]) { err = "internal: any-hit twin root"; return false; }
+        }
     }
     img.n_inner = counts[0]; img.n_tri_leaf = counts[1]; img.n_tlas_leaf = counts[2];
     img.params.node_bytes = (uint32_t)off;

@@ -77,6 +77,14 @@ int atns_build_blas_opt(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
 int atns_optimize_nodes(const atn_bvh_node* nodes, uint32_t count, const atns_bvh_options* options,
                         atn_bvh_node** out_nodes, uint32_t* out_count, atns_bvh_stats* out_stats);
 
+/* The second threading the upload gives a bottom-level list for its shadow rays (csrc/host/anyhit_twin.hpp): the same tree -- boxes,
+ * leaves, parent-child relations -- with the two children of an inner node in the order an ANY-hit walk is expected to finish
+ * sooner in (surface-area model); out_cost_*: the model's expected cost of such a walk in the list as given and in the twin.  The
+ * answer of an any-hit walk does not depend on the order, so the integrator may use it without changing a result; exported for
+ * tools and tests.  *out_nodes: `count` nodes, malloc'ed (atns_free).  Returns 0, -1 (null), -3 (memory), -4 (`nodes` is not a binary
+ * tree in pre-order along its hit links: such a list gets no twin). */
+int atns_anyhit_twin(const atn_bvh_node* nodes, uint32_t count, atn_bvh_node** out_nodes, double* out_cost_as_given, double* out_cost_twin);
+
 /* Top-level tree over instances.  boxes: n * {min.xyz, max.xyz} (world space, already
  * transformed like aabb::transform in threaded_bvh.cpp:203-204); object_ids: transformable index
  * of each instance; blas_list_ids: index of the instance's node list (>= 1), or -1 for "no

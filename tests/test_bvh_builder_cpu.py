@@ -252,3 +252,72 @@ def test_post_passes_on_an_imported_tree(orc):
     bad = nodes.copy(); bad["miss"][0] = 1.0
     assert lib.atns_optimize_nodes(bad.ctypes.data, n, None, C.byref(o), C.byref(c), None) == -4
     assert lib.atns_optimize_nodes(None, n, None, C.byref(o), C.byref(c), None) == -1
+
+
+def _twin(nodes):
+    from aten_amd import layout as L
+    from aten_amd._hostlib import hostlib
+    lib = hostlib()
+    nodes = np.ascontiguousarray(nodes)
+    out = C.c_void_p(); a = C.c_double(); b = C.c_double()
+    rc = lib.atns_anyhit_twin(nodes.ctypes.data, len(nodes), C.byref(out), C.byref(a), C.byref(b))
+    if rc:
+        return rc, None, None, None
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(len(nodes) * 48,)).view(L.BVH_NODE).copy()
+    lib.atns_free(out)
+    return rc, res, a.value, b.value
+
+
+def test_anyhit_twin_is_the_same_tree_in_another_child_order():
+    """atns_anyhit_twin (csrc/host/anyhit_twin.hpp; what the upload gives a list for its any-hit rays): a valid threaded list in
+    pre-order with the SAME nodes -- every box and payload once -- and the same parent-child relations (an inner node keeps its two
+    children, only their order may change); the model's expected any-hit cost does not go up.  The reference-built sponza_lod.sbvh
+    is expected to gain (0.88), the atrium's regular grids and the Cornell box are not (> 0.95: they get no twin at upload); lists
+    that are not binary trees in pre-order are refused."""
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.builder import read_sbvh
+    from aten_amd._hostlib import hostlib
+    _, _, nodes = read_sbvh(os.path.join(ROOT, "assets", "sponza", "sponza_lod.sbvh"))
+    n = len(nodes)
+    rc, twin, given, cost = _twin(nodes)
+    assert rc == 0 and len(twin) == n and hostlib().atns_validate_nodes(twin.ctypes.data, n) == 19000
+    assert cost <= 0.9 * given and cost > 0.5 * given
+    leaf = twin["f0"] >= 0
+    idx = np.arange(n)
+    assert np.all(twin["hit"][~leaf] == idx[~leaf] + 1) and np.all(twin["hit"][leaf] == twin["miss"][leaf])
+    key = lambda a: sorted(map(tuple, np.concatenate([a["boxmin"], a["boxmax"], a["f0"][:, None], a["f1"][:, None], a["f2"][:, None], a["f3"][:, None]], 1).tolist()))
+    assert key(nodes) == key(twin)
+
+    def shape(a):
+        """The tree up to the order of siblings: hash(node) = hash(box, payload, {hash(child), hash(child)}), from the root"""
+        import sys
+        is_leaf = (a["f0"] >= 0) | (a["f1"] >= 0)
+        hit = a["hit"].astype(np.int64); miss = a["miss"].astype(np.int64)
+        raw = [a["boxmin"][j].tobytes() + a["boxmax"][j].tobytes() + np.float32([a["f0"][j], a["f1"][j], a["f2"][j], a["f3"][j]]).tobytes() for j in range(len(a))]
+        memo = {}
+        order = []
+        i = 0
+        while i >= 0:
+            order.append(i); i = int(hit[i])
+        for j in reversed(order):                                       # children come after their parent along the hit links
+            if is_leaf[j]:
+                memo[j] = hash(raw[j])
+            else:
+                first = int(hit[j])
+                second = int(hit[first]) if is_leaf[first] else int(miss[first])
+                memo[j] = hash((raw[j], frozenset([memo[first], memo[second]])))
+        return memo[0]
+    assert shape(nodes) == shape(twin)
+    assert not np.array_equal(nodes["f1"], twin["f1"])                  # ... and it IS another order
+    # the scenes the model says gain nothing
+    for fs in (scenedefs.atrium(detail=0.25)[0], scenedefs.cornell_box()[0]):
+        for lst in fs.arrays["bvh_lists"][1:]:
+            rc, _, given, cost = _twin(lst)
+            if rc == 0:
+                assert 0.95 * given < cost <= given * (1 + 1e-6)
+    # not a binary tree in pre-order: a backward link, an inner node whose first child's subtree ends where its own does
+    bad = nodes.copy(); bad["miss"][0] = 1.0
+    assert _twin(bad)[0] == -4
+    bad = nodes.copy(); bad["hit"][5] = 2.0
+    assert _twin(bad)[0] == -4
+    assert _twin(nodes[:1])[0] == -4

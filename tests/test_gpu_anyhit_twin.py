@@ -1,0 +1,138 @@
+"""The any-hit twin (csrc/host/anyhit_twin.hpp, scene_upload.hpp): at upload a bottom-level list may get a second threading of the
+same tree, in the child order an any-hit walk is expected to finish sooner in, and the rays that only ask "is anything in the way
+of an infinite light" (stop_t = +inf: IBL, directional) walk it.  The answer of such a walk does not depend on the order -- until the
+first accepted hit t_max is the constant the ray came with -- so every film must be BYTE-EQUAL to the one rendered without twins
+(ATEN_AMD_ANYHIT_TWIN=0), whatever the scene, walk flavour or update path; only the shadow rays' visit counters go down."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_camera
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    def __init__(self, **kw):
+        self.kw = kw
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            os.environ[k] = str(v)
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def _render(fs, c, w, h, twin, frames=(0, 3), depth=5, stats=False, flavour=None, lds=None):
+    from aten_amd.renderer import PathTracing
+    env = dict(ATEN_AMD_ANYHIT_TWIN=twin)
+    if flavour is not None: env["ATEN_AMD_TRACE"] = flavour
+    if lds is not None: env["ATEN_AMD_LDS_NODES"] = lds
+    with _Env(**env):
+        r = PathTracing(0)
+        try:
+            r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+            films = [r.render(w, h, depth, 3, frame=f, count_stats=stats).copy() for f in frames]
+            return films, (r.stats() if stats else None)
+        finally:
+            r.close()
+
+
+def test_headline_scene_films_are_byte_equal_and_shadow_walks_shorter(orc, sponza):
+    """The reference-built sponza_lod.sbvh with IBL (every shadow ray is an any-hit ray): films with and without the twin are the
+    same bytes; closest-hit visits, rays and hits are the same numbers; shadow-ray node visits fall by more than 15 %."""
+    fs, cam = sponza
+    w, h = 256, 144
+    c = make_camera(orc, cam, w, h)
+    a, sa = _render(fs, c, w, h, 0, stats=True)
+    b, sb = _render(fs, c, w, h, 1, stats=True)
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    for k in ("closest_rays", "shadow_rays", "hits", "closest_nodes", "closest_tris"):
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    assert sb["shadow_nodes"] < 0.85 * sa["shadow_nodes"], (sb["shadow_nodes"], sa["shadow_nodes"])
+    # the plain walk takes the same turn at the same place
+    p, _ = _render(fs, c, w, h, 1, flavour="s")
+    assert p[0].tobytes() == a[0].tobytes() and p[1].tobytes() == a[1].tobytes()
+
+
+def test_every_light_kind_and_every_way_into_a_nested_tree(orc):
+    """The Cornell variant with area + point + spot + directional lights (only the directional light's shadow rays are any-hit rays:
+    area lights need the closest hit's object, punctual ones its distance), twins forced onto every list (the model would give these
+    small trees none): identity and transformed instances behind a top layer, refill walk / plain walk / plain walk over an LDS copy."""
+    from aten_amd.scene import scenedefs
+    fs, cam = scenedefs.cornell_box_variant(lights="mixed")
+    w, h = 96, 96
+    c = make_camera(orc, cam, w, h)
+    want, s0 = _render(fs, c, w, h, 0, stats=True, flavour="s", lds="0")
+    for flavour, lds in (("r", "0"), ("s", "0"), ("s", "1")):
+        got, s2 = _render(fs, c, w, h, 2, stats=True, flavour=flavour, lds=lds)
+        assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes(), (flavour, lds)
+        assert s2["closest_nodes"] == s0["closest_nodes"] and s2["shadow_rays"] == s0["shadow_rays"]
+
+
+def test_a_rebuilt_list_loses_its_twin(orc):
+    """atn_lbvh_rebuild_list replaces the tree a twin was a threading of: the twin is switched off with it (every TLAS leaf that enters
+    the list), also with frames in flight, and the frames after the rebuild equal those of a context that never had twins."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.camera import create_camera
+    from test_gpu_lbvh import tick_data, push_tick
+    W, H = 160, 120
+    b, oid, cam = scenedefs.deformable_room(0.0)
+    env = scenedefs.synthetic_envmap(256, 128)
+    tid = b.add_texture("sky", env)
+    b.add_ibl(tid, avg_illum=scenedefs.envmap_avg_illum(env))                       # an infinite light: any-hit shadow rays
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    films = {}
+    for twin in (0, 2):
+        with _Env(ATEN_AMD_ANYHIT_TWIN=twin):
+            r = PathTracing(0)
+            try:
+                fs0, d0 = tick_data(b, oid, 0.0)
+                r.UpdateSceneData(fs0); r.updateCamera(c); r.initSampler(W, H, 0)
+                r.set_frames_in_flight(3)
+                out = [r.render(W, H, frame=0).copy()]
+                for f in range(1, 4):
+                    r.render(W, H, frame=f, download=False)                          # frames of the old tree still in flight
+                fs, d = tick_data(b, oid, 1.3)
+                push_tick(r, fs, d)
+                r.reset()
+                out.append(r.render(W, H, frame=7).copy())
+                fs, d = tick_data(b, oid, 2.2)
+                push_tick(r, fs, d)
+                r.reset()
+                out.append(r.render(W, H, frame=8).copy())
+                films[twin] = out
+            finally:
+                r.close()
+    for x, y in zip(films[0], films[2]):
+        assert x.tobytes() == y.tobytes()
+    assert films[0][0].tobytes() != films[0][1].tobytes()
+
+
+def test_top_layer_update_keeps_the_twins(orc):
+    """atn_update_tlas re-emits the TLAS leaves with their twin words: moving the instanced boxes gives the same bytes with and
+    without twins, and the same as a full upload of the moved scene."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    still, cam = scenedefs.cornell_box_variant(lights="mixed", move_boxes=False)
+    moved, _ = scenedefs.cornell_box_variant(lights="mixed", move_boxes=True)
+    w, h = 80, 80
+    c = make_camera(orc, cam, w, h)
+    want, _ = _render(moved, c, w, h, 0, frames=(2,))
+    for twin in (0, 2):
+        with _Env(ATEN_AMD_ANYHIT_TWIN=twin):
+            r = PathTracing(0)
+            try:
+                r.UpdateSceneData(still); r.updateCamera(c); r.initSampler(w, h, 0)
+                base = r.render(w, h, 5, 3, frame=2).copy()
+                r.updateBVH(moved); r.reset()
+                assert r.render(w, h, 5, 3, frame=2).tobytes() == want[0].tobytes()
+                r.updateBVH(still); r.reset()
+                assert r.render(w, h, 5, 3, frame=2).tobytes() == base.tobytes()
+            finally:
+                r.close()

@@ -1934,6 +1934,12 @@ void* atn_svgf_output_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.sv_out.p
 void* atn_film_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.film.p : nullptr; }
 void* atn_tile_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.tile_out.p : nullptr; }
 uint32_t atn_tile_slots(atn_ctx* ctx) { return ctx ? ctx->r.n_slots : 0; }
+uint32_t atn_anyhit_twins(atn_ctx* ctx)
+{
+    uint32_t n = 0;
+    if (ctx) for (const int32_t d : ctx->r.list_twin_delta) n += d != 0 ? 1u : 0u;
+    return n;
+}
 void* atn_stream(atn_ctx* ctx) { return ctx ? (void*)ctx->r.stream : nullptr; }
 void* atn_side_stream(atn_ctx* ctx)
 {

@@ -192,6 +192,10 @@ class PathTracing:
         self._check(self._l.atn_download_path_cost(self._ctx, out.ctypes.data))
         return out
 
+    def anyhit_twins(self):
+        """atn_anyhit_twins: bottom-level lists that have an any-hit twin right now."""
+        return int(self._l.atn_anyhit_twins(self._ctx))
+
     def stats(self):
         s = np.zeros(8, np.uint64)
         self._check(self._l.atn_get_stats(self._ctx, s.ctypes.data))

@@ -135,6 +135,11 @@ int atn_reset(atn_ctx* ctx);
 /* Device-side results of the last atn_render (valid until the next call on ctx). */
 void* atn_film_device(atn_ctx* ctx);            /* float4[width*height]; only this rank's pixels are written */
 void* atn_tile_device(atn_ctx* ctx);            /* float4[atn_tile_slots]: this rank's pixels in slot order */
+/* How many bottom-level lists of the uploaded scene have an any-hit twin right now (csrc/host/anyhit_twin.hpp: a second threading
+ * of the same tree that the shadow rays of infinite lights walk; results do not depend on it).  ATEN_AMD_ANYHIT_TWIN = 0 / 1 / 2 at
+ * upload: none / where the surface-area model expects it to pay (default) / wherever a list is a binary tree.  An LBVH rebuild of a
+ * list drops its twin. */
+uint32_t atn_anyhit_twins(atn_ctx* ctx);
 uint32_t atn_tile_slots(atn_ctx* ctx);          /* identical on every rank: ceil(n_tiles / world) * 64 */
 void* atn_stream(atn_ctx* ctx);                 /* hipStream_t all work is enqueued on */
 int atn_synchronize(atn_ctx* ctx);

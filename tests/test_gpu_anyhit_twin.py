@@ -35,8 +35,12 @@ def _render(fs, c, w, h, twin, frames=(0, 3), depth=5, stats=False, flavour=None
         r = PathTracing(0)
         try:
             r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+            n_lists = len(fs.arrays["bvh_lists"]) - 1
+            assert r.anyhit_twins() <= n_lists and (twin != 0 or r.anyhit_twins() == 0) and (twin != 2 or r.anyhit_twins() >= 1)
             films = [r.render(w, h, depth, 3, frame=f, count_stats=stats).copy() for f in frames]
-            return films, (r.stats() if stats else None)
+            st = r.stats() if stats else None
+            if st is not None: st["twins"] = r.anyhit_twins()
+            return films, st
         finally:
             r.close()
 
@@ -54,6 +58,7 @@ def test_headline_scene_films_are_byte_equal_and_shadow_walks_shorter(orc, sponz
     for k in ("closest_rays", "shadow_rays", "hits", "closest_nodes", "closest_tris"):
         assert sa[k] == sb[k], (k, sa[k], sb[k])
     assert sb["shadow_nodes"] < 0.85 * sa["shadow_nodes"], (sb["shadow_nodes"], sa["shadow_nodes"])
+    assert sa["twins"] == 0 and sb["twins"] == 1
     # the plain walk takes the same turn at the same place
     p, _ = _render(fs, c, w, h, 1, flavour="s")
     assert p[0].tobytes() == a[0].tobytes() and p[1].tobytes() == a[1].tobytes()
@@ -99,7 +104,9 @@ def test_a_rebuilt_list_loses_its_twin(orc):
                 for f in range(1, 4):
                     r.render(W, H, frame=f, download=False)                          # frames of the old tree still in flight
                 fs, d = tick_data(b, oid, 1.3)
+                n_before = r.anyhit_twins()
                 push_tick(r, fs, d)
+                assert r.anyhit_twins() == (n_before - 1 if twin else 0)                 # the rebuilt list's twin is gone
                 r.reset()
                 out.append(r.render(W, H, frame=7).copy())
                 fs, d = tick_data(b, oid, 2.2)

@@ -106,6 +106,7 @@ public:
     bool env_probe_streams = true;  // ATEN_AMD_PROBE_STREAMS=0: take the bank streams as the runtime hands them out
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     int env_anyhit_twin = 1;    // ATEN_AMD_ANYHIT_TWIN: 0 = no any-hit twins, 1 = where the model says they pay (scene_upload.hpp, kTwinPays), 2 = wherever possible
+    int env_anyhit_twin_dirs = 8;   // ATEN_AMD_ANYHIT_TWIN_DIRS: 8 = one twin per direction octant (default), 1 = the one direction-free twin
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_trace_blocks = 0;
     int env_shade_waves = 0;    // ATEN_AMD_SHADE_WAVES=4|5 forces the k_shade_wn flavour (default: 5 when frames are in flight, else 4)
@@ -637,7 +638,8 @@ public:
         HostSceneImage img;
         std::string err;
         if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));   // (read per upload: tests switch it)
-        if (!build_host_image(img, s, err, env_anyhit_twin)) return fail(ATN_ERR_UNSUPPORTED, err);
+        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN_DIRS")) env_anyhit_twin_dirs = std::atoi(e) == 1 ? 1 : 8;
+        if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs)) return fail(ATN_ERR_UNSUPPORTED, err);
         ATN_HIP(nodes.upload(img.nodes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));

@@ -24,9 +24,10 @@ namespace atn {
 //                     for every such instance -- mat4::applyRay(I, ray), which is not the world ray: the direction is re-normalised --
 //                     and the plain walk over an LDS copy computes it once per ray (DevScene::ident_row, traverse.hpp)
 //                     q1 = {meshid, top hit link, top miss link, twin}
-//                     twin (0 = none): byte distance from the BLAS root record to the root of the list's ANY-HIT TWIN -- the same
-//                     tree threaded in the child order an any-hit walk is expected to finish sooner in (host/anyhit_twin.hpp; an
-//                     any-hit walk's answer does not depend on the order).  Shadow rays enter there, closest-hit rays never.
+//                     twin (0 = none): byte distance from the BLAS root record to the root of the list's first ANY-HIT TWIN -- the
+//                     same tree threaded in a child order an any-hit walk is expected to finish sooner in (host/anyhit_twin.hpp; an
+//                     any-hit walk's answer does not depend on the order); bit 0: eight twins, one per octant of the ray's direction,
+//                     each as long as the list (traverse.hpp: anyhit_root).  Rays with stop_t = +inf enter there, no other ray does.
 //   dead leaf (32 B): a leaf with neither triangle nor nested tree (sphere instance: never tested on this
 //              path); an inner record whose hit link IS its miss link.
 constexpr int32_t kLinkEnd = -1;

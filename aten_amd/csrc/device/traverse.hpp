@@ -181,6 +181,18 @@ struct Walk {
     int32_t node, objid, meshid, top_hit, top_miss;
 };
 
+// The root an any-hit ray enters a nested tree at (scene_dev.hpp, TLAS leaf `twin` word: distance to the list's first any-hit twin,
+// which is the size of the list and of every twin; bit 0: eight twins back to back, one per octant of the ray's direction inside the
+// instance -- bit a = dir[a] > 0).  Any twin is a threading of the same tree and an any-hit walk's answer is the same in all of
+// them: which one a ray takes only decides how soon it meets its occluder.
+ATN_DEV int32_t anyhit_root(int32_t root, int32_t twin, const f3& d)
+{
+    const int32_t delta = twin & ~15;
+    int32_t r = root + delta;
+    if (twin & 1) r += (int32_t)((d.x > 0.0F ? 1u : 0u) | (d.y > 0.0F ? 2u : 0u) | (d.z > 0.0F ? 4u : 0u)) * delta;
+    return r;
+}
+
 // IDENT (the plain walk over an LDS copy of a small scene): instances whose W2L is bit for bit the identity matrix (TLAS-leaf flag
 // kTlasIdentity, set at upload) all see the SAME local ray -- mat4::applyRay(I, ray): the origin through the matrix product, the
 // direction re-normalised, NOT the world ray -- so it is computed here once per ray, with every lane of the wave taking part, instead
@@ -215,7 +227,7 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
             slab_setup(w.ray, w.wray.org, w.wray.dir);
         }
         w.lray = w.ray;
-        w.node = sc.root_blas + (stop_t == kInf ? sc.root_twin : 0);        // any-hit rays walk the list's twin (scene_dev.hpp)
+        w.node = stop_t == kInf ? anyhit_root(sc.root_blas, sc.root_twin, w.ray.dir) : sc.root_blas;        // any-hit rays walk the list's twin (scene_dev.hpp)
         w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         return;
     }
@@ -356,7 +368,7 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             }
             is_hit = true;
             // BLAS root link (never kLinkEnd: empty lists are rejected at upload); any-hit rays (stop_t = +inf, Job::fetch): the root of the list's twin
-            w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);
+            w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);
             ended = false;
         }
     }
@@ -427,7 +439,7 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
                 w.ray = w.wray;
             }
             is_hit = true;
-            w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);      // BLAS root link (any-hit rays: the twin's)
+            w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);      // BLAS root link (any-hit rays: the twin's)
         }
         if (w.node == kLinkEnd) {
             // leave the bottom layer (top_* are kLinkEnd inside the top layer)
@@ -548,7 +560,7 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     w.ray = w.wray;
                 }
                 is_hit = true;
-                w.node = __float_as_int(q0.z) + (w.stop_t == kInf ? __float_as_int(q1.w) : 0);      // BLAS root link (any-hit rays: the twin's)
+                w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);      // BLAS root link (any-hit rays: the twin's)
             }
             if (w.node == kLinkEnd) {
                 // leave the bottom layer (top_* are kLinkEnd inside the top layer)

@@ -37,7 +37,11 @@ constexpr float kAnyhitLeafCost = 3.0f;     // a triangle test against a box tes
 
 // false: `src` is not a binary tree in pre-order along its hit links (nothing is written); the walk itself accepts more
 // general lists (scene_upload.hpp: analyse_list), those simply get no twin.
-inline bool make_anyhit_twin(const atn_bvh_node* src, uint32_t count, AnyhitTwin& out)
+// dir_sign (optional): the twin for the any-hit rays that travel with these signs (+1 / -1 per axis): where the EXIT faces of the two
+// children along that direction lie more than dir_tolerance of the node's extent apart, the child that reaches further comes first
+// (back to front: what blocks a ray that leaves a surface lies far along it, profiles/r05_variants_direction_lists.txt); elsewhere
+// the model decides as in the direction-free twin.
+inline bool make_anyhit_twin(const atn_bvh_node* src, uint32_t count, AnyhitTwin& out, const int* dir_sign = nullptr, float dir_tolerance = 0.05f)
 {
     if (!src || count < 3) return false;
     // pre-order along the hit links; a subtree ends where the miss link points
@@ -103,6 +107,17 @@ inline bool make_anyhit_twin(const atn_bvh_node* src, uint32_t count, AnyhitTwin
         dg[j] = vg[0] + (1.0f - p[0]) * vg[1];
         const float ab = vt[0] + (1.0f - p[0]) * vt[1], ba = vt[1] + (1.0f - p[1]) * vt[0];
         flip[j] = ba < ab ? 1 : 0;
+        if (dir_sign) {
+            const atn_bvh_node& na = src[order[c[0]]]; const atn_bvh_node& nb = src[order[c[1]]]; const atn_bvh_node& nn = src[order[j]];
+            float ea = 0, eb = 0, ext = 0;
+            for (int a = 0; a < 3; a++) {
+                if (dir_sign[a] > 0) { ea += na.boxmax[a]; eb += nb.boxmax[a]; }
+                else { ea -= na.boxmin[a]; eb -= nb.boxmin[a]; }
+                ext += nn.boxmax[a] - nn.boxmin[a];
+            }
+            if (eb - ea > dir_tolerance * ext) flip[j] = 1;
+            else if (ea - eb > dir_tolerance * ext) flip[j] = 0;
+        }
         dt[j] = flip[j] ? ba : ab;
         out.flipped += flip[j];
     }

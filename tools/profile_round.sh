@@ -13,6 +13,8 @@ bash tools/pmc_collect.sh "$OUT/pmc" "1 2 3 4 5 6 7" "$@" > "$OUT/pmc.log" 2>&1
 python tools/pmc_to_json.py "$OUT/pmc" "$WORKLOAD" > "profiles/${TAG}_counters_${NAME}.json"
 cp "profiles/${TAG}_counters_${NAME}.json" "$OUT/"
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/${TAG}_${NAME}_pmc.txt"
+# the raw per-dispatch CSVs (tens of MB for the 4K config) have been reduced to the two files above: gpurun_out/ travels back only below 64 MiB
+find "$OUT/pmc" -mindepth 1 -maxdepth 1 -type d -name 'pass*' -exec rm -rf {} +
 (cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" > "$OUT/prof.log" 2>&1)
 DB=$(find "$OUT/prof" -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" > "$OUT/${TAG}_${NAME}_kernel_stats.txt"

@@ -1323,6 +1323,13 @@ public:
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<true, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<true, false>), gr, tb, lds, st, pb, scene, bs, bc, b);
                         }
+                        else if (b == 0) {
+                            // only closest-hit rays (there is no bounce -1 to cast shadows): the closest-hit kernel is the same walk
+                            // without the shadow job's code in it (every ray's stop_t is a constant there; the fused kernel's plain
+                            // flavour grew by the any-hit twins' root selection: primary rays 0.168 -> 0.203 ms per frame, back at
+                            // 0.168 through this launch)
+                            hipLaunchKernelGGL((k_trace_closest<false, false>), gr, tb, lds, st, pb, scene, 0);
+                        }
                         else {
                             if (scene.any_alpha) hipLaunchKernelGGL((k_trace_fused<false, true>), gr, tb, lds, st, pb, scene, bs, bc, b);
                             else hipLaunchKernelGGL((k_trace_fused<false, false>), gr, tb, lds, st, pb, scene, bs, bc, b);

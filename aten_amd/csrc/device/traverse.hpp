@@ -188,9 +188,8 @@ struct Walk {
 ATN_DEV int32_t anyhit_root(int32_t root, int32_t twin, const f3& d)
 {
     const int32_t delta = twin & ~15;
-    int32_t r = root + delta;
-    if (twin & 1) r += (int32_t)((d.x > 0.0F ? 1u : 0u) | (d.y > 0.0F ? 2u : 0u) | (d.z > 0.0F ? 4u : 0u)) * delta;
-    return r;
+    const uint32_t octant = (d.x > 0.0F ? 1u : 0u) | (d.y > 0.0F ? 2u : 0u) | (d.z > 0.0F ? 4u : 0u);
+    return root + delta + (int32_t)((twin & 1) ? octant : 0u) * delta;
 }
 
 // IDENT (the plain walk over an LDS copy of a small scene): instances whose W2L is bit for bit the identity matrix (TLAS-leaf flag
@@ -227,7 +226,8 @@ ATN_DEV void walk_start(Walk& w, const DevScene& sc, const float4& a, const floa
             slab_setup(w.ray, w.wray.org, w.wray.dir);
         }
         w.lray = w.ray;
-        w.node = stop_t == kInf ? anyhit_root(sc.root_blas, sc.root_twin, w.ray.dir) : sc.root_blas;        // any-hit rays walk the list's twin (scene_dev.hpp)
+        w.node = sc.root_blas;
+        if (sc.root_twin != 0 && stop_t == kInf) w.node = anyhit_root(sc.root_blas, sc.root_twin, w.ray.dir);       // any-hit rays walk a twin (scene_dev.hpp)
         w.objid = sc.root_objid; w.meshid = sc.root_meshid; w.top_hit = kLinkEnd; w.top_miss = kLinkEnd;
         return;
     }
@@ -368,7 +368,8 @@ ATN_DEV void walk_iteration(Walk& w, bool& all_finite, const DevScene& sc, const
             }
             is_hit = true;
             // BLAS root link (never kLinkEnd: empty lists are rejected at upload); any-hit rays (stop_t = +inf, Job::fetch): the root of the list's twin
-            w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);
+            w.node = __float_as_int(q0.z);
+            if (w.stop_t == kInf && __float_as_int(q1.w) != 0) w.node = anyhit_root(w.node, __float_as_int(q1.w), w.ray.dir);
             ended = false;
         }
     }
@@ -439,7 +440,8 @@ ATN_DEV void walk_run(Walk& w, const DevScene& sc, const char* __restrict__ nb, 
                 w.ray = w.wray;
             }
             is_hit = true;
-            w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);      // BLAS root link (any-hit rays: the twin's)
+            w.node = __float_as_int(q0.z);
+            if (w.stop_t == kInf && __float_as_int(q1.w) != 0) w.node = anyhit_root(w.node, __float_as_int(q1.w), w.ray.dir);      // BLAS root link (any-hit rays: the twin's)
         }
         if (w.node == kLinkEnd) {
             // leave the bottom layer (top_* are kLinkEnd inside the top layer)
@@ -560,7 +562,8 @@ ATN_DEV void trace_simple(const DevScene& sc, uint32_t count, const Job& job, Tr
                     w.ray = w.wray;
                 }
                 is_hit = true;
-                w.node = w.stop_t == kInf ? anyhit_root(__float_as_int(q0.z), __float_as_int(q1.w), w.ray.dir) : __float_as_int(q0.z);      // BLAS root link (any-hit rays: the twin's)
+                w.node = __float_as_int(q0.z);
+            if (w.stop_t == kInf && __float_as_int(q1.w) != 0) w.node = anyhit_root(w.node, __float_as_int(q1.w), w.ray.dir);      // BLAS root link (any-hit rays: the twin's)
             }
             if (w.node == kLinkEnd) {
                 // leave the bottom layer (top_* are kLinkEnd inside the top layer)

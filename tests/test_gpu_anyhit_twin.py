@@ -146,3 +146,19 @@ def test_top_layer_update_keeps_the_twins(orc):
                 assert r.render(w, h, 5, 3, frame=2).tobytes() == base.tobytes()
             finally:
                 r.close()
+
+
+def test_screen_shards_with_twins_equal_one_context_without(orc, sponza):
+    """atn_mgpu_*: every shard uploads its own replica -- with twins -- and the assembled film is the film of one context without."""
+    from aten_amd.renderer import MultiGpuPathTracing
+    fs, cam = sponza
+    w, h = 192, 108
+    c = make_camera(orc, cam, w, h)
+    want, _ = _render(fs, c, w, h, 0, frames=(4,))
+    with _Env(ATEN_AMD_ANYHIT_TWIN=1, ATEN_AMD_ANYHIT_TWIN_DIRS=8):
+        m = MultiGpuPathTracing([0, 0, 0])
+        try:
+            m.UpdateSceneData(fs); m.updateCamera(c); m.initSampler(w, h, 0)
+            assert m.render(w, h, 5, 3, frame=4).tobytes() == want[0].tobytes()
+        finally:
+            m.close()

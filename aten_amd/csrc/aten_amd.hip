@@ -639,7 +639,9 @@ public:
         std::string err;
         if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));   // (read per upload: tests switch it)
         if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN_DIRS")) env_anyhit_twin_dirs = std::atoi(e) == 1 ? 1 : 8;
-        if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs)) return fail(ATN_ERR_UNSUPPORTED, err);
+        int layout_top = kLayoutTopLevels;     // ATEN_AMD_NODE_LAYOUT=0: bottom-level records in walk order (tests: films do not depend on it)
+        if (const char* e = std::getenv("ATEN_AMD_NODE_LAYOUT")) layout_top = std::atoi(e) == 0 ? 0 : kLayoutTopLevels;
+        if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs, layout_top)) return fail(ATN_ERR_UNSUPPORTED, err);
         ATN_HIP(nodes.upload(img.nodes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));

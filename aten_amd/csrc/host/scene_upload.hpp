@@ -117,6 +117,28 @@ inline bool analyse_list(ListLayout& L, const atn_bvh_node* src, uint32_t count,
     return true;
 }
 
+// Where a list's records go, from `off` on.  Links are explicit, so the layout is free (the root stays first: a list's typed root
+// link and an LBVH rebuild's region start there).  top_levels = 0: walk (pre-)order, what r01-r04 used "for locality".  Default
+// (kLayoutTopLevels): the nodes of the first 16 levels level by level -- the records most walks visit, packed into one stretch with
+// the two children of a node next to each other (a miss goes to the sibling: same 64-byte chunk for two inner records) -- and everything
+// below in walk order.  Measured (r05, profiles/r05_variants_node_layout.txt): sponza_lod 3.25 -> 3.18 ms per frame, the atrium (20 MB
+// of records, L2-bound) 5.02 -> 4.85; 8 / 12 levels gain less, 20 / 24 / all levels the same; sibling pairs below the top levels
+// instead of walk order: the same on sponza_lod, slightly worse on the atrium; padding so that no record straddles a 64-byte chunk:
+// -0.5 % on the atrium, not kept (the twins of a list must all be of the list's size).
+constexpr int kLayoutTopLevels = 16;
+inline void assign_offsets(ListLayout& L, uint64_t& off, int top_levels)
+{
+    const uint32_t n = (uint32_t)L.order.size();
+    auto place = [&](uint32_t j) { L.offset[j] = (uint32_t)std::min<uint64_t>(off, 0xfffffff0u); off += record_bytes(L.kind[j]); };
+    if (top_levels > 0) {
+        // (bucket the walk positions by depth: one pass, not one per level)
+        std::vector<std::vector<uint32_t>> level((size_t)top_levels);
+        for (uint32_t j = 0; j < n; j++) if (L.depth[j] < top_levels) level[(size_t)L.depth[j]].push_back(j);
+        for (const auto& lv : level) for (const uint32_t j : lv) place(j);
+    }
+    for (uint32_t j = 0; j < n; j++) if (top_levels <= 0 || L.depth[j] >= top_levels) place(j);
+}
+
 // What a list's records need from the rest of the scene.
 struct ListEmitCtx {
     const atn_object_param* objects = nullptr; uint32_t n_objects = 0; uint32_t n_matrices = 0;
@@ -268,7 +290,8 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
 // Measured on the headline scene: shadow-ray node visits 261.6 M per frame as given, 198.8 M with one twin, 134.6 M with eight;
 // 3.555 / 3.42 / 3.27 ms per frame.
 constexpr double kTwinPays = 0.95;
-inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err, int anyhit_twins = 0, int twin_dirs = 8)
+inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err, int anyhit_twins = 0, int twin_dirs = 8,
+                             int node_layout_top_levels = kLayoutTopLevels)
 {
     if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
     const uint32_t nl = s->n_bvh_lists;
@@ -310,11 +333,8 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             if (lay[k].kind[j] == KIND_TRI) img.list_tri_leaves[k]++;
             else if (lay[k].kind[j] == KIND_INNER) img.list_inner[k]++;
         }
-        for (uint32_t j = 0; j < lay[k].order.size(); j++) {
-            if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
-            lay[k].offset[j] = (uint32_t)off;
-            off += record_bytes(lay[k].kind[j]);
-        }
+        assign_offsets(lay[k], off, k == 0 ? 0 : node_layout_top_levels);
+        if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }
         img.list_bytes[k] = (uint32_t)(off - img.list_root[k]);
         if (!twin[k].empty()) {
             // the twin's records follow the list's own (not part of list_bytes: the list's region is what an LBVH rebuild rewrites);
@@ -323,7 +343,7 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
             if (twin_lay[k][0].kind[0] != lay[k].kind[0] || off + (uint64_t)img.list_bytes[k] * twin[k].size() >= (1ull << 31)) { twin[k].clear(); continue; }
             img.list_twin_delta[k] = (int32_t)(off - img.list_root[k]) | (twin[k].size() > 1 ? 1 : 0);
             for (size_t g = 0; g < twin[k].size(); g++)
-                for (uint32_t j = 0; j < twin_lay[k][g].order.size(); j++) { twin_lay[k][g].offset[j] = (uint32_t)off; off += record_bytes(twin_lay[k][g].kind[j]); }
+                assign_offsets(twin_lay[k][g], off, node_layout_top_levels);
         }
     }
     if (off >= (1ull << 31)) { err = "too many BVH nodes for 31-bit byte-offset links"; return false; }

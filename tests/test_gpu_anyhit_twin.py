@@ -162,3 +162,16 @@ def test_screen_shards_with_twins_equal_one_context_without(orc, sponza):
             assert m.render(w, h, 5, 3, frame=4).tobytes() == want[0].tobytes()
         finally:
             m.close()
+
+
+def test_node_layout_changes_no_film(orc, sponza):
+    """Where the records lie in the node image (ATEN_AMD_NODE_LAYOUT: walk order, or the top levels first -- the default) decides
+    nothing: links are explicit.  Films byte-equal on the headline scene (one deep list + eight twins) and behind a top layer."""
+    from aten_amd.scene import scenedefs
+    for (fs, cam), w, h in ((sponza, 192, 108), (scenedefs.cornell_box_variant(lights="mixed"), 96, 96)):
+        c = make_camera(orc, cam, w, h)
+        films = {}
+        for layout in (0, 1):
+            with _Env(ATEN_AMD_NODE_LAYOUT=layout):
+                films[layout], _ = _render(fs, c, w, h, 2, frames=(1,))
+        assert films[0][0].tobytes() == films[1][0].tobytes()

@@ -19,7 +19,7 @@ SYMBOLS = [
     "atn_set_frames_in_flight", "atn_bank_streams", "atn_side_stream", "atn_mgpu_set_frames_in_flight", "atn_set_sampling_options", "atn_sample_texture",
     "atn_svgf_render", "atn_svgf_set_motion_depth", "atn_svgf_reset", "atn_svgf_set_atrous_iterations",
     "atn_svgf_download", "atn_svgf_output_device", "atn_svgf_set_dilate_temporal_weight", "atn_svgf_denoise", "atn_svgf_upload",
-    "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_anyhit_twins", "atn_stream", "atn_synchronize",
+    "atn_film_device", "atn_tile_device", "atn_tile_slots", "atn_anyhit_twins", "atn_planar_area_lights", "atn_stream", "atn_synchronize",
     "atn_assemble_tiles", "atn_assemble_tiles_on", "atn_download_film", "atn_upload_film", "atn_get_stats", "atn_get_kernel_times",
     "atn_reset_kernel_times", "atn_generate_paths", "atn_trace_closest", "atn_cmj_samples", "atn_cmj_batch", "atn_ray_offset", "atn_get_random", "atn_random_count",
     "atn_material_table", "atn_material_eval", "atn_compact", "atn_compact2", "atn_sizeof_scene_desc", "atn_sizeof_destination",
@@ -90,6 +90,7 @@ def lib():
         l.atn_tile_device.argtypes = [vp]; l.atn_tile_device.restype = vp
         l.atn_tile_slots.argtypes = [vp]; l.atn_tile_slots.restype = C.c_uint32
         l.atn_anyhit_twins.argtypes = [vp]; l.atn_anyhit_twins.restype = C.c_uint32
+        l.atn_planar_area_lights.argtypes = [vp]; l.atn_planar_area_lights.restype = C.c_uint32
         l.atn_stream.argtypes = [vp]; l.atn_stream.restype = vp
         l.atn_side_stream.argtypes = [vp]; l.atn_side_stream.restype = vp
         l.atn_synchronize.argtypes = [vp]

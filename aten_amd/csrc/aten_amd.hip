@@ -126,6 +126,7 @@ public:
     DevScene scene{};
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
+    uint32_t n_planar_lights = 0;           // area lights flagged planar + rigid at upload (scene.planar_lights says whether the flags still hold)
     std::vector<int32_t> list_twin_delta;   // HostSceneImage::list_twin_delta: where each list's any-hit twin starts (0 = none)
     std::vector<HostSceneImage::TlasRef> tlas_refs;     // the top layer's TLAS-leaf records and the lists they enter
     uint32_t top_base = 0, n_host_matrices = 0;
@@ -641,7 +642,11 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN_DIRS")) env_anyhit_twin_dirs = std::atoi(e) == 1 ? 1 : 8;
         int layout_top = kLayoutTopLevels;     // ATEN_AMD_NODE_LAYOUT=0: bottom-level records in walk order (tests: films do not depend on it)
         if (const char* e = std::getenv("ATEN_AMD_NODE_LAYOUT")) layout_top = std::atoi(e) == 0 ? 0 : kLayoutTopLevels;
-        if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs, layout_top)) return fail(ATN_ERR_UNSUPPORTED, err);
+        bool planar_lights = true;             // ATEN_AMD_PLANAR_LIGHTS=0: shadow rays towards area lights always walk to their closest hit (tests)
+        if (const char* e = std::getenv("ATEN_AMD_PLANAR_LIGHTS")) planar_lights = std::atoi(e) != 0;
+        if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs, layout_top, planar_lights)) return fail(ATN_ERR_UNSUPPORTED, err);
+        n_planar_lights = 0;
+        for (const atn_light_param& l : img.lights) n_planar_lights += l._pad != 0 ? 1u : 0u;
         ATN_HIP(nodes.upload(img.nodes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));
@@ -807,6 +812,7 @@ public:
         if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; host_matrices.assign(mtxs, mtxs + n_mtxs); }
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
+        if (n_mtxs) scene.planar_lights = 0;    // (a light's instance may have a new matrix)
         tlas_refs.swap(new_refs);
         scene.root_link = root;
         fill_root_direct(scene, rec.data(), top_base, n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr), n_mtxs ? n_mtxs : n_host_matrices);
@@ -838,6 +844,7 @@ public:
                 if (tr[i].idx[v] < 0 || (uint32_t)tr[i].idx[v] >= n_scene_vtx) return fail(ATN_ERR_UNSUPPORTED, "triangle vertex index out of range");
         }
         ATN_HIP(hipSetDevice(device));
+        scene.planar_lights = 0;        // a light's vertices may be among these: its shadow rays walk to their closest hit from here on
         const size_t vb = (size_t)n_vtx * sizeof(float4), tb = (size_t)n_tr * sizeof(atn_triangle_param);
         { int r = begin_scene_update((pos ? vb : 0) + (nml ? vb : 0) + tb + 256); if (r) return r; }
         if (n_vtx && pos) { int r = stage_copy(vtx_pos.p + vtx_offset, pos, vb); if (r) return r; log_range(SB_VTX_POS, (size_t)vtx_offset * sizeof(float4), vb); }
@@ -1795,6 +1802,7 @@ int atn_scene_device_arrays(atn_ctx* ctx, void** vtx_pos, void** vtx_nml, void**
     // the caller writes these arrays itself from now on: one copy of the scene, updates in place behind the frames in flight
     { int q = ctx->r.quiesce(); if (q) return q; }
     ctx->r.drop_alt_set(); ctx->r.scene_in_place = true;
+    ctx->r.scene.planar_lights = 0;     // (the caller writes vertices from now on)
     if (vtx_pos) *vtx_pos = ctx->r.vtx_pos.p;
     if (vtx_nml) *vtx_nml = ctx->r.vtx_nml.p;
     if (triangles) *triangles = ctx->r.tris.p;
@@ -1945,6 +1953,7 @@ void* atn_svgf_output_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.sv_out.p
 void* atn_film_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.film.p : nullptr; }
 void* atn_tile_device(atn_ctx* ctx) { return ctx ? (void*)ctx->r.tile_out.p : nullptr; }
 uint32_t atn_tile_slots(atn_ctx* ctx) { return ctx ? ctx->r.n_slots : 0; }
+uint32_t atn_planar_area_lights(atn_ctx* ctx) { return (ctx && ctx->r.scene.planar_lights) ? ctx->r.n_planar_lights : 0u; }
 uint32_t atn_anyhit_twins(atn_ctx* ctx)
 {
     uint32_t n = 0;

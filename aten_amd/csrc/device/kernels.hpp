@@ -655,7 +655,10 @@ struct ShadowJob {
         const bool has_obj = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
         // (a light with neither object nor attribute is visible iff nothing is hit, like an infinite one)
         const bool near_only = (lp->attrib & ATN_LIGHT_ATTR_SINGULAR) && !(lp->attrib & ATN_LIGHT_ATTR_INFINITE);
-        stop_t = has_obj ? -kInf : (near_only ? so.w : kInf);
+        // (an area light whose object is planar and rigidly placed is met at distToLight and nowhere else, so a hit nearer than that is on
+        // another object and settles "blocked": scene_upload.hpp, planar_area_light)
+        const bool planar = has_obj && sc.planar_lights != 0 && lp->_pad != 0;
+        stop_t = has_obj ? (planar ? so.w * 0.999F : -kInf) : (near_only ? so.w : kInf);
         // with more than one lookup an ignored hit restarts the ray BEHIND it, so it has to be the closest one
         if (ALPHA && sc.any_alpha && (sc.enable_alpha_blending || (lbits & kShadowStencilFlag))) stop_t = -kInf;
         a = make_float4(so.x, so.y, so.z, so.w - kEps);         // t_max = distToLight - AT_MATH_EPSILON (:304)

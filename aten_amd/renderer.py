@@ -196,6 +196,10 @@ class PathTracing:
         """atn_anyhit_twins: bottom-level lists that have an any-hit twin right now."""
         return int(self._l.atn_anyhit_twins(self._ctx))
 
+    def planar_area_lights(self):
+        """atn_planar_area_lights: area lights whose shadow rays may stop at the first hit nearer than the light."""
+        return int(self._l.atn_planar_area_lights(self._ctx))
+
     def stats(self):
         s = np.zeros(8, np.uint64)
         self._check(self._l.atn_get_stats(self._ctx, s.ctypes.data))

@@ -219,6 +219,7 @@ def run_workload(args, cfg, ctx):
     dev = "cuda:%d" % local_rank
     r = PathTracing(local_rank)
     r.UpdateSceneData(fs)
+    n_planar = r.planar_area_lights()
     n_twins = r.anyhit_twins()      # bottom-level lists whose any-hit rays walk a second threading of the same tree (films do not depend on it)
     r.updateCamera(camera)
     r.initSampler(W, H, 0)
@@ -654,7 +655,7 @@ def run_workload(args, cfg, ctx):
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
                        "frames_in_flight": in_flight,
                        "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"])),
-                       "anyhit_twins": n_twins},
+                       "anyhit_twins": n_twins, "planar_area_lights": n_planar},
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / steps), 2),
             "work_per_frame": {k: round(v) for k, v in per_frame.items()},
             "kernel_ms_per_frame": kernel_ms_per_frame,

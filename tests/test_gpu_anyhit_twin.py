@@ -175,3 +175,53 @@ def test_node_layout_changes_no_film(orc, sponza):
             with _Env(ATEN_AMD_NODE_LAYOUT=layout):
                 films[layout], _ = _render(fs, c, w, h, 2, frames=(1,))
         assert films[0][0].tobytes() == films[1][0].tobytes()
+
+
+def test_shadow_rays_towards_planar_area_lights_stop_early(orc):
+    """An area light's shadow ray needs the closest hit's OBJECT -- but when the light's object is planar and rigidly placed the ray meets
+    it at distToLight and nowhere else, so a hit nearer than that is on another object and settles "blocked" (scene_upload.hpp,
+    planar_area_light).  Films byte-equal with the rule off (ATEN_AMD_PLANAR_LIGHTS=0); shadow walks shorter where lights are occluded;
+    a sphere light or a light moved through atn_update_tlas is not (or no longer) treated so."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+
+    def run(fs, cam, w, h, on, depth=5, move=None):
+        with _Env(ATEN_AMD_PLANAR_LIGHTS=on):
+            r = PathTracing(0)
+            try:
+                c = make_camera(orc, cam, w, h)
+                r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+                n0 = r.planar_area_lights()
+                if move is not None:
+                    r.updateBVH(move); r.reset()
+                films = [r.render(w, h, depth, 3, frame=f, count_stats=True).copy() for f in (0, 2)]
+                return films, r.stats(), n0, r.planar_area_lights()
+            finally:
+                r.close()
+    fs, cam = scenedefs.atrium(detail=0.25)
+    a, sa, na, _ = run(fs, cam, 160, 90, 0)
+    b, sb, nb, _ = run(fs, cam, 160, 90, 1)
+    assert na == 0 and nb == 1
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    for k in ("closest_rays", "shadow_rays", "hits", "closest_nodes"):
+        assert sa[k] == sb[k]
+    assert sb["shadow_nodes"] < 0.97 * sa["shadow_nodes"], (sb["shadow_nodes"], sa["shadow_nodes"])
+    # the Cornell box: the lamp is a planar quad under the identity
+    fs, cam = scenedefs.cornell_box()
+    a, sa, _, _ = run(fs, cam, 128, 128, 0)
+    b, sb, nb, _ = run(fs, cam, 128, 128, 1)
+    assert nb == 1 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b)) and sb["shadow_nodes"] <= sa["shadow_nodes"]
+    # a sphere light is no planar polygon object; every light kind beside the lamp
+    sp, cam = scenedefs.cornell_box_variant(lights="sphere")
+    _, _, n_sp, _ = run(sp, cam, 64, 64, 1, depth=2)
+    assert n_sp == 0
+    mixed, cam = scenedefs.cornell_box_variant(lights="mixed")
+    a, _, _, _ = run(mixed, cam, 96, 96, 0)
+    b, _, nb, _ = run(mixed, cam, 96, 96, 1)
+    assert nb == 1 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    # new instance matrices through atn_update_tlas: the flags no longer hold (the lamp's instance may have moved), results as ever
+    still, cam = scenedefs.cornell_box_variant(lights="area", move_boxes=False)
+    moved, _ = scenedefs.cornell_box_variant(lights="area", move_boxes=True)
+    a, _, _, _ = run(still, cam, 80, 80, 0, move=moved)
+    b, _, n_before, n_after = run(still, cam, 80, 80, 1, move=moved)
+    assert n_before == 1 and n_after == 0 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))

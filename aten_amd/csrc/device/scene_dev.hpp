@@ -12,7 +12,8 @@ namespace atn {
 // name an inner record also carries the sign bit (kLinkNotInner; offsets are below 2^31): the hot loop's "is this lane on
 // an inner node" is ONE signed compare (`link >= 0`) instead of a mask and a compare.  Links are explicit,
 // so the walk order -- and therefore every hit/miss decision -- is exactly the reference's
-// (threaded_bvh_traverser.h:98-304) whatever the storage order is; records are stored in walk (pre-)order for locality.
+// (threaded_bvh_traverser.h:98-304) whatever the storage order is; a bottom-level list's records lie top levels first, walk (pre-)order below
+// (host/scene_upload.hpp: assign_offsets), the top layer's in walk order.
 //
 //   inner    (32 B): q0 = {boxmin.xyz, hit link}    q1 = {boxmax.xyz, miss link}
 //   tri leaf (48 B): q0 = {v0.xyz, triangle id}     q1 = {e1.xyz, next link}   q2 = {e2.xyz, 0}

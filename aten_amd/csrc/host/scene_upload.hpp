@@ -279,7 +279,8 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
 }
 
 // Node image (bytes): [BLAS list 1 | BLAS list 2 | ... | top layer (list 0)].
-//  * every list in walk order (locality; the links are explicit, so correctness does not depend on it)
+//  * every bottom-level list followed by its any-hit twins; inside a list the records lie as assign_offsets puts them (the links are
+//    explicit, so correctness does not depend on it)
 //  * the top layer comes last so that update_top_layer (≙ Renderer::updateBVH, "only for top layer") can replace it
 //    without moving the others; top-layer records are all kInnerBytes long.
 // The shadow ray towards an AREA light needs the closest hit's OBJECT (scene::hitLight, scene/scene.h:118-131: visible iff it is the

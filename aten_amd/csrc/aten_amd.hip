@@ -118,6 +118,7 @@ public:
     DevBuf<atn_object_param> objects;
     DevBuf<DevMaterial> materials;
     DevBuf<atn_light_param> lights;
+    DevBuf<float4> light_plane;
     DevBuf<DevTexture> textures;
     DevBuf<atn_toon_param> toon;
     DevBuf<atn_light_param> npr_lights;
@@ -659,6 +660,7 @@ public:
         ATN_HIP(npr_lights.upload(img.npr_lights, stream));
         ATN_HIP(screen_shadow.upload(img.screen_shadow, stream));
         ATN_HIP(lights.upload(img.lights, stream));
+        ATN_HIP(light_plane.upload(img.light_plane, stream));
         ATN_HIP(texels.upload(img.texels, stream));
         ATN_HIP(texels8.upload(img.texels8, stream));
         ATN_HIP(textures.upload(img.textures, stream));
@@ -672,7 +674,7 @@ public:
         scene.nodes = nodes.p; scene.tris = tris.p; scene.shade_tris = shade_tris.p; scene.vtx_pos = vtx_pos.p; scene.vtx_nml = vtx_nml.p;
         scene.objects = objects.p; scene.matrices = matrices.p; scene.materials = materials.p; scene.carpaint = carpaint.p;
         scene.toon = toon.p; scene.npr_lights = npr_lights.p; scene.screen_shadow = img.screen_shadow.empty() ? nullptr : screen_shadow.p;
-        scene.lights = lights.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
+        scene.lights = lights.p; scene.light_plane = light_plane.p; scene.texels = texels.p; scene.texels8 = texels8.p; scene.textures = textures.p;
         scene.mtx_quads = (uint32_t)img.matrices.size();
         has_scene = true;
         env_host.clear(); env_w = env_h = 0; ibl_tables_ready = false;

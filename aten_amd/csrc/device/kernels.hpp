@@ -655,9 +655,18 @@ struct ShadowJob {
         const bool has_obj = lp->type == ATN_LIGHT_AREA && lp->arealight_objid >= 0;
         // (a light with neither object nor attribute is visible iff nothing is hit, like an infinite one)
         const bool near_only = (lp->attrib & ATN_LIGHT_ATTR_SINGULAR) && !(lp->attrib & ATN_LIGHT_ATTR_INFINITE);
-        // (an area light whose object is planar and rigidly placed is met at distToLight and nowhere else, so a hit nearer than that is on
-        // another object and settles "blocked": scene_upload.hpp, planar_area_light)
-        const bool planar = has_obj && sc.planar_lights != 0 && lp->_pad != 0;
+        // An area light whose object is planar and rigidly placed is met where the ray crosses its plane and nowhere else; when that
+        // crossing is certain to lie beyond 0.999 distToLight, a hit nearer than that is on another object and settles "blocked"
+        // (scene_upload.hpp, planar_area_light, has the argument and the two conditions below).
+        bool planar = false;
+        if (has_obj && sc.planar_lights != 0) {
+            const float4 pl = sc.light_plane[lbits & 0xffffffu];
+            const float cos_l = fabsf(dot(mk3(pl), dir));
+            // the origin is ray::Offset(p, n): at most 256 ulps (or 2^-16) per coordinate from p
+            const float big = fmaxf(fmaxf(fabsf(so.x), fabsf(so.y)), fabsf(so.z));
+            const float off = 1.7320508F * fmaxf(big * (300.0F * 1.1920929e-7F), 1.0F / 65536.0F);
+            planar = pl.w != 0.0F && cos_l >= 0.01F && off <= 5e-4F * so.w * cos_l;
+        }
         stop_t = has_obj ? (planar ? so.w * 0.999F : -kInf) : (near_only ? so.w : kInf);
         // with more than one lookup an ignored hit restarts the ray BEHIND it, so it has to be the closest one
         if (ALPHA && sc.any_alpha && (sc.enable_alpha_blending || (lbits & kShadowStencilFlag))) stop_t = -kInf;

@@ -111,8 +111,9 @@ struct DevScene {
     const uint32_t* texels8;            // packed r | g << 8 | b << 16 | a << 24
     const DevTexture* textures;
     int32_t n_lights;
-    int32_t planar_lights;              // 1 = lights[i]._pad says "a planar area light on a rigid instance" (host/scene_upload.hpp: planar_area_light);
+    int32_t planar_lights;              // 1 = light_plane[i].w says "a planar area light on a rigid instance" (host/scene_upload.hpp: planar_area_light);
                                         // cleared by every update that can move a light's vertices or its instance
+    const float4* light_plane;          // per light: {the plane's unit normal in world space, 1} or zeros
     float inv_n_lights;                 // 1.0f / (float)n_lights: the light pick's pdf, divided once (0 without lights)
     int32_t n_textures;
     int32_t n_materials;

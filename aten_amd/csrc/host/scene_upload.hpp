@@ -31,6 +31,7 @@ struct HostSceneImage {
     std::vector<atn_light_param> npr_lights;
     std::vector<float> screen_shadow;
     std::vector<atn_light_param> lights;
+    std::vector<float4> light_plane;    // per light: {unit normal of a planar area light's plane in world space, 1}, or zeros (planar_area_light)
     std::vector<float4> texels;
     std::vector<uint32_t> texels8;
     std::vector<DevTexture> textures;
@@ -289,10 +290,16 @@ inline bool validate_ranges(const atn_object_param* objs, uint32_t n_objs, uint3
 // at a point of that plane at distToLight, meets the light's object there and nowhere else: an accepted hit with t <= 0.999 distToLight
 // is on some OTHER object, and since the walk's closest hit can only be nearer still, the closest hit's object is not the light's
 // either -- the answer is "blocked" and the walk may stop (ShadowJob::fetch: a finite stop_t, the rule punctual lights already use).
-// Same list, same order, same decisions up to that hit: the answer is the reference's.  Measured: atrium shadow-ray node visits
+// Same list, same order, same decisions up to that hit: the answer is the reference's.
+// "At distToLight" needs care: the ray starts at ray::Offset(p, n) (math/ray.h:26-74: up to 256 ulps or 2^-16 per coordinate away from
+// p) but points along pos - p, so it crosses the light's plane at distToLight - ((o' - p) . n_l) / (dir . n_l): for a grazing ray that
+// is anywhere.  fetch therefore applies the rule only when |dir . n_l| >= 0.01 and the largest possible |o' - p| is at most
+// 5e-4 * distToLight * |dir . n_l| -- then the crossing, and with it every hit on the light's object (Moeller-Trumbore's own rounding
+// at such an angle: << 1e-4), lies beyond 0.999 * distToLight.  The plane's world-space normal per light: HostSceneImage::light_plane.  Measured: atrium shadow-ray node visits
 // 296.7 M -> 273.8 M per frame, 4.88 -> 4.77 ms; the Cornell box (most of its shadow rays reach the lamp) unchanged.
-inline bool planar_area_light(const atn_scene_desc* s, const atn_light_param& l)
+inline bool planar_area_light(const atn_scene_desc* s, const atn_light_param& l, float world_normal[3])
 {
+    const atn_mat4* l2w = nullptr;
     if (l.type != ATN_LIGHT_AREA || l.arealight_objid < 0 || (uint32_t)l.arealight_objid >= s->n_objects) return false;
     const atn_object_param* o = &s->objects[l.arealight_objid];
     if (o->type == ATN_OBJ_INSTANCE) {
@@ -305,6 +312,7 @@ inline bool planar_area_light(const atn_scene_desc* s, const atn_light_param& l)
                     for (int c = 0; c < 3; c++) d += (double)m.m[a][c] * (double)m.m[b][c];
                     if (std::fabs(d - (a == b ? 1.0 : 0.0)) > 1e-6) return false;
                 }
+            l2w = &s->matrices[o->mtx_id];                                   // (L2W sits before W2L: instance.h:253-269)
         }
         if (o->object_id < 0 || (uint32_t)o->object_id >= s->n_objects) return false;
         o = &s->objects[o->object_id];
@@ -341,6 +349,15 @@ inline bool planar_area_light(const atn_scene_desc* s, const atn_light_param& l)
         }
         if (!have_plane) return false;
     }
+    // the plane's unit normal in world space (a rigid matrix: its rotation part applied to the normal)
+    double w[3] = { n[0], n[1], n[2] };
+    if (l2w) {
+        for (int a = 0; a < 3; a++) w[a] = (double)l2w->m[a][0] * n[0] + (double)l2w->m[a][1] * n[1] + (double)l2w->m[a][2] * n[2];
+        const double len = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if (!(std::fabs(len - 1.0) <= 1e-5)) return false;
+        for (int a = 0; a < 3; a++) w[a] /= len;
+    }
+    for (int a = 0; a < 3; a++) world_normal[a] = (float)w[a];
     return true;
 }
 
@@ -486,7 +503,12 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
     }
     img.lights.assign(s->lights, s->lights + s->n_lights);
     // area lights whose shadow rays may stop early (planar_area_light, below): the flag lives in OUR copy's padding word
-    for (uint32_t i = 0; i < s->n_lights; i++) img.lights[i]._pad = (planar_lights && planar_area_light(s, s->lights[i])) ? 1 : 0;
+    img.light_plane.assign(s->n_lights ? s->n_lights : 1, make_float4(0, 0, 0, 0));       // {world-space unit normal, 1} of a planar area light, else 0
+    for (uint32_t i = 0; i < s->n_lights; i++) {
+        float wn[3];
+        img.lights[i]._pad = 0;
+        if (planar_lights && planar_area_light(s, s->lights[i], wn)) { img.light_plane[i] = make_float4(wn[0], wn[1], wn[2], 1.0F); img.lights[i]._pad = 1; }
+    }
     img.params.planar_lights = planar_lights ? 1 : 0;
     // textures: RGBA8 where every channel of every texel is exactly k / 255.0f (DevTexture), float4 otherwise
     img.textures.resize(s->n_textures);

@@ -321,3 +321,22 @@ def test_anyhit_twin_is_the_same_tree_in_another_child_order():
     bad = nodes.copy(); bad["hit"][5] = 2.0
     assert _twin(bad)[0] == -4
     assert _twin(nodes[:1])[0] == -4
+
+
+def test_upload_host_logic(tmp_path):
+    """tests/cxx/upload_host_test.cpp: csrc/host/scene_upload.hpp (pure host C++) compiled with hipcc for its headers and run here
+    without a GPU -- the node image with any-hit twins (one / eight) and both layouts can be walked list by list along its typed
+    links, every twin holds its list's triangles, the TLAS leaf and the direct-start copy carry the twin word; planar_area_light
+    accepts a flat lamp under a rigid matrix (rotated: the normal rotates with it) and refuses a bent, a scaled and a point one."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "upload_host_test")
+    lib_dir = os.path.join(ROOT, "aten_amd")
+    from aten_amd._hostlib import hostlib
+    hostlib()                                                           # (builds libaten_amd_scene.so if it is missing)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O1", "-w", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "upload_host_test.cpp"), "-L", lib_dir, "-laten_amd_scene",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -30,6 +30,7 @@ SYMBOLS = [
     "atn_mgpu_upload_scene", "atn_mgpu_update_tlas", "atn_mgpu_update_camera", "atn_mgpu_init_sampler",
     "atn_mgpu_set_random", "atn_mgpu_render", "atn_mgpu_reset", "atn_mgpu_synchronize", "atn_mgpu_film_device",
     "atn_mgpu_download_film",
+    "atn_set_regeneration", "atn_get_regeneration", "atn_render_burst", "atn_regen_stage_counts",
 ]
 
 
@@ -70,6 +71,10 @@ def lib():
         l.atn_set_screen_shard.argtypes = [vp, C.c_int32, C.c_int32]
         l.atn_render.argtypes = [vp, C.POINTER(Destination), vp]
         l.atn_reset.argtypes = [vp]
+        l.atn_set_regeneration.argtypes = [vp, C.c_int32]
+        l.atn_get_regeneration.argtypes = [vp]; l.atn_get_regeneration.restype = C.c_int32
+        l.atn_render_burst.argtypes = [vp, C.POINTER(Destination), C.c_int32, vp]
+        l.atn_regen_stage_counts.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         l.atn_set_path_batches.argtypes = [vp, C.c_int32]
         l.atn_set_frames_in_flight.argtypes = [vp, C.c_int32]
         l.atn_bank_streams.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -102,7 +102,8 @@ def build_host(force=False):
 # libaten_amd.so is two translation units with ONE flag of difference (device/svgf_atrous.hpp says why):
 #   aten_amd.hip      -fno-slp-vectorize  (no packed-fp32 pairing: the path-tracing kernels lose 15-25 % of their registers to it)
 #   svgf_atrous.hip   vectoriser on       (straight-line tap arithmetic, 22 % faster packed)
-HIP_UNITS = [("aten_amd.hip", ["-fno-slp-vectorize"]), ("svgf_atrous.hip", [])]
+#   regen.hip         -fno-slp-vectorize  (the path-regeneration kernels: same sources and flags as aten_amd.hip's, compiled beside them)
+HIP_UNITS = [("aten_amd.hip", ["-fno-slp-vectorize"]), ("regen.hip", ["-fno-slp-vectorize"]), ("svgf_atrous.hip", [])]
 
 
 def hip_compile(out_lib, extra_flags=(), objdir=None, hipcc=None):

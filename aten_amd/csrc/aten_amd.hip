@@ -17,6 +17,7 @@
 
 #include "../../include/aten_amd.h"
 #include "device/kernels.hpp"
+#include "device/regen_launch.hpp"
 #include "device/svgf.hpp"
 #include "device/lbvh.hpp"
 #include "host/scene_upload.hpp"
@@ -161,7 +162,10 @@ public:
 
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
+    DevBuf<float4> pend;                    // path regeneration: a pixel's previous sample while its last shadow ray is in flight
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
+    DevBuf<uint32_t> rg_counters;           // path regeneration: [3][rg_stages + 2] live paths / shadow rays / fetch cursor of every stage
+    int32_t rg_stages = 0;                  // stages the counters hold (of the bank's last regenerated burst: atn_regen_stage_counts)
     DevBuf<unsigned long long> stats;
     DevBuf<uint32_t> cost, cost_film;       // per-slot / per-pixel {node visits, triangle tests} of the last count_stats frame
     int32_t cost_w = 0, cost_h = 0;
@@ -177,8 +181,9 @@ public:
     // Only the film orders consecutive frames: a frame's k_gather waits for the previous frame's.
     static constexpr int kMaxInFlight = 4;      // (5 / 6 / 8 banks with 8 hardware queues: no gain, profiles/r04_variants_shade_waves.txt)
     struct Bank {
-        DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out;
-        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
+        DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out, pend;
+        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters, rg_counters;
+        int32_t rg_stages = 0;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
         uint64_t bank_epoch = 0;
@@ -203,7 +208,7 @@ public:
         ray_o.swap(b.ray_o); ray_d.swap(b.ray_d); thr.swap(b.thr); contrib.swap(b.contrib); isect.swap(b.isect);
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
-        counters.swap(b.counters);
+        counters.swap(b.counters); pend.swap(b.pend); rg_counters.swap(b.rg_counters); std::swap(rg_stages, b.rg_stages);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
         for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
@@ -1378,6 +1383,7 @@ public:
         if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
         if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
         ATN_HIP(hipSetDevice(device));
+        if (d->sample > 1 && regen_applies(*d, 1)) return render_regen(d, 1, out_host);
         const bool count = d->count_stats != 0, prof = d->profile != 0;
         int rc;
         if (frames_in_flight > 1) {
@@ -1428,6 +1434,153 @@ public:
         }
         if (out_host || count) ATN_HIP(hipStreamSynchronize(stream));
         return ATN_OK;      // profiling spans are resolved lazily in kernel_times() (no sync in the frame loop)
+    }
+
+
+    // ------------------------------------------------------------------------------------------------
+    // Path regeneration (BASELINE.json north_star "path compaction/regeneration"; atn_set_regeneration, atn_render_burst).
+    //
+    // The serial loop above -- the reference's, src/libidaten/kernel/pathtracing.cpp:105-138 -- is `for sample { generate; for bounce
+    // { trace; shade } ; accumulate } gather`: every launch of a sample works on what is left of the population after the bounces
+    // before it, a pixel whose path ended early idles until the longest path of the sample is over, and the next sample (or the next
+    // progressive frame) starts from an empty machine.  Here one POOL of slots -- a slot is a pixel -- runs a whole burst of
+    // `n_frames` progressive frames x `spp` samples: `begin; for stage { trace; shade } ; end`.  A path that ends in shade(stage)
+    // has its sample epilogue run there (accumulate; after the frame's last sample Film::put), and the pixel's next primary ray is
+    // written into the same slot and queued for trace(stage + 1); bounce, sample and frame are per-path state (kernels.hpp).  Per
+    // pixel the samples and frames follow each other in the serial order with the serial operations, so films are BYTE-equal to
+    // the serial loop's (tests/test_gpu_regen.py); what changes is only which launch a piece of work rides in.
+    //
+    // A path that runs out of depth with a shadow ray to trace hands its contribution over (`pend`) and the next sample starts at
+    // once; the shadow ray adds its light to `pend` in the next stage's trace launch and the epilogue runs at the start of that
+    // stage's shade (F_PENDING) -- before anything of the new sample can reach accum or the film.
+    //
+    // Stages are launched up to the bound n_frames * spp * maxDepth (a pixel's worst case); the kernels read their counts from
+    // device memory, and a stage whose queue is empty costs a kernel start.
+    // ------------------------------------------------------------------------------------------------
+    int regen_mode = 0;         // atn_set_regeneration: 0 = serial sample loop, 1 = regenerated pool wherever it applies
+    uint64_t rg_host_totals[4] = {};
+    static constexpr int32_t kRegenMaxStages = 1 << 16;
+    static constexpr int32_t kRegenMaxDepth = 128;      // 4096 CMJ dimensions / 32 per bounce (kRegenDimMask)
+
+    bool regen_applies(const atn_destination& d, int32_t n_frames) const
+    {
+        if (regen_mode == 0 || d.count_stats) return false;        // (counted frames use the serial loop's counting kernels)
+        if (d.maxDepth > kRegenMaxDepth || (uint32_t)d.sample >= kRegenMaxSpp || (uint32_t)n_frames >= kRegenMaxFrames) return false;
+        if (n_frames > 1 && !d.progressive) return false;           // (a burst of overwriting frames is its last frame)
+        return (int64_t)n_frames * d.sample * d.maxDepth <= kRegenMaxStages;
+    }
+
+    // ≙ n_frames x (idaten::PathTracing::render, pathtracing.cpp:49-153) with frame = d->frame, d->frame + 1, ...
+    int render_burst(const atn_destination* d, int32_t n_frames, atn_vec4* out_host)
+    {
+        if (!d) return fail(ATN_ERR_INVALID_ARG, "null destination");
+        if (n_frames <= 0) return fail(ATN_ERR_INVALID_ARG, "bad burst length");
+        if (regen_applies(*d, n_frames)) {
+            if (!has_scene) return fail(ATN_ERR_NO_SCENE, "atn_upload_scene has not been called");
+            if (!has_camera) return fail(ATN_ERR_INVALID_ARG, "atn_update_camera has not been called");
+            if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
+            if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
+            ATN_HIP(hipSetDevice(device));
+            return render_regen(d, n_frames, out_host);
+        }
+        atn_destination one = *d;
+        for (int32_t k = 0; k < n_frames; k++) {
+            one.frame = d->frame + (uint32_t)k;
+            const int rc = render(&one, k + 1 == n_frames ? out_host : nullptr);
+            if (rc) return rc;
+        }
+        return ATN_OK;
+    }
+
+    int render_regen(const atn_destination* d, int32_t n_frames, atn_vec4* out_host)
+    {
+        const bool prof = d->profile != 0;
+        int rc;
+        if (frames_in_flight > 1) swap_bank(spare[frame_seq % (uint64_t)(frames_in_flight - 1)]);
+        frame_seq++;
+        rc = wait_scene_epoch();
+        if (rc) return rc;
+        rc = ensure_frame(d->width, d->height, d->maxDepth);
+        if (rc) return rc;
+        const int32_t stages = n_frames * d->sample * d->maxDepth;
+        if (pend.n < n_slots) ATN_HIP(pend.resize(n_slots));
+        if (rg_counters.n < (size_t)3 * (stages + 2)) ATN_HIP(rg_counters.resize((size_t)3 * (stages + 2)));
+        rg_stages = stages;
+        FrameParams fp = frame_params(*d);
+        fp.burst_frames = n_frames; fp.spp = d->sample;
+        PathBuffers pb = buffers(false);
+        pb.pend = pend.p;
+        pb.q_count = rg_counters.p; pb.sh_count = rg_counters.p + (stages + 2); pb.fetch_closest = rg_counters.p + 2 * (size_t)(stages + 2);
+        pb.fetch_shadow = nullptr;
+        const RegenOut ro{ film.p, tile_out.p };
+
+        if (!flavour_forced) use_refill = tree_is_deep && n_slots >= kRefillMinPaths;
+        const uint32_t n = n_slots;
+        int items = n >= 400u * 1000u ? kChunkItems : 2;
+        if (env_shade_items) items = env_shade_items;
+        fp.chunk_items = items;
+        const uint32_t g_shade = grid_for((n + (uint32_t)items - 1u) / (uint32_t)items);
+        const uint32_t g_slots = grid_for(n), g_all = (n + 255u) / 256u, g_fused = trace_grid(2u * n);
+        const bool big = n >= 1500u * 1000u;
+        const bool small_set = scene.material_set == kMsCore || scene.material_set == kMsDisney || scene.material_set == kMsAnalytic;
+        const int shade_waves = !small_set ? 0 : env_shade_waves ? env_shade_waves
+                              : (frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
+        const bool lds_nodes = lds_scene_bytes() != 0u;
+        const uint32_t sb = (lds_nodes && lds_scene_bytes() > 8192u) ? 256u : simple_block;
+
+        ATN_HIP(hipMemsetAsync(rg_counters.p, 0, (size_t)3 * (stages + 2) * sizeof(uint32_t), stream));
+        // every shade launch of the burst may put pixels into the film: behind the film's last writer from the start
+        if (film_pending) ATN_HIP(hipStreamWaitEvent(stream, ev_film, 0));
+        prof_begin(prof, ATN_K_GEN);
+        regen_launch_begin(g_slots, stream, pb, fp, camera);
+        prof_end(prof);
+        for (int32_t i = 0; i <= stages; i++) {
+            // trace(i): the shadow rays shade(i - 1) cast + the closest-hit rays of the paths (continued and regenerated) it queued
+            const bool refill_now = use_refill && i != 0;       // (stage 0 holds primary rays only: coherent, the plain walk)
+            RegenTraceLaunch tl{};
+            tl.refill = refill_now; tl.alpha = scene.any_alpha != 0; tl.lds_nodes = lds_nodes;
+            tl.grid = refill_now ? g_fused : g_fused * (256u / sb); tl.block = refill_now ? (uint32_t)kTraceBlock : sb;
+            tl.lds_bytes = lds_nodes ? lds_scene_bytes() : 0u;
+            prof_begin(prof, (use_refill && i == 0) ? ATN_K_TRACE_CLOSEST : ATN_K_TRACE_FUSED);
+            regen_launch_trace(tl, stream, pb, scene, i - 1, i < stages ? i : -1, i);
+            prof_end(prof);
+            if (i < stages) {
+                prof_begin(prof, ATN_K_SHADE);
+                regen_launch_shade(scene.material_set, shade_waves, g_shade, stream, pb, scene, fp, camera, i, ro);
+                prof_end(prof);
+            }
+        }
+        prof_begin(prof, ATN_K_GATHER);
+        regen_launch_end(g_all, stream, pb, fp, ro);
+        prof_end(prof);
+        ATN_HIP(hipGetLastError());
+        if (frames_in_flight > 1) {
+            ATN_HIP(hipEventRecord(ev_gather, stream)); rc = record_scene_read(); if (rc) return rc;
+            if (!ev_film) ATN_HIP(hipEventCreateWithFlags(&ev_film, hipEventDisableTiming));
+            ATN_HIP(hipEventRecord(ev_film, stream)); film_pending = true;
+        }
+        if (out_host) {
+            ATN_HIP(hipMemcpyAsync(out_host, film.p, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToHost, stream));
+            ATN_HIP(hipStreamSynchronize(stream));
+        }
+        return ATN_OK;
+    }
+
+    // per-stage populations of the current bank's last regenerated burst: closest-hit rays and shadow rays of every stage
+    int regen_stage_counts(uint32_t* closest, uint32_t* shadow, uint32_t capacity, uint32_t* n_stages)
+    {
+        ATN_HIP(hipSetDevice(device));
+        ATN_HIP(hipStreamSynchronize(stream));
+        const uint32_t ns = (uint32_t)rg_stages + 1u;
+        if (n_stages) *n_stages = rg_stages > 0 ? ns : 0u;
+        if (rg_stages <= 0 || !rg_counters.p) return ATN_OK;
+        std::vector<uint32_t> h((size_t)2 * (rg_stages + 2));
+        ATN_HIP(hipMemcpy(h.data(), rg_counters.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < ns && i < capacity; i++) {
+            if (closest) closest[i] = h[i];
+            if (shadow) shadow[i] = h[(size_t)(rg_stages + 2) + i];
+        }
+        return ATN_OK;
     }
 
     // ------------------------------------------------------------------------------------------------
@@ -1824,6 +1977,20 @@ int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world)
 }
 
 int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.render(dst, out_host); }); }
+int atn_render_burst(atn_ctx* ctx, const atn_destination* dst, int32_t n_frames, atn_vec4* out_host) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.render_burst(dst, n_frames, out_host); }); }
+int atn_set_regeneration(atn_ctx* ctx, int32_t mode)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    if (mode < 0 || mode > 1) return ctx->r.fail(ATN_ERR_INVALID_ARG, "regeneration mode out of range");
+    ctx->r.regen_mode = mode;
+    return ATN_OK;
+}
+int32_t atn_get_regeneration(atn_ctx* ctx) { return ctx ? ctx->r.regen_mode : 0; }
+int atn_regen_stage_counts(atn_ctx* ctx, uint32_t* closest, uint32_t* shadow, uint32_t capacity, uint32_t* n_stages)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    return guarded(ctx, [&] { return ctx->r.regen_stage_counts(closest, shadow, capacity, n_stages); });
+}
 int atn_reset(atn_ctx* ctx) { CTX_QUIET_OR_FAIL(ctx); return ctx->r.reset(); }
 int atn_set_path_batches(atn_ctx* ctx, int32_t n)
 {

@@ -14,12 +14,35 @@
 #include "shading.hpp"
 #include "toon.hpp"
 
+// Two translation units include this file: aten_amd.hip (everything but the regeneration kernels) and regen.hip (ATN_REGEN_TU: the
+// regeneration kernels and the templates they instantiate).  Kernels that are not templates belong to exactly one of them.
+#ifdef ATN_REGEN_TU
+#define ATN_MAIN_TU 0
+#else
+#define ATN_MAIN_TU 1
+#endif
+
 namespace atn {
 
 constexpr uint32_t F_TERMINATED = 1u, F_SINGULAR = 2u, F_HIT = 4u;
 constexpr uint32_t kShadowSlotMask = (1u << 26) - 1u;      // shadow-job payload: slot bits (ShadowJob)
 constexpr uint32_t kShadowStencilFlag = 0x40000000u;      // in sh_d.w next to the light index: the shaded surface's material is StencilType::ALWAYS
 constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.last_hit_mtrl_idx names a Specular material
+
+// ---- path regeneration (the pool form of the sample loop, PathTracing::run_regen in aten_amd.hip) -------------------------
+// A slot is a PIXEL for a whole burst of `burst_frames` progressive frames x `spp` samples: the moment its path ends, k_regen_shade
+// runs the sample epilogue (and, after the frame's last sample, the film put) and writes the pixel's next primary ray into the
+// same slot, so every launch of the burst works on a full population instead of one that decays bounce by bounce and sample by
+// sample.  What the serial loop keeps in launch arguments becomes per-path state, packed into words that travel anyway:
+//   ray_d.w : flags (bits 0-4) | bounce (bits 5-12) | sample of the frame (bits 13-31)
+//   thr.w   : CMJ dimension (bits 0-11) | frame of the burst (bits 12-31)
+constexpr uint32_t F_PENDING = 16u;         // the pixel's PREVIOUS sample still waits for its last shadow ray: its epilogue runs at the next shade
+constexpr uint32_t kRegenFlagMask = 31u;
+constexpr uint32_t kRegenBounceShift = 5u, kRegenBounceMask = 255u;
+constexpr uint32_t kRegenSampleShift = 13u;
+constexpr uint32_t kRegenDimMask = 4095u, kRegenFrameShift = 12u;
+constexpr uint32_t kRegenMaxSpp = 1u << 19, kRegenMaxFrames = 1u << 20;
+constexpr uint32_t kShadowFinalFlag = 0x20000000u;        // in sh_c.w / sh_d.w: the shadow ray of a path's LAST vertex -- its light goes to `pend`, not `contrib`
 
 struct PathBuffers {
     float4* ray_o;      // org.xyz, pdfb
@@ -42,6 +65,7 @@ struct PathBuffers {
     uint32_t* fetch_shadow;     // [maxDepth]
     uint32_t* cost;     // [2 * slots] node visits / triangle tests of the pixel's walks this sample (count_stats frames; else null)
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
+    float4* pend;       // regeneration only: contrib.xyz of the pixel's previous sample while its last shadow ray is in flight (F_PENDING)
 };
 
 struct FrameParams {
@@ -59,6 +83,7 @@ struct FrameParams {
     uint32_t n_seeds;
     int32_t break_on_terminate;
     int32_t progressive;
+    int32_t burst_frames, spp;  // regeneration only: progressive frames frame .. frame + burst_frames - 1, spp samples each
 };
 
 // slot -> pixel.  Slots are grouped in 8x8 pixel tiles (one tile per wave64): a wave's primary
@@ -148,6 +173,7 @@ ATN_DEV void pinhole_sample(const atn_camera_param& cam, float s, float t, f3& o
     org = origin;
 }
 
+#if ATN_MAIN_TU
 // GeneratePath, renderer/pathtracing/pathtracing_impl.h:65-110
 __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp, atn_camera_param cam,
                                                    const uint32_t* __restrict__ seeds)
@@ -185,6 +211,102 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
                       [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
     }
 }
+
+#endif  // ATN_MAIN_TU
+
+// ---- path regeneration: the pieces k_regen_begin / k_regen_shade / k_regen_end share ---------------------------------------
+// GeneratePath (pathtracing_impl.h:65-110) for pixel (ix, iy), sampler frame `fs` = frame + sample: the same operations on the
+// same operands as k_gen_path, so the same bits.
+ATN_DEV void regen_primary(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, uint32_t slot, int32_t ix, int32_t iy,
+                           uint32_t frame_k, uint32_t sample_s, uint32_t flags)
+{
+    const uint32_t idx = (uint32_t)(iy * fp.width + ix);
+    const uint32_t rnd = pb.seeds[idx % fp.n_seeds];
+    const uint32_t fs = fp.frame + frame_k + sample_s;
+    const uint32_t scramble = rnd * 0x1fe3434fu * ((fs + 133u * rnd) / 256u);
+    Cmj smp; smp.idx = fs % 256u; smp.dim = 0; smp.scramble = scramble;
+    const float r1 = cmj_next(smp);
+    const float r2 = cmj_next(smp);
+    const float s = ((float)ix + r1) / (float)cam.width;
+    const float t = ((float)iy + r2) / (float)cam.height;
+    f3 org, dir;
+    pinhole_sample(cam, s, t, org, dir);
+    pb.ray_o[slot] = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
+    pb.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(flags | (sample_s << kRegenSampleShift)));    // bounce 0
+    pb.thr[slot] = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(smp.dim | (frame_k << kRegenFrameShift)));
+    pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+}
+
+struct RegenOut {
+    float4* film;       // full-frame vec4[w*h]
+    float4* tile_out;   // this GPU's pixels in slot order (may be null)
+};
+
+// One sample's epilogue -- OnRender's inner loop, pathtracing.cpp:339-352 = k_accumulate_sample -- and, when it was the pixel's last
+// sample of the frame, Film::put / FilmProgressive::put (film.cpp:33-45,61-71) = k_gather.  `c`: the sample's contribution;
+// `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path).  Per pixel the operations and
+// their order are the serial loop's: the pixel's samples and frames pass through its slot one after the other.
+ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro, uint32_t slot, uint32_t pixel,
+                            const f3& c, uint32_t sample_s, bool frame_last)
+{
+    float4 a = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+    if (sample_s != 0u) a = pb.accum[slot];
+    const bool invalid = isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z)
+        || c.x < 0 || c.y < 0 || c.z < 0;                     // Renderer::isInvalidColor, renderer.h:58-68
+    if (!invalid) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0F; }
+    if (!frame_last) { pb.accum[slot] = a; return; }
+    const float cnt = a.w;
+    const float4 v = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
+    float4 out;
+    if (fp.progressive) {
+        const float4 cur = ro.film[pixel];
+        const float n = (float)((int32_t)cur.w);
+        const float d = n + 1;
+        out = make_float4((n * cur.x + v.x) / d, (n * cur.y + v.y) / d, (n * cur.z + v.z) / d, n + 1);
+    }
+    else {
+        out = v;
+    }
+    ro.film[pixel] = out;
+    if (ro.tile_out) ro.tile_out[slot] = out;
+}
+
+#if !ATN_MAIN_TU
+// the pool's first population: sample 0 of frame 0 for every pixel of this shard (= k_gen_path with the regeneration state words)
+__global__ void __launch_bounds__(256) k_regen_begin(PathBuffers pb, FrameParams fp, atn_camera_param cam)
+{
+    __shared__ BlockAppendShared sh;
+    const uint32_t n = (uint32_t)fp.slot_end;
+    for (uint32_t chunk = (uint32_t)fp.slot_begin + blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
+        uint32_t flags = 0;
+#pragma unroll 1
+        for (int k = 0; k < kChunkItems; k++) {
+            const uint32_t slot = chunk + (uint32_t)k * 256u + threadIdx.x;
+            int32_t ix = 0, iy = 0;
+            if (!(slot < n && slot_to_pixel(fp, slot, ix, iy))) continue;
+            regen_primary(pb, fp, cam, slot, ix, iy, 0u, 0u, 0u);
+            flags |= 1u << k;
+        }
+        block_append2(sh, pb.queue[0], &pb.q_count[0], flags, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
+                      [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
+    }
+}
+
+// after the last stage: the epilogue (and film put) of pixels whose very last sample ended with a shadow ray in flight, and the
+// zero k_gather writes into the tile buffer for slots outside the frame
+__global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams fp, RegenOut ro)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fp.n_slots) return;
+    int32_t x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) {
+        if (ro.tile_out) ro.tile_out[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+        return;
+    }
+    const uint32_t w = __float_as_uint(pb.ray_d[slot].w);
+    if (w & F_PENDING) regen_epilogue(pb, fp, ro, slot, (uint32_t)(y * fp.width + x), mk3(pb.pend[slot]), (uint32_t)fp.spp - 1u, true);
+}
+#endif  // !ATN_MAIN_TU
 
 // REFILL selects the persistent, lane-refilling walk (large trees) or the plain walk (small trees and small launches,
 // where the refill bookkeeping costs more than the idle lanes it removes).
@@ -273,16 +395,20 @@ struct SvgfShade {
 #endif
 struct ShadePartShared { uint32_t perm[kChunk]; uint32_t wcount[kChunkItems][4][2]; };
 
-template <bool SVGF, int MS>
-ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FrameParams& fp, const atn_camera_param& cam, int32_t bounce, const SvgfShade& sv)
+// REGEN: the path-regeneration flavour (k_regen_shade).  `bounce_arg` is then the STAGE of the pool -- it selects queues and counters --
+// and a path's own bounce, sample and frame come out of its state words; a path that ends runs its sample epilogue here and the
+// pixel's next primary ray takes its place in the next stage's queue.
+template <bool SVGF, int MS, bool REGEN = false>
+ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FrameParams& fp, const atn_camera_param& cam, int32_t bounce_arg, const SvgfShade& sv,
+                        const RegenOut& ro = RegenOut{})
 {
     __shared__ BlockAppendShared sh;
 #if ATN_SHADE_PARTITION
     __shared__ ShadePartShared part;
 #endif
-    const uint32_t count = pb.q_count[bounce];
-    const uint32_t* __restrict__ q = pb.queue[bounce & 1];
-    uint32_t* __restrict__ qn = pb.queue[(bounce + 1) & 1];
+    const uint32_t count = pb.q_count[bounce_arg];
+    const uint32_t* __restrict__ q = pb.queue[bounce_arg & 1];
+    uint32_t* __restrict__ qn = pb.queue[(bounce_arg + 1) & 1];
 #if !ATN_SHADE_PARTITION
     uint32_t nhits = 0;
 #endif
@@ -350,6 +476,13 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             const f3 ray_org = mk3(ro4), ray_dir = mk3(rd4);
             float pdfb = ro4.w;
             uint32_t flags = __float_as_uint(rd4.w);
+            uint32_t rg_sample = 0u, rg_frame = 0u;     // REGEN: the path's sample of the frame, frame of the burst
+            int32_t bounce = bounce_arg;
+            if constexpr (REGEN) {
+                rg_sample = flags >> kRegenSampleShift;
+                bounce = (int32_t)((flags >> kRegenBounceShift) & kRegenBounceMask);
+                flags &= kRegenFlagMask;
+            }
             const float4 is4 = pb.isect[slot];
             const int32_t hit_objid = __float_as_int(is4.x);
             const float4 thr4 = pb.thr[slot];
@@ -364,12 +497,26 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 slot_to_pixel(fp, slot, px, py);
                 s4.w = (uint32_t)(py * fp.width + px);
                 const uint32_t rnd = pb.seeds[s4.w < fp.n_seeds ? s4.w : s4.w % here(fp.n_seeds)];    // (one seed per pixel is the rule)
-                const uint32_t fs = fp.frame + (uint32_t)fp.sample;
-                s4.x = fs % 256u;
+                uint32_t fs = fp.frame + (uint32_t)fp.sample;
                 s4.y = __float_as_uint(thr4.w);
+                if constexpr (REGEN) {
+                    rg_frame = s4.y >> kRegenFrameShift;
+                    s4.y &= kRegenDimMask;
+                    fs = fp.frame + rg_frame + rg_sample;
+                }
+                s4.x = fs % 256u;
                 s4.z = rnd * 0x1fe3434fu * ((fs + 133u * rnd) / 256u);
             }
             Cmj smp; smp.idx = s4.x; smp.dim = s4.y; smp.scramble = s4.z;
+            if constexpr (REGEN) {
+                // the pixel's previous sample ended with a shadow ray in flight: that ray has been traced since (its light is in
+                // `pend`), the sample's epilogue runs now, before anything of this sample can reach accum or the film
+                if (flags & F_PENDING) {
+                    flags &= ~F_PENDING;
+                    const bool prev_last = rg_sample == 0u;     // (such a sample was not terminated: no break, the next index is the next sample)
+                    regen_epilogue(pb, fp, ro, slot, s4.w, mk3(pb.pend[slot]), prev_last ? (uint32_t)fp.spp - 1u : rg_sample - 1u, prev_last);
+                }
+            }
 
             flags &= ~F_HIT;
             const bool is_hit = hit_objid >= 0;
@@ -539,7 +686,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         flags |= F_TERMINATED;
                     }
                     // (the path's throughput and sampler position are final here: stored now, not carried across the NEE block)
-                    pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+                    pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
                     thr_stored = true;
                     if (!(flags & F_TERMINATED)) {
                         pdfb = ms.pdf;
@@ -548,12 +695,15 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                             const bool last_spec = m.id >= 0 && m.id < sc.n_materials && sc.materials[m.id].type == ATN_MTRL_SPECULAR;
                             flags = last_spec ? (flags | F_LAST_SPECULAR) : (flags & ~F_LAST_SPECULAR);
                         }
-                        const f3 no = ray_offset(rec.p, ray_along_normal);
-                        const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
-                        pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
-                        pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
-                        wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
+                        if (!REGEN || push_next) {      // (a regenerated pool has no use for the ray of a path that ran out of depth)
+                            const f3 no = ray_offset(rec.p, ray_along_normal);
+                            const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
+                            pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
+                            pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(!REGEN ? flags
+                                : (flags | ((uint32_t)(bounce + 1) << kRegenBounceShift) | (rg_sample << kRegenSampleShift))));
+                            wrote_ray = true;
+                        }
                     }
                     // ---- the NEE evaluation (see above); HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     if (nee && !(flags & F_TERMINATED)) {
@@ -566,7 +716,8 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         push_shadow = radiance_nee_then<MS>(sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r, nullptr,
                                                             [&](const f3& radiance) {
                             // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
-                            const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u));
+                            const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)
+                                                                | ((REGEN && !push_next) ? kShadowFinalFlag : 0u));
                             // the contribution first: `radiance` is dead before the shadow ray's geometry is worked out
                             const f3 lightcontrib = (thr_in * radiance) * albedo;
                             pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, lbits);     // (the light bits again: all finish() needs)
@@ -579,12 +730,35 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     }
                 }
             }
-            if (!push_next && !wrote_ray) {
+            if constexpr (REGEN) {
+                if (!push_next) {
+                    // ---- the path ends here: sample epilogue, then the pixel's next sample (or next frame) takes the slot
+                    f3 ctot = mk3(pb.contrib[slot]);
+                    if (contrib_changed) { ctot = ctot + contrib_add; contrib_changed = false; }
+                    const bool pending = push_shadow;       // out of depth with a shadow ray to trace: the epilogue waits for it (F_PENDING)
+                    const bool frame_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && (flags & F_TERMINATED));   // pathtracing.cpp:350-352
+                    if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, 0.0F);
+                    else regen_epilogue(pb, fp, ro, slot, s4.w, ctot, rg_sample, frame_last);
+                    const uint32_t nk = frame_last ? rg_frame + 1u : rg_frame, ns = frame_last ? 0u : rg_sample + 1u;
+                    if (nk < (uint32_t)fp.burst_frames) {
+                        int32_t px = 0, py = 0;
+                        slot_to_pixel(fp, slot, px, py);
+                        regen_primary(pb, fp, cam, slot, px, py, nk, ns, pending ? F_PENDING : 0u);
+                        thr_stored = true;
+                        push_next = true;
+                    }
+                    else {
+                        pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(pending ? F_PENDING : 0u));     // (k_regen_end looks for it)
+                        thr_stored = true;
+                    }
+                }
+            }
+            else if (!push_next && !wrote_ray) {
                 // path ends here (terminated; a path that merely ran out of depth stored its flags with its last ray):
                 // keep the flags for the sample epilogue
                 pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
             }
-            if (!thr_stored) pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
+            if (!thr_stored) pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
             if (contrib_changed) {
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
@@ -597,7 +771,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
 #else
       auto entry_of = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
 #endif
-      block_append2(sh, qn, &pb.q_count[bounce + 1], push_bits & 0xffffu, pb.shadow_q, &pb.sh_count[bounce], push_bits >> 16, entry_of);
+      block_append2(sh, qn, &pb.q_count[bounce_arg + 1], push_bits & 0xffffu, pb.shadow_q, &pb.sh_count[bounce_arg], push_bits >> 16, entry_of);
     }
 #if !ATN_SHADE_PARTITION
     if (pb.stats) wave_add_stat(&pb.stats[2], nhits);
@@ -635,7 +809,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_boun
 // otherwise (the ray then simply counts as blocked).  A restart re-uses the lane: finish() returns true with the new
 // ray.  Payload bits: 0-25 slot, 26 "an ignored hit was the light object", 27-30 lookups done, 31 (FusedJob) shadow.
 
-template <bool ALPHA>
+// REGEN (path regeneration): the shadow ray of a path's last vertex (kShadowFinalFlag) adds its light to `pend` -- by then the slot's
+// `contrib` belongs to the pixel's next sample.
+template <bool ALPHA, bool REGEN = false>
 struct ShadowJob {
     PathBuffers pb;
     DevScene sc;
@@ -737,8 +913,10 @@ struct ShadowJob {
             }
         }
         if (visible) {
-            const float4 c = pb.contrib[slot];
-            pb.contrib[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
+            float4* dst = pb.contrib;
+            if constexpr (REGEN) { if (lbits & kShadowFinalFlag) dst = pb.pend; }
+            const float4 c = dst[slot];
+            dst[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
         }
         return false;
     }
@@ -763,9 +941,9 @@ __global__ void __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace
 // longest ray), so a frame pays it depth + 1 times instead of 2 * depth times, and each launch has twice the rays to
 // fill the machine with.  The two job kinds touch disjoint state (shadow: contrib; closest: isect).  bs < 0 or
 // bc < 0 = that half is absent (first / last launch of a sample).
-template <bool ALPHA>
+template <bool ALPHA, bool REGEN = false>
 struct FusedJob {
-    ShadowJob<ALPHA> s;
+    ShadowJob<ALPHA, REGEN> s;
     ClosestJob c;
     uint32_t n_shadow;
     float t_min;
@@ -795,16 +973,29 @@ struct FusedJob {
 };
 
 // LDSN: the walk over an LDS copy of the whole node image (small scenes)
-template <bool REFILL, bool ALPHA, bool LDSN = false>
+template <bool REFILL, bool ALPHA, bool LDSN = false, bool REGEN = false>
 __global__ void ATN_TRACE_ATTR __launch_bounds__(kTraceBlock > 256 ? kTraceBlock : 256) k_trace_fused(PathBuffers pb, DevScene sc, int32_t bs, int32_t bc, int32_t launch)
 {
     const uint32_t n_shadow = bs >= 0 ? pb.sh_count[bs] : 0u;
     const uint32_t n_closest = bc >= 0 ? pb.q_count[bc] : 0u;
-    const FusedJob<ALPHA> job{ ShadowJob<ALPHA>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
+    const FusedJob<ALPHA, REGEN> job{ ShadowJob<ALPHA, REGEN>{ pb, sc, kEps }, ClosestJob{ pb, pb.queue[(bc >= 0 ? bc : 0) & 1], kEps }, n_shadow, kEps };
     TravCounters tc{};
-    trace_dispatch<false, REFILL, FusedJob<ALPHA>, LDSN>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
+    trace_dispatch<false, REFILL, FusedJob<ALPHA, REGEN>, LDSN>(sc, n_shadow + n_closest, &pb.fetch_closest[launch], job, &tc);
 }
 
+// k_shade of the regenerated pool (PathTracing::run_regen): stage `stage` of the burst
+template <int MS>
+__global__ void __launch_bounds__(256) k_regen_shade(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t stage, RegenOut ro)
+{
+    shade_body<false, MS, true>(pb, sc, fp, cam, stage, SvgfShade{}, ro);
+}
+template <int MS, int WAVES>
+__global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_bounds__(256) k_regen_shade_wn(PathBuffers pb, DevScene sc, FrameParams fp, atn_camera_param cam, int32_t stage, RegenOut ro)
+{
+    shade_body<false, MS, true>(pb, sc, fp, cam, stage, SvgfShade{}, ro);
+}
+
+#if ATN_MAIN_TU
 // Per-sample epilogue of OnRender's inner loop (pathtracing.cpp:339-352): skip invalid colours,
 // accumulate, stop sampling this pixel once its path terminated.
 __global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, FrameParams fp)
@@ -824,6 +1015,7 @@ __global__ void __launch_bounds__(256) k_accumulate_sample(PathBuffers pb, Frame
     const uint32_t flags = __float_as_uint(pb.ray_d[slot].w);
     if (fp.break_on_terminate && (flags & F_TERMINATED)) pb.done[slot] = 1;
 }
+#endif  // ATN_MAIN_TU
 
 // col / cnt -> Film::put / FilmProgressive::put (renderer/film.cpp:33-45,61-71).
 // film: full-frame vec4[w*h] (row 0 = bottom); tile_out: this GPU's pixels in slot order
@@ -865,6 +1057,7 @@ __global__ void __launch_bounds__(256) k_gather(PathBuffers pb, FrameParams fp, 
     if (tile_out) tile_out[slot] = out;
 }
 
+#if ATN_MAIN_TU       // (to the end of the file: stage kernels and helpers of aten_amd.hip)
 // Scatter all-gathered tile buffers (rank-major, each n_slots_per_rank float4) into a full frame.
 __global__ void __launch_bounds__(256) k_assemble_tiles(const float4* __restrict__ gathered, float4* film,
                                                         int32_t width, int32_t height, int32_t tiles_x, int32_t tiles_y,
@@ -1066,3 +1259,6 @@ __global__ __launch_bounds__(256) void k_cost_to_pixels(FrameParams fp, const ui
     out[2u * p + 1u] = cost[2u * slot + 1u];
 }
 } // namespace atn
+#else
+} // namespace atn
+#endif  // ATN_MAIN_TU

@@ -123,6 +123,28 @@ class PathTracing:
         self.width, self.height = width, height
         return out
 
+    def set_regeneration(self, on):
+        """Path regeneration (include/aten_amd.h): the samples of a frame / the frames of a burst share one pool of path slots."""
+        self._check(self._l.atn_set_regeneration(self._ctx, int(on)))
+
+    def render_burst(self, width, height, n_frames, max_depth=5, rr_depth=3, spp=1, frame=0, progressive=True,
+                     break_on_terminate=True, download=True, profile=False):
+        """n_frames consecutive frames (frame, frame + 1, ...) in one call; the film after the last one."""
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, int(progressive), int(break_on_terminate), 0, int(profile))
+        out = np.empty((height, width, 4), np.float32) if download else None
+        self._check(self._l.atn_render_burst(self._ctx, C.byref(d), n_frames, out.ctypes.data if download else None))
+        self.width, self.height = width, height
+        return out
+
+    def regen_stage_counts(self):
+        """(closest-hit rays, shadow rays) per launch of the last regenerated burst."""
+        n = C.c_uint32(0)
+        self._check(self._l.atn_regen_stage_counts(self._ctx, None, None, 0, C.byref(n)))
+        q = np.zeros(n.value, np.uint32); sh = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._check(self._l.atn_regen_stage_counts(self._ctx, q.ctypes.data, sh.ctypes.data, n.value, C.byref(n)))
+        return q, sh
+
     def set_path_batches(self, n):
         self._check(self._l.atn_set_path_batches(self._ctx, n))
 

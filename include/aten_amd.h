@@ -129,6 +129,26 @@ int atn_set_screen_shard(atn_ctx* ctx, int32_t rank, int32_t world);
  * out_host: optional vec4[width*height], row 0 = bottom (like aten::Film); NULL = stay on device. */
 int atn_render(atn_ctx* ctx, const atn_destination* dst, atn_vec4* out_host);
 
+/* ---- path regeneration (BASELINE.json north_star: "path compaction/regeneration") ---------------------------------------------
+ * The loop behind atn_render is the reference's (src/libidaten/kernel/pathtracing.cpp:105-138): sample by sample, bounce by bounce, one
+ * compaction per bounce, on a ray population that decays until the sample's longest path is over.  With regeneration on, a frame's
+ * samples -- and, through atn_render_burst, a run of consecutive progressive frames -- share one POOL of path slots, one per pixel: the
+ * moment a pixel's path ends, the shade kernel runs its sample epilogue (pathtracing.cpp:339-352; after the frame's last sample
+ * Film::put / FilmProgressive::put, film.cpp:33-71) and writes the pixel's next primary ray (GeneratePath, pathtracing_impl.h:65-110)
+ * into the same slot, so every launch works on a full population.  Per pixel the samples and frames keep the serial order and
+ * arithmetic: films are BYTE-equal to the serial loop's, with both values of break_on_terminate, on any screen shard.
+ *
+ * atn_set_regeneration: 0 = the serial loop (default), 1 = the pool wherever it applies: atn_render with sample > 1 and atn_render_burst
+ * (not with count_stats -- counted frames use the serial loop's counting kernels -- and not atn_svgf_render, whose AOVs are per frame).
+ * atn_render_burst: n_frames x atn_render with frame = dst->frame, dst->frame + 1, ... (the serial loop does exactly that when
+ * regeneration is off or does not apply; n_frames > 1 regenerates only with dst->progressive); out_host receives the film after the last.
+ * atn_regen_stage_counts: closest-hit rays and shadow rays of every launch of the last regenerated burst (the pool's occupancy),
+ * n_stages entries (at most `capacity` written); either array may be NULL. */
+int atn_set_regeneration(atn_ctx* ctx, int32_t mode);
+int32_t atn_get_regeneration(atn_ctx* ctx);
+int atn_render_burst(atn_ctx* ctx, const atn_destination* dst, int32_t n_frames, atn_vec4* out_host);
+int atn_regen_stage_counts(atn_ctx* ctx, uint32_t* closest, uint32_t* shadow, uint32_t capacity, uint32_t* n_stages);
+
 /* ≙ idaten::Renderer::reset (renderer.h:40-43): clears the progressive film. */
 int atn_reset(atn_ctx* ctx);
 

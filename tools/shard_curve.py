@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--regen", type=int, default=0, help="K > 0: path regeneration, bursts of K progressive frames (atn_render_burst)")
+    ap.add_argument("--shards", default="1,2,4,8")
+    ap.add_argument("--all-samples", action="store_true")
+    ap.add_argument("--occupancy", action="store_true", help="with --regen: print the per-launch populations of one burst")
     args = ap.parse_args()
     from aten_amd.renderer import PathTracing
     from aten_amd.scene import scenedefs
@@ -34,21 +38,37 @@ def main():
     r.initSampler(W, H, 0)
     if args.frames_in_flight:
         r.set_frames_in_flight(args.frames_in_flight)
-    out = {}
-    for n in (1, 2, 4, 8):
+    out, occ = {}, {}
+    brk = not args.all_samples
+    r.set_regeneration(args.regen > 0)
+    K = max(args.regen, 1)
+    steps = (args.steps + K - 1) // K * K
+
+    def run(first, n_frames):
+        for i in range(first, first + n_frames, K):
+            if args.regen:
+                r.render_burst(W, H, K, args.depth, 3, spp=args.spp, frame=i, break_on_terminate=brk, download=False)
+            else:
+                r.render(W, H, args.depth, 3, spp=args.spp, frame=i, break_on_terminate=brk, download=False)
+
+    for n in [int(x) for x in args.shards.split(",")]:
         r.setScreenShard(0, n)
-        for i in range(5):
-            r.render(W, H, args.depth, 3, spp=args.spp, frame=i, download=False)
+        run(0, K if args.regen else 5)
         r.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            r.render(W, H, args.depth, 3, spp=args.spp, frame=i, download=False)
+        run(0, steps)
         r.synchronize()
-        out[n] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
-    base = out[1]
-    print(json.dumps({"scene": args.scene, "ms_per_frame_rank0_of_N": out,
-                      "speedup_bound": {n: round(base / v, 2) for n, v in out.items()},
-                      "frames_in_flight": args.frames_in_flight or 1}))
+        out[n] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+        if args.regen and args.occupancy:
+            q, sh = r.regen_stage_counts()
+            occ[n] = {"closest": [int(x) for x in q], "shadow": [int(x) for x in sh], "slots": int(r.tile_slots())}
+    base = out.get(1, next(iter(out.values())))
+    rec = {"scene": args.scene, "ms_per_frame_rank0_of_N": out, "speedup_bound": {n: round(base / v, 2) for n, v in out.items()},
+           "frames_in_flight": args.frames_in_flight or 1, "regen_burst": args.regen, "spp": args.spp, "depth": args.depth,
+           "break_on_terminate": brk, "size": [W, H]}
+    if occ:
+        rec["occupancy"] = occ
+    print(json.dumps(rec))
     r.close()
 
 

@@ -31,6 +31,7 @@ SYMBOLS = [
     "atn_mgpu_set_random", "atn_mgpu_render", "atn_mgpu_reset", "atn_mgpu_synchronize", "atn_mgpu_film_device",
     "atn_mgpu_download_film",
     "atn_set_regeneration", "atn_get_regeneration", "atn_render_burst", "atn_regen_stage_counts",
+    "atn_mgpu_set_regeneration", "atn_mgpu_render_burst",
 ]
 
 
@@ -127,6 +128,8 @@ def lib():
         l.atn_mgpu_set_random.argtypes = [vp, vp, C.c_uint32]
         l.atn_mgpu_render.argtypes = [vp, C.POINTER(Destination), vp]
         l.atn_mgpu_reset.argtypes = [vp]
+        l.atn_mgpu_set_regeneration.argtypes = [vp, C.c_int32]
+        l.atn_mgpu_render_burst.argtypes = [vp, C.POINTER(Destination), C.c_int32, vp]
         l.atn_mgpu_synchronize.argtypes = [vp]
         l.atn_mgpu_film_device.argtypes = [vp]; l.atn_mgpu_film_device.restype = vp
         l.atn_mgpu_download_film.argtypes = [vp, vp]

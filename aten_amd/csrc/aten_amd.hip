@@ -163,8 +163,10 @@ public:
     // path state
     DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, film, tile_out;
     DevBuf<float4> pend;                    // path regeneration: a pixel's previous sample while its last shadow ray is in flight
+    DevBuf<float4> rg_frames;               // path regeneration: [frames of the burst][slots] pixel values on their way to the film (k_regen_end)
     DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters;
-    DevBuf<uint32_t> rg_counters;           // path regeneration: [3][rg_stages + 2] live paths / shadow rays / fetch cursor of every stage
+    DevBuf<uint32_t> rg_counters;           // path regeneration: [3][rg_stages + 3] live paths, shadow rays, fetch cursor of every stage (from stage -1)
+    DevBuf<uint32_t> rg_regions;            // path regeneration: what a shade launch hands to the compaction: [2][slots + chunk] entries, counts per chunk and group
     int32_t rg_stages = 0;                  // stages the counters hold (of the bank's last regenerated burst: atn_regen_stage_counts)
     DevBuf<unsigned long long> stats;
     DevBuf<uint32_t> cost, cost_film;       // per-slot / per-pixel {node visits, triangle tests} of the last count_stats frame
@@ -181,8 +183,8 @@ public:
     // Only the film orders consecutive frames: a frame's k_gather waits for the previous frame's.
     static constexpr int kMaxInFlight = 4;      // (5 / 6 / 8 banks with 8 hardware queues: no gain, profiles/r04_variants_shade_waves.txt)
     struct Bank {
-        DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out, pend;
-        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters, rg_counters;
+        DevBuf<float4> ray_o, ray_d, thr, contrib, isect, sh_o, sh_d, sh_c, accum, tile_out, pend, rg_frames;
+        DevBuf<uint32_t> done, queue0, queue1, shadow_q, counters, rg_counters, rg_regions;
         int32_t rg_stages = 0;
         uint32_t n_slots = 0;
         int32_t counters_depth = 0;
@@ -208,7 +210,7 @@ public:
         ray_o.swap(b.ray_o); ray_d.swap(b.ray_d); thr.swap(b.thr); contrib.swap(b.contrib); isect.swap(b.isect);
         sh_o.swap(b.sh_o); sh_d.swap(b.sh_d); sh_c.swap(b.sh_c); accum.swap(b.accum); tile_out.swap(b.tile_out);
         done.swap(b.done); queue0.swap(b.queue0); queue1.swap(b.queue1); shadow_q.swap(b.shadow_q);
-        counters.swap(b.counters); pend.swap(b.pend); rg_counters.swap(b.rg_counters); std::swap(rg_stages, b.rg_stages);
+        counters.swap(b.counters); pend.swap(b.pend); rg_frames.swap(b.rg_frames); rg_counters.swap(b.rg_counters); rg_regions.swap(b.rg_regions); std::swap(rg_stages, b.rg_stages);
         std::swap(n_slots, b.n_slots); std::swap(counters_depth, b.counters_depth); std::swap(bank_epoch, b.bank_epoch); std::swap(bank_scene_set, b.scene_set);
         for (int k = 0; k < 3; k++) std::swap(ev_read[k], b.ev_read[k]);
         std::swap(stream, b.stream); std::swap(ev_fork, b.ev_fork); std::swap(ev_gather, b.ev_gather);
@@ -1454,6 +1456,10 @@ public:
     // once; the shadow ray adds its light to `pend` in the next stage's trace launch and the epilogue runs at the start of that
     // stage's shade (F_PENDING) -- before anything of the new sample can reach accum or the film.
     //
+    // The film itself is written once per burst, by k_regen_end, from the burst's staging planes (one pixel value per frame): only that
+    // launch is ordered behind the previous burst's (ev_film), so bursts on different banks (atn_set_frames_in_flight) overlap like
+    // serial frames in flight do.  A burst is cut into pieces of at most kRegenStagingBytes of staging planes.
+    //
     // Stages are launched up to the bound n_frames * spp * maxDepth (a pixel's worst case); the kernels read their counts from
     // device memory, and a stage whose queue is empty costs a kernel start.
     // ------------------------------------------------------------------------------------------------
@@ -1461,6 +1467,7 @@ public:
     uint64_t rg_host_totals[4] = {};
     static constexpr int32_t kRegenMaxStages = 1 << 16;
     static constexpr int32_t kRegenMaxDepth = 128;      // 4096 CMJ dimensions / 32 per bounce (kRegenDimMask)
+    static constexpr size_t kRegenStagingBytes = (size_t)1 << 30;
 
     bool regen_applies(const atn_destination& d, int32_t n_frames) const
     {
@@ -1481,7 +1488,19 @@ public:
             if (n_seeds == 0) return fail(ATN_ERR_INVALID_ARG, "atn_init_sampler / atn_set_random has not been called");
             if (d->width <= 0 || d->height <= 0 || d->maxDepth <= 0 || d->sample <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
             ATN_HIP(hipSetDevice(device));
-            return render_regen(d, n_frames, out_host);
+            // pieces of at most kRegenStagingBytes of staging planes (1080p: 32 frames; a 4K frame is 133 MB)
+            const uint64_t tiles = (uint64_t)((d->width + 7) / 8) * ((d->height + 7) / 8);
+            const uint64_t plane = ((tiles + world - 1) / world) * 64u * sizeof(float4);
+            int32_t piece = (int32_t)(kRegenStagingBytes / (plane ? plane : 1u));
+            if (piece < 1) piece = 1;
+            atn_destination part = *d;
+            for (int32_t k = 0; k < n_frames; k += piece) {
+                const int32_t n = n_frames - k < piece ? n_frames - k : piece;
+                part.frame = d->frame + (uint32_t)k;
+                const int rc = render_regen(&part, n, k + n == n_frames ? out_host : nullptr);
+                if (rc) return rc;
+            }
+            return ATN_OK;
         }
         atn_destination one = *d;
         for (int32_t k = 0; k < n_frames; k++) {
@@ -1504,15 +1523,17 @@ public:
         if (rc) return rc;
         const int32_t stages = n_frames * d->sample * d->maxDepth;
         if (pend.n < n_slots) ATN_HIP(pend.resize(n_slots));
-        if (rg_counters.n < (size_t)3 * (stages + 2)) ATN_HIP(rg_counters.resize((size_t)3 * (stages + 2)));
+        const size_t cstride = (size_t)stages + 3;        // counters of stages -1 .. stages + 1
+        if (rg_counters.n < 3 * cstride) ATN_HIP(rg_counters.resize(3 * cstride));
+        if (rg_frames.n < (size_t)n_frames * n_slots) ATN_HIP(rg_frames.resize((size_t)n_frames * n_slots));
         rg_stages = stages;
         FrameParams fp = frame_params(*d);
         fp.burst_frames = n_frames; fp.spp = d->sample;
         PathBuffers pb = buffers(false);
         pb.pend = pend.p;
-        pb.q_count = rg_counters.p; pb.sh_count = rg_counters.p + (stages + 2); pb.fetch_closest = rg_counters.p + 2 * (size_t)(stages + 2);
+        pb.q_count = rg_counters.p + 1; pb.sh_count = rg_counters.p + cstride + 1; pb.fetch_closest = rg_counters.p + 2 * cstride + 1;
         pb.fetch_shadow = nullptr;
-        const RegenOut ro{ film.p, tile_out.p };
+        const RegenOut ro{ rg_frames.p, film.p, tile_out.p };
 
         if (!flavour_forced) use_refill = tree_is_deep && n_slots >= kRefillMinPaths;
         const uint32_t n = n_slots;
@@ -1520,7 +1541,14 @@ public:
         if (env_shade_items) items = env_shade_items;
         fp.chunk_items = items;
         const uint32_t g_shade = grid_for((n + (uint32_t)items - 1u) / (uint32_t)items);
-        const uint32_t g_slots = grid_for(n), g_all = (n + 255u) / 256u, g_fused = trace_grid(2u * n);
+        const uint32_t g_all = (n + 255u) / 256u, g_fused = trace_grid(2u * n);
+        // the regions a shade launch writes for the compaction in front of the next stage (kernels.hpp, k_regen_compact)
+        const uint32_t chunk_size = 256u * (uint32_t)items, n_chunks = (n + chunk_size - 1u) / chunk_size, n_groups = (n_chunks + kRegenGroup - 1u) / kRegenGroup;
+        const size_t region_words = (size_t)n_chunks * chunk_size;
+        const size_t rg_words = 2 * region_words + 2 * (size_t)n_chunks + 4 * (size_t)n_groups;
+        if (rg_regions.n < rg_words) ATN_HIP(rg_regions.resize(rg_words));
+        pb.q_regions = rg_regions.p; pb.sh_regions = rg_regions.p + region_words; pb.region_counts = rg_regions.p + 2 * region_words;
+        uint32_t* const group_counts[2] = { pb.region_counts + 2 * (size_t)n_chunks, pb.region_counts + 2 * (size_t)n_chunks + 2 * (size_t)n_groups };
         const bool big = n >= 1500u * 1000u;
         const bool small_set = scene.material_set == kMsCore || scene.material_set == kMsDisney || scene.material_set == kMsAnalytic;
         const int shade_waves = !small_set ? 0 : env_shade_waves ? env_shade_waves
@@ -1528,11 +1556,12 @@ public:
         const bool lds_nodes = lds_scene_bytes() != 0u;
         const uint32_t sb = (lds_nodes && lds_scene_bytes() > 8192u) ? 256u : simple_block;
 
-        ATN_HIP(hipMemsetAsync(rg_counters.p, 0, (size_t)3 * (stages + 2) * sizeof(uint32_t), stream));
-        // every shade launch of the burst may put pixels into the film: behind the film's last writer from the start
-        if (film_pending) ATN_HIP(hipStreamWaitEvent(stream, ev_film, 0));
+        ATN_HIP(hipMemsetAsync(rg_counters.p, 0, 3 * cstride * sizeof(uint32_t), stream));
+        ATN_HIP(hipMemsetAsync(group_counts[0], 0, 4 * (size_t)n_groups * sizeof(uint32_t), stream));
         prof_begin(prof, ATN_K_GEN);
-        regen_launch_begin(g_slots, stream, pb, fp, camera);
+        pb.group_counts = group_counts[0];
+        regen_launch_begin(g_shade, stream, pb, fp, camera);
+        regen_launch_compact(n_chunks, stream, pb, 0, chunk_size, group_counts[1], n_groups);
         prof_end(prof);
         for (int32_t i = 0; i <= stages; i++) {
             // trace(i): the shadow rays shade(i - 1) cast + the closest-hit rays of the paths (continued and regenerated) it queued
@@ -1546,10 +1575,15 @@ public:
             prof_end(prof);
             if (i < stages) {
                 prof_begin(prof, ATN_K_SHADE);
+                pb.group_counts = group_counts[(i + 1) & 1];
                 regen_launch_shade(scene.material_set, shade_waves, g_shade, stream, pb, scene, fp, camera, i, ro);
+                prof_end(prof);
+                prof_begin(prof, ATN_K_ACCUM);      // (timed under the serial loop's per-sample epilogue kind)
+                regen_launch_compact(n_chunks, stream, pb, i + 1, chunk_size, group_counts[i & 1], n_groups);
                 prof_end(prof);
             }
         }
+        if (film_pending) ATN_HIP(hipStreamWaitEvent(stream, ev_film, 0));     // the film is a running mean: burst order
         prof_begin(prof, ATN_K_GATHER);
         regen_launch_end(g_all, stream, pb, fp, ro);
         prof_end(prof);
@@ -1574,11 +1608,12 @@ public:
         const uint32_t ns = (uint32_t)rg_stages + 1u;
         if (n_stages) *n_stages = rg_stages > 0 ? ns : 0u;
         if (rg_stages <= 0 || !rg_counters.p) return ATN_OK;
-        std::vector<uint32_t> h((size_t)2 * (rg_stages + 2));
+        const size_t cstride = (size_t)rg_stages + 3;
+        std::vector<uint32_t> h(2 * cstride);
         ATN_HIP(hipMemcpy(h.data(), rg_counters.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < ns && i < capacity; i++) {
-            if (closest) closest[i] = h[i];
-            if (shadow) shadow[i] = h[(size_t)(rg_stages + 2) + i];
+            if (closest) closest[i] = h[1 + i];
+            if (shadow) shadow[i] = h[cstride + 1 + i];
         }
         return ATN_OK;
     }
@@ -2304,6 +2339,22 @@ int atn_mgpu_render(atn_mgpu* mg, const atn_destination* dst, atn_vec4* out_host
 {
     MG_OR_FAIL(mg);
     return mg_guarded(mg, [&] { return mg->m.render(dst, out_host); });
+}
+int atn_mgpu_render_burst(atn_mgpu* mg, const atn_destination* dst, int32_t n_frames, atn_vec4* out_host)
+{
+    MG_OR_FAIL(mg);
+    return mg_guarded(mg, [&] { return mg->m.render_burst(dst, n_frames, out_host); });
+}
+int atn_mgpu_set_regeneration(atn_mgpu* mg, int32_t mode)
+{
+    MG_OR_FAIL(mg);
+    if (mode < 0 || mode > 1) return mg->m.fail(ATN_ERR_INVALID_ARG, "regeneration mode out of range");
+    return mg_guarded(mg, [&] {
+        int rc = mg->m.synchronize();
+        if (rc) return rc;
+        for (int i = 0; i < mg->m.n; i++) mg->m.shard[i]->regen_mode = mode;
+        return (int)ATN_OK;
+    });
 }
 int atn_mgpu_reset(atn_mgpu* mg)
 {

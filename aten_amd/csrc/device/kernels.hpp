@@ -36,6 +36,17 @@ constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.la
 // sample.  What the serial loop keeps in launch arguments becomes per-path state, packed into words that travel anyway:
 //   ray_d.w : flags (bits 0-4) | bounce (bits 5-12) | sample of the frame (bits 13-31)
 //   thr.w   : CMJ dimension (bits 0-11) | frame of the burst (bits 12-31)
+// Two things a pool that lives for tens of stages needs, and the serial loop's five bounces do not:
+//  * QUEUES THAT STAY IN SLOT ORDER.  The serial loop's append reserves room for a block's entries with one atomic, so the blocks' runs
+//    land in the order the blocks finish -- harmless for five bounces after a freshly generated, sorted queue.  In a pool every
+//    stage shuffles the runs again and a chunk of the next stage straddles two unrelated runs: after ten stages a wave's 64 entries
+//    are 64 unrelated pixels -- state reads uncoalesced, primary rays incoherent: shade +56 %, trace +8 % on sponza_lod after 8 frames,
+//    growing with the length of the burst.  So k_regen_shade writes a chunk's entries into the chunk's OWN region (no atomic, a count
+//    per chunk) and k_regen_compact squeezes the regions into the next stage's dense queues in order: a stable compaction, and the
+//    queue remains the sorted list of live slots for the whole burst.
+//  * a frame's finished pixel value goes to a staging plane of the burst (RegenOut::frames), not into the film: the film is a running
+//    mean, ordered frame by frame, and a burst that wrote it from its first stage on could not overlap with the burst before it.
+//    k_regen_end applies the burst's frames to the film, pixel by pixel in frame order, once the previous burst's k_regen_end is done.
 constexpr uint32_t F_PENDING = 16u;         // the pixel's PREVIOUS sample still waits for its last shadow ray: its epilogue runs at the next shade
 constexpr uint32_t kRegenFlagMask = 31u;
 constexpr uint32_t kRegenBounceShift = 5u, kRegenBounceMask = 255u;
@@ -66,6 +77,13 @@ struct PathBuffers {
     uint32_t* cost;     // [2 * slots] node visits / triangle tests of the pixel's walks this sample (count_stats frames; else null)
     unsigned long long* stats; // [8]: closest rays, shadow rays, hits, closest node visits, closest tri tests, shadow node visits, shadow tri tests
     float4* pend;       // regeneration only: contrib.xyz of the pixel's previous sample while its last shadow ray is in flight (F_PENDING)
+    // regeneration only: what k_regen_shade writes for k_regen_compact -- chunk c's surviving / regenerated entries and shadow entries
+    // in region c (chunk_size entries wide) of q_regions / sh_regions, their numbers in region_counts[2 * c], [2 * c + 1], and the
+    // sums of every kRegenGroup chunks' numbers in group_counts[2 * g], [2 * g + 1] (atomic adds: sums do not depend on their order)
+    uint32_t* q_regions;
+    uint32_t* sh_regions;
+    uint32_t* region_counts;
+    uint32_t* group_counts;
 };
 
 struct FrameParams {
@@ -117,7 +135,8 @@ struct BlockAppendShared { uint32_t wave_total[2][4]; uint32_t base[2]; };
 
 // flagsA/flagsB: bit k set <=> this thread's k-th entry goes to queue A/B.  entry(k) returns the
 // value to append for item k.  Must be called by all 256 threads of the block.
-template <class EntryFn>
+// REGION: the queues are this block's own (a region per chunk, k_regen_shade): entries from index 0, the totals STORED to the counters.
+template <class EntryFn, bool REGION = false>
 ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, uint32_t flagsA,
                            uint32_t* qB, uint32_t* cntB, uint32_t flagsB, EntryFn entry)
 {
@@ -134,8 +153,11 @@ ATN_DEV void block_append2(BlockAppendShared& sh, uint32_t* qA, uint32_t* cntA, 
     if (threadIdx.x == 0) {
         const uint32_t a = sh.wave_total[0][0] + sh.wave_total[0][1] + sh.wave_total[0][2] + sh.wave_total[0][3];
         const uint32_t b = sh.wave_total[1][0] + sh.wave_total[1][1] + sh.wave_total[1][2] + sh.wave_total[1][3];
+        if constexpr (REGION) { *cntA = a; *cntB = b; sh.base[0] = 0u; sh.base[1] = 0u; }
+        else {
         sh.base[0] = a ? atomicAdd(cntA, a) : 0u;
         sh.base[1] = (b && cntB) ? atomicAdd(cntB, b) : 0u;
+        }
     }
     __syncthreads();
     uint32_t offA = sh.base[0], offB = sh.base[1];
@@ -217,8 +239,9 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
 // ---- path regeneration: the pieces k_regen_begin / k_regen_shade / k_regen_end share ---------------------------------------
 // GeneratePath (pathtracing_impl.h:65-110) for pixel (ix, iy), sampler frame `fs` = frame + sample: the same operations on the
 // same operands as k_gen_path, so the same bits.
-ATN_DEV void regen_primary(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, uint32_t slot, int32_t ix, int32_t iy,
-                           uint32_t frame_k, uint32_t sample_s, uint32_t flags)
+struct RegenState { float4 o, d, t; };     // what a slot's ray_o / ray_d / thr hold
+ATN_DEV RegenState regen_primary_state(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, int32_t ix, int32_t iy,
+                                       uint32_t frame_k, uint32_t sample_s, uint32_t flags)
 {
     const uint32_t idx = (uint32_t)(iy * fp.width + ix);
     const uint32_t rnd = pb.seeds[idx % fp.n_seeds];
@@ -231,23 +254,34 @@ ATN_DEV void regen_primary(const PathBuffers& pb, const FrameParams& fp, const a
     const float t = ((float)iy + r2) / (float)cam.height;
     f3 org, dir;
     pinhole_sample(cam, s, t, org, dir);
-    pb.ray_o[slot] = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
-    pb.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(flags | (sample_s << kRegenSampleShift)));    // bounce 0
-    pb.thr[slot] = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(smp.dim | (frame_k << kRegenFrameShift)));
+    RegenState st;
+    st.o = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
+    st.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(flags | (sample_s << kRegenSampleShift)));    // bounce 0
+    st.t = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(smp.dim | (frame_k << kRegenFrameShift)));
+    return st;
+}
+ATN_DEV void regen_primary(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, uint32_t slot, int32_t ix, int32_t iy,
+                           uint32_t frame_k, uint32_t sample_s, uint32_t flags)
+{
+    const RegenState st = regen_primary_state(pb, fp, cam, ix, iy, frame_k, sample_s, flags);
+    pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
     pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
 }
 
 struct RegenOut {
-    float4* film;       // full-frame vec4[w*h]
-    float4* tile_out;   // this GPU's pixels in slot order (may be null)
+    float4* frames;     // [burst_frames][n_slots]: the pixel value (col / cnt, 1) every frame of the burst hands to Film::put
+    float4* film;       // full-frame vec4[w*h] (k_regen_end only)
+    float4* tile_out;   // this GPU's pixels in slot order (k_regen_end only; may be null)
 };
+constexpr uint32_t kRegenGroup = 64u;       // chunks per group of k_regen_compact's two-level prefix sum
 
 // One sample's epilogue -- OnRender's inner loop, pathtracing.cpp:339-352 = k_accumulate_sample -- and, when it was the pixel's last
-// sample of the frame, Film::put / FilmProgressive::put (film.cpp:33-45,61-71) = k_gather.  `c`: the sample's contribution;
-// `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path).  Per pixel the operations and
-// their order are the serial loop's: the pixel's samples and frames pass through its slot one after the other.
-ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro, uint32_t slot, uint32_t pixel,
-                            const f3& c, uint32_t sample_s, bool frame_last)
+// sample of the frame, the value k_gather hands to Film::put / FilmProgressive::put (film.cpp:33-45,61-71), stored for k_regen_end.
+// `c`: the sample's contribution; `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path);
+// `frame_k`: the frame of the burst.  Per pixel the operations and their order are the serial loop's: the pixel's samples and frames
+// pass through its slot one after the other.
+ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro, uint32_t slot,
+                            const f3& c, uint32_t sample_s, uint32_t frame_k, bool frame_last)
 {
     float4 a = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
     if (sample_s != 0u) a = pb.accum[slot];
@@ -256,44 +290,69 @@ ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const 
     if (!invalid) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0F; }
     if (!frame_last) { pb.accum[slot] = a; return; }
     const float cnt = a.w;
-    const float4 v = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
-    float4 out;
-    if (fp.progressive) {
-        const float4 cur = ro.film[pixel];
-        const float n = (float)((int32_t)cur.w);
-        const float d = n + 1;
-        out = make_float4((n * cur.x + v.x) / d, (n * cur.y + v.y) / d, (n * cur.z + v.z) / d, n + 1);
-    }
-    else {
-        out = v;
-    }
-    ro.film[pixel] = out;
-    if (ro.tile_out) ro.tile_out[slot] = out;
+    ro.frames[(size_t)frame_k * (uint32_t)fp.n_slots + slot] = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
 }
 
 #if !ATN_MAIN_TU
-// the pool's first population: sample 0 of frame 0 for every pixel of this shard (= k_gen_path with the regeneration state words)
+// The pool's first population: sample 0 of frame 0 for every pixel of this shard (= k_gen_path with the regeneration state words), as
+// regions for k_regen_compact(0) like a shade launch's output ("stage -1": q_count[-1] = the slots it worked on).
 __global__ void __launch_bounds__(256) k_regen_begin(PathBuffers pb, FrameParams fp, atn_camera_param cam)
 {
     __shared__ BlockAppendShared sh;
-    const uint32_t n = (uint32_t)fp.slot_end;
-    for (uint32_t chunk = (uint32_t)fp.slot_begin + blockIdx.x * kChunk; chunk < n; chunk += gridDim.x * kChunk) {
+    const uint32_t n = (uint32_t)fp.n_slots;
+    const int items = fp.chunk_items;
+    const uint32_t chunk_size = 256u * (uint32_t)items;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) pb.q_count[-1] = n;
+    for (uint32_t chunk = blockIdx.x * chunk_size; chunk < n; chunk += gridDim.x * chunk_size) {
         uint32_t flags = 0;
 #pragma unroll 1
-        for (int k = 0; k < kChunkItems; k++) {
+        for (int k = 0; k < items; k++) {
             const uint32_t slot = chunk + (uint32_t)k * 256u + threadIdx.x;
             int32_t ix = 0, iy = 0;
             if (!(slot < n && slot_to_pixel(fp, slot, ix, iy))) continue;
             regen_primary(pb, fp, cam, slot, ix, iy, 0u, 0u, 0u);
             flags |= 1u << k;
         }
-        block_append2(sh, pb.queue[0], &pb.q_count[0], flags, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
-                      [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; });
+        auto entry_of = [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; };
+        const uint32_t c = chunk / chunk_size;
+        block_append2<decltype(entry_of), true>(sh, pb.q_regions + chunk, &pb.region_counts[2u * c], flags,
+                                                pb.sh_regions + chunk, &pb.region_counts[2u * c + 1u], 0u, entry_of);
+        if (threadIdx.x == 0u) { const uint32_t v = pb.region_counts[2u * c]; if (v) atomicAdd(&pb.group_counts[2u * (c / kRegenGroup)], v); }
     }
 }
 
-// after the last stage: the epilogue (and film put) of pixels whose very last sample ended with a shadow ray in flight, and the
-// zero k_gather writes into the tile buffer for slots outside the frame
+// The stable compaction between two stages: region c of q_regions / sh_regions (what chunk c of shade(stage - 1) kept or regenerated,
+// and its shadow rays) goes to the dense queues at the sum of the counts before it -- groups of kRegenGroup chunks first, then the
+// chunks of its own group -- so the next stage's queues list their slots in the order of this stage's.  Block c = region c; the
+// last valid region also writes the totals (q_count[stage], sh_count[stage - 1]); block 0 clears the group sums of the other parity
+// for shade(stage).
+__global__ void __launch_bounds__(256) k_regen_compact(PathBuffers pb, int32_t stage, uint32_t chunk_size, uint32_t* group_counts_next, uint32_t n_groups)
+{
+    __shared__ uint32_t red[2][4];
+    const uint32_t n_prev = pb.q_count[stage - 1];
+    const uint32_t n_chunks = (n_prev + chunk_size - 1u) / chunk_size;      // chunks shade(stage - 1) worked on
+    const uint32_t c = blockIdx.x;
+    if (c == 0u) { for (uint32_t g = threadIdx.x; g < 2u * n_groups; g += 256u) group_counts_next[g] = 0u; }
+    if (c >= n_chunks) return;
+    const uint32_t g0 = c / kRegenGroup;
+    uint32_t sq = 0, ss = 0;
+    for (uint32_t g = threadIdx.x; g < g0; g += 256u) { sq += pb.group_counts[2u * g]; ss += pb.group_counts[2u * g + 1u]; }
+    for (uint32_t r = g0 * kRegenGroup + threadIdx.x; r < c; r += 256u) { sq += pb.region_counts[2u * r]; ss += pb.region_counts[2u * r + 1u]; }
+    for (int off = 32; off > 0; off >>= 1) { sq += __shfl_down(sq, off); ss += __shfl_down(ss, off); }
+    if ((threadIdx.x & 63u) == 0u) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    const uint32_t base_q = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const uint32_t base_s = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const uint32_t nq = pb.region_counts[2u * c], ns = pb.region_counts[2u * c + 1u];
+    uint32_t* __restrict__ qd = pb.queue[stage & 1];
+    for (uint32_t e = threadIdx.x; e < nq; e += 256u) qd[base_q + e] = pb.q_regions[(size_t)c * chunk_size + e];
+    for (uint32_t e = threadIdx.x; e < ns; e += 256u) pb.shadow_q[base_s + e] = pb.sh_regions[(size_t)c * chunk_size + e];
+    if (c == n_chunks - 1u && threadIdx.x == 0u) { pb.q_count[stage] = base_q + nq; pb.sh_count[stage - 1] = base_s + ns; }
+}
+
+// After the last stage: the epilogue of pixels whose very last sample ended with a shadow ray in flight, then the burst's frames into
+// the film -- Film::put / FilmProgressive::put (film.cpp:33-45,61-71) = k_gather, frame after frame for every pixel -- and the zero
+// k_gather writes into the tile buffer for slots outside the frame.
 __global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams fp, RegenOut ro)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,7 +363,24 @@ __global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams f
         return;
     }
     const uint32_t w = __float_as_uint(pb.ray_d[slot].w);
-    if (w & F_PENDING) regen_epilogue(pb, fp, ro, slot, (uint32_t)(y * fp.width + x), mk3(pb.pend[slot]), (uint32_t)fp.spp - 1u, true);
+    if (w & F_PENDING) regen_epilogue(pb, fp, ro, slot, mk3(pb.pend[slot]), (uint32_t)fp.spp - 1u, (uint32_t)fp.burst_frames - 1u, true);
+    const uint32_t pixel = (uint32_t)(y * fp.width + x);
+    float4 out = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+    if (fp.progressive) out = ro.film[pixel];
+    for (int32_t k = 0; k < fp.burst_frames; k++) {
+        const float4 v = ro.frames[(size_t)k * (uint32_t)fp.n_slots + slot];
+        if (fp.progressive) {
+            const float4 cur = out;
+            const float n = (float)((int32_t)cur.w);
+            const float d = n + 1;
+            out = make_float4((n * cur.x + v.x) / d, (n * cur.y + v.y) / d, (n * cur.z + v.z) / d, n + 1);
+        }
+        else {
+            out = v;
+        }
+    }
+    ro.film[pixel] = out;
+    if (ro.tile_out) ro.tile_out[slot] = out;
 }
 #endif  // !ATN_MAIN_TU
 
@@ -394,6 +470,11 @@ struct SvgfShade {
 #define ATN_SHADE_PARTITION 1
 #endif
 struct ShadePartShared { uint32_t perm[kChunk]; uint32_t wcount[kChunkItems][4][2]; };
+// REGEN: what brings a chunk's results back into the order of its queue entries (inv: where in the chunk an entry of the permutation
+// came from; oflag: per queue entry, bit 0 = goes on to the next stage, bit 1 = has a shadow ray).  The hits-first permutation is for
+// the shading only: a queue written in permuted order is scrambled a little more by every stage, and after some tens of stages a
+// wave's 64 entries are 64 slots from all over the chunk's neighbourhood -- every state read one cache line per lane.
+template <bool ON> struct ShadeOrderShared { uint16_t inv[ON ? kChunk : 1]; uint8_t oflag[ON ? kChunk : 1]; };
 
 // REGEN: the path-regeneration flavour (k_regen_shade).  `bounce_arg` is then the STAGE of the pool -- it selects queues and counters --
 // and a path's own bounce, sample and frame come out of its state words; a path that ends runs its sample epilogue here and the
@@ -405,6 +486,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
     __shared__ BlockAppendShared sh;
 #if ATN_SHADE_PARTITION
     __shared__ ShadePartShared part;
+    __shared__ ShadeOrderShared<REGEN> order[1];
 #endif
     const uint32_t count = pb.q_count[bounce_arg];
     const uint32_t* __restrict__ q = pb.queue[bounce_arg & 1];
@@ -449,7 +531,11 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                   if (w < wave) { bh_w += part.wcount[k][w][0]; bm_w += part.wcount[k][w][1]; }
                   before_h += part.wcount[k][w][0]; before_m += part.wcount[k][w][1];
               }
-              if (valid) part.perm[hit ? bh_w + bits_below_lane(bh) : total_hits + bm_w + bits_below_lane(bm)] = q[j];
+              if (valid) {
+                  const uint32_t pos = hit ? bh_w + bits_below_lane(bh) : total_hits + bm_w + bits_below_lane(bm);
+                  part.perm[pos] = q[j];
+                  if constexpr (REGEN) order[0].inv[pos] = (uint16_t)(j - chunk);
+              }
           }
           __syncthreads();
       }
@@ -514,9 +600,38 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 if (flags & F_PENDING) {
                     flags &= ~F_PENDING;
                     const bool prev_last = rg_sample == 0u;     // (such a sample was not terminated: no break, the next index is the next sample)
-                    regen_epilogue(pb, fp, ro, slot, s4.w, mk3(pb.pend[slot]), prev_last ? (uint32_t)fp.spp - 1u : rg_sample - 1u, prev_last);
+                    regen_epilogue(pb, fp, ro, slot, mk3(pb.pend[slot]), prev_last ? (uint32_t)fp.spp - 1u : rg_sample - 1u,
+                                   prev_last ? rg_frame - 1u : rg_frame, prev_last);
                 }
             }
+            // REGEN: where the path ends.  The sample epilogue -- at once, or handed over (`pend`, F_PENDING) when the path ran out of
+            // depth without being terminated: the shadow ray of its last vertex, if NEE casts one, is yet to be traced -- and the state of
+            // the pixel's next sample (or next frame) for the slot.  The caller stores that state for ALL lanes of the wave together with
+            // the continued paths' (one full-line store per array: an array written by two groups of lanes at two places of the kernel
+            // costs the L2 and the HBM a read-modify-write per line -- measured).
+            bool rg_stored = false;
+            auto regen_end = [&](bool out_of_depth) -> RegenState {
+                f3 ctot = mk3(pb.contrib[slot]);
+                if (contrib_changed) { ctot = ctot + contrib_add; contrib_changed = false; }
+                const bool pending = out_of_depth;      // (not terminated)
+                const bool frame_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && !out_of_depth);    // pathtracing.cpp:350-352
+                if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, 0.0F);
+                else regen_epilogue(pb, fp, ro, slot, ctot, rg_sample, rg_frame, frame_last);
+                const uint32_t nk = frame_last ? rg_frame + 1u : rg_frame, ns = frame_last ? 0u : rg_sample + 1u;
+                RegenState st;
+                if (nk < (uint32_t)fp.burst_frames) {
+                    int32_t px = 0, py = 0;
+                    slot_to_pixel(fp, slot, px, py);
+                    st = regen_primary_state(pb, fp, cam, px, py, nk, ns, pending ? F_PENDING : 0u);
+                    pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+                    push_next = true;
+                }
+                else {
+                    st.o = ro4; st.t = thr4;
+                    st.d = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(pending ? F_PENDING : 0u));     // (k_regen_end looks for it)
+                }
+                return st;
+            };
 
             flags &= ~F_HIT;
             const bool is_hit = hit_objid >= 0;
@@ -686,7 +801,32 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         flags |= F_TERMINATED;
                     }
                     // (the path's throughput and sampler position are final here: stored now, not carried across the NEE block)
-                    pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
+                    bool nee_final = false;     // REGEN: the vertex is the path's last and NEE's shadow ray adds to `pend`
+                    if constexpr (REGEN) {
+                        RegenState st;
+                        bool cont = false;
+                        if (!(flags & F_TERMINATED)) {
+                            pdfb = ms.pdf;
+                            flags = (m.attrib & ATN_MTRL_ATTR_SINGULAR) ? (flags | F_SINGULAR) : (flags & ~F_SINGULAR);
+                            cont = bounce + 1 < fp.max_depth;
+                            nee_final = !cont;
+                        }
+                        if (cont) {
+                            const f3 no = ray_offset(rec.p, ray_along_normal);
+                            const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
+                            st.o = make_float4(no.x, no.y, no.z, pdfb);
+                            st.d = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags | ((uint32_t)(bounce + 1) << kRegenBounceShift) | (rg_sample << kRegenSampleShift)));
+                            st.t = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
+                            push_next = true;
+                        }
+                        else {
+                            st = regen_end(nee_final);
+                        }
+                        pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
+                        rg_stored = true; thr_stored = true; wrote_ray = true;
+                    }
+                    else {
+                    pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
                     thr_stored = true;
                     if (!(flags & F_TERMINATED)) {
                         pdfb = ms.pdf;
@@ -695,15 +835,13 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                             const bool last_spec = m.id >= 0 && m.id < sc.n_materials && sc.materials[m.id].type == ATN_MTRL_SPECULAR;
                             flags = last_spec ? (flags | F_LAST_SPECULAR) : (flags & ~F_LAST_SPECULAR);
                         }
+                        const f3 no = ray_offset(rec.p, ray_along_normal);
+                        const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
+                        pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
+                        pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
+                        wrote_ray = true;
                         push_next = (bounce + 1 < fp.max_depth);
-                        if (!REGEN || push_next) {      // (a regenerated pool has no use for the ray of a path that ran out of depth)
-                            const f3 no = ray_offset(rec.p, ray_along_normal);
-                            const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
-                            pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
-                            pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(!REGEN ? flags
-                                : (flags | ((uint32_t)(bounce + 1) << kRegenBounceShift) | (rg_sample << kRegenSampleShift))));
-                            wrote_ray = true;
-                        }
+                    }
                     }
                     // ---- the NEE evaluation (see above); HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     if (nee && !(flags & F_TERMINATED)) {
@@ -717,7 +855,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                                                             [&](const f3& radiance) {
                             // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
                             const float lbits = __uint_as_float((uint32_t)li | ((m.attrib & kAttrStencilAlways) ? kShadowStencilFlag : 0u)
-                                                                | ((REGEN && !push_next) ? kShadowFinalFlag : 0u));
+                                                                | (nee_final ? kShadowFinalFlag : 0u));
                             // the contribution first: `radiance` is dead before the shadow ray's geometry is worked out
                             const f3 lightcontrib = (thr_in * radiance) * albedo;
                             pb.sh_c[slot] = make_float4(lightcontrib.x, lightcontrib.y, lightcontrib.z, lbits);     // (the light bits again: all finish() needs)
@@ -731,26 +869,10 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 }
             }
             if constexpr (REGEN) {
-                if (!push_next) {
-                    // ---- the path ends here: sample epilogue, then the pixel's next sample (or next frame) takes the slot
-                    f3 ctot = mk3(pb.contrib[slot]);
-                    if (contrib_changed) { ctot = ctot + contrib_add; contrib_changed = false; }
-                    const bool pending = push_shadow;       // out of depth with a shadow ray to trace: the epilogue waits for it (F_PENDING)
-                    const bool frame_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && (flags & F_TERMINATED));   // pathtracing.cpp:350-352
-                    if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, 0.0F);
-                    else regen_epilogue(pb, fp, ro, slot, s4.w, ctot, rg_sample, frame_last);
-                    const uint32_t nk = frame_last ? rg_frame + 1u : rg_frame, ns = frame_last ? 0u : rg_sample + 1u;
-                    if (nk < (uint32_t)fp.burst_frames) {
-                        int32_t px = 0, py = 0;
-                        slot_to_pixel(fp, slot, px, py);
-                        regen_primary(pb, fp, cam, slot, px, py, nk, ns, pending ? F_PENDING : 0u);
-                        thr_stored = true;
-                        push_next = true;
-                    }
-                    else {
-                        pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(pending ? F_PENDING : 0u));     // (k_regen_end looks for it)
-                        thr_stored = true;
-                    }
+                if (!rg_stored) {       // a miss, an emissive or first-hit toon surface: the path ended without reaching the block above
+                    const RegenState st = regen_end(false);
+                    pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
+                    thr_stored = true;
                 }
             }
             else if (!push_next && !wrote_ray) {
@@ -758,19 +880,36 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 // keep the flags for the sample epilogue
                 pb.ray_d[slot] = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(flags));
             }
-            if (!thr_stored) pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
+            if (!thr_stored) pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim));
             if (contrib_changed) {
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             }
         }
-        push_bits |= (push_next ? 1u << k : 0u) | (push_shadow ? 0x10000u << k : 0u);
+        if constexpr (REGEN) { if (valid) order[0].oflag[order[0].inv[e]] = (uint8_t)((push_next ? 1u : 0u) | (push_shadow ? 2u : 0u)); }
+        else push_bits |= (push_next ? 1u << k : 0u) | (push_shadow ? 0x10000u << k : 0u);
       }
 #if ATN_SHADE_PARTITION
       auto entry_of = [&](int k) { return part.perm[(uint32_t)k * 256u + threadIdx.x]; };
 #else
       auto entry_of = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
 #endif
+      if constexpr (REGEN) {
+          // into this chunk's own regions, in the order of the chunk's queue entries, no atomic on a queue cursor (k_regen_compact makes
+          // the dense queues of them)
+          __syncthreads();
+          for (int k = 0; k < items; k++) {
+              const uint32_t jl = (uint32_t)k * 256u + threadIdx.x;
+              const uint32_t f = jl < n_valid ? (uint32_t)order[0].oflag[jl] : 0u;
+              push_bits |= ((f & 1u) << k) | (((f >> 1) & 1u) << (16 + k));
+          }
+          auto entry_in_order = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
+          const uint32_t c = chunk / chunk_size;
+          block_append2<decltype(entry_in_order), true>(sh, pb.q_regions + chunk, &pb.region_counts[2u * c], push_bits & 0xffffu,
+                                                        pb.sh_regions + chunk, &pb.region_counts[2u * c + 1u], push_bits >> 16, entry_in_order);
+          if (threadIdx.x < 2u) { const uint32_t v = pb.region_counts[2u * c + threadIdx.x]; if (v) atomicAdd(&pb.group_counts[2u * (c / kRegenGroup) + threadIdx.x], v); }
+      }
+      else
       block_append2(sh, qn, &pb.q_count[bounce_arg + 1], push_bits & 0xffffu, pb.shadow_q, &pb.sh_count[bounce_arg], push_bits >> 16, entry_of);
     }
 #if !ATN_SHADE_PARTITION

@@ -19,6 +19,8 @@ void regen_launch_trace(const RegenTraceLaunch& cfg, hipStream_t st, const PathB
 // waves: 0 = the compiler's allocation, 4 / 5 = held to that many waves per SIMD (the three smaller material sets only)
 void regen_launch_shade(int material_set, int waves, uint32_t grid, hipStream_t st, const PathBuffers& pb, const DevScene& sc, const FrameParams& fp,
                         const atn_camera_param& cam, int32_t stage, const RegenOut& ro);
+// the stable compaction in front of trace(stage): regions written by shade(stage - 1) (by regen_launch_begin for stage 0) -> dense queues
+void regen_launch_compact(uint32_t grid, hipStream_t st, const PathBuffers& pb, int32_t stage, uint32_t chunk_size, uint32_t* group_counts_next, uint32_t n_groups);
 void regen_launch_end(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro);
 
 } // namespace atn

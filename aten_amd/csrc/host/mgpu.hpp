@@ -168,9 +168,14 @@ public:
 
     // ≙ idaten::PathTracing::render for the whole node.  Returns once everything is ENQUEUED (or, with out_host,
     // once the frame is in host memory).
-    int render(const atn_destination* d, atn_vec4* out_host)
+    int render(const atn_destination* d, atn_vec4* out_host) { return render_burst(d, 1, out_host); }
+
+    // n_frames consecutive frames on every shard (atn_render_burst: one regenerated pool per shard when regeneration is on), then ONE
+    // exchange: the progressive film is only looked at after the burst, so its tiles travel once per burst, not once per frame.
+    int render_burst(const atn_destination* d, int32_t n_frames, atn_vec4* out_host)
     {
         if (!d || d->width <= 0 || d->height <= 0) return fail(ATN_ERR_INVALID_ARG, "bad destination");
+        if (n_frames <= 0) return fail(ATN_ERR_INVALID_ARG, "bad burst length");
         const int k = (int)(frames & 1u);
         const int d0 = shard[0]->device;
         const size_t px = (size_t)d->width * d->height;
@@ -190,7 +195,7 @@ public:
         const bool wait_assembled = assembled_recorded[k];
         int rc = on_all([&](int i) -> int {
             PathTracing& r = *shard[i];
-            int rr = r.render(d, nullptr);
+            int rr = n_frames == 1 ? r.render(d, nullptr) : r.render_burst(d, n_frames, nullptr);
             if (rr != ATN_OK) return rr;
             // push this shard's tiles into slot i of the gather buffer on device 0 (peer copy on the shard's stream)
             if (wait_assembled) { if (hipStreamWaitEvent(r.stream, ev_assembled[k], 0) != hipSuccess) return r.fail(ATN_ERR_HIP, "hipStreamWaitEvent"); }

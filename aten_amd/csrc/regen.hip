@@ -17,6 +17,11 @@ void regen_launch_begin(uint32_t grid, hipStream_t st, const PathBuffers& pb, co
     hipLaunchKernelGGL(k_regen_begin, dim3(grid), dim3(256), 0, st, pb, fp, cam);
 }
 
+void regen_launch_compact(uint32_t grid, hipStream_t st, const PathBuffers& pb, int32_t stage, uint32_t chunk_size, uint32_t* group_counts_next, uint32_t n_groups)
+{
+    hipLaunchKernelGGL(k_regen_compact, dim3(grid), dim3(256), 0, st, pb, stage, chunk_size, group_counts_next, n_groups);
+}
+
 void regen_launch_end(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro)
 {
     hipLaunchKernelGGL(k_regen_end, dim3(grid), dim3(256), 0, st, pb, fp, ro);

@@ -444,6 +444,18 @@ class MultiGpuPathTracing:
         self.width, self.height = width, height
         return out
 
+    def set_regeneration(self, on):
+        self._check(self._l.atn_mgpu_set_regeneration(self._mg, int(on)))
+
+    def render_burst(self, width, height, n_frames, max_depth=5, rr_depth=3, spp=1, frame=0, progressive=True,
+                     break_on_terminate=True, download=True):
+        """n_frames consecutive frames on every shard, one exchange of the tiles at the end."""
+        d = Destination(width, height, max_depth, rr_depth, spp, frame, int(progressive), int(break_on_terminate), 0, 0)
+        out = np.empty((height, width, 4), np.float32) if download else None
+        self._check(self._l.atn_mgpu_render_burst(self._mg, C.byref(d), n_frames, out.ctypes.data if download else None))
+        self.width, self.height = width, height
+        return out
+
     def reset(self):
         self._check(self._l.atn_mgpu_reset(self._mg))
 

@@ -243,9 +243,18 @@ def run_workload(args, cfg, ctx):
     stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
     full = [None]
 
+    regen_timed = int(cfg.get("regen_timed") or 0)      # --regen K: the timed steps ARE regenerated bursts of K frames
+    if regen_timed:
+        r.set_regeneration(True)
+
     def step(frame, profile):
         if svgf:
             r.svgf_render(W, H, depth, rr, spp=spp, frame=frame, compute_motion=True, download=False, profile=profile)
+            return
+        if regen_timed:
+            # (a step is still one frame: every K-th step enqueues the burst that holds it)
+            if frame % regen_timed == 0:
+                r.render_burst(W, H, regen_timed, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False, profile=profile)
             return
         r.render(W, H, depth, rr, spp=spp, frame=frame, progressive=True, break_on_terminate=brk, download=False,
                  profile=profile)
@@ -331,6 +340,35 @@ def run_workload(args, cfg, ctx):
         film_sha256 = hashlib.sha256(np.ascontiguousarray(final_img).tobytes()).hexdigest()
         if not cfg.get("dump"):
             final_img = None
+
+    # Path regeneration (atn_set_regeneration / atn_render_burst) beside the serial loop: the same K frames from
+    # a reset film as bursts of `regen_burst` frames in one pool of path slots, same frames in flight.  OFF in the timed region above
+    # unless --regen is given: measured, it does not win on these workloads -- the line carries both numbers and the film check.
+    regen_info = None
+    regen_burst = int(cfg.get("regen_burst", 8))
+    if not svgf and not use_dist and regen_burst > 0 and not cfg.get("regen_timed"):
+        nb = max(1, steps // regen_burst)
+
+        def regen_region():
+            r.reset()
+            sync_all()
+            t0 = time.perf_counter()
+            for b in range(nb):
+                r.render_burst(W, H, regen_burst, depth, rr, spp=spp, frame=b * regen_burst, progressive=True, break_on_terminate=brk, download=False)
+            sync_all()
+            return time.perf_counter() - t0
+        r.set_regeneration(True)
+        regen_region()
+        ts = [regen_region() for _ in range(3)]
+        regen_film = hashlib.sha256(np.ascontiguousarray(r.download_film()).tobytes()).hexdigest() if nb * regen_burst == steps else None
+        q, sh = r.regen_stage_counts()
+        r.set_regeneration(False)
+        regen_ms = 1e3 * float(np.median(ts)) / (nb * regen_burst)
+        regen_info = {"enabled_in_timed_region": False, "burst_frames": regen_burst, "ms_per_frame": round(regen_ms, 4),
+                      "serial_ms_per_frame": round(1e3 * elapsed / steps, 4), "speedup": round(1e3 * elapsed / steps / regen_ms, 4),
+                      "film_equals_serial": (regen_film == film_sha256) if regen_film else None,
+                      "stages": int(len(q)), "mean_closest_rays_per_stage": round(float(q[q > 0].mean()) if (q > 0).any() else 0.0),
+                      "path_slots": int(r.tile_slots())}
 
     # the same K frames with ONE frame in flight: what a caller that waits for every frame sees (frame LATENCY); `value`
     # above is THROUGHPUT with `in_flight` frames overlapping (progressive accumulation never waits for a frame)
@@ -654,6 +692,7 @@ def run_workload(args, cfg, ctx):
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
                        "frames_in_flight": in_flight,
+                       "regeneration": ({"enabled_in_timed_region": True, "burst_frames": regen_timed} if regen_timed else regen_info),
                        "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"])),
                        "anyhit_twins": n_twins, "planar_area_lights": n_planar},
             "ray_segments_per_frame": round(ray_segments), "Mray_segments_per_s": round(ray_segments / 1e6 / (elapsed / steps), 2),
@@ -698,6 +737,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="consecutive frames enqueued on rotating banks of path state and streams (atn_set_frames_in_flight): "
                          "one frame's launch tails overlap the next frame's bulk; 1 = strictly one frame at a time")
+    ap.add_argument("--regen", type=int, default=0,
+                    help="K > 0: the timed steps are path-regenerated bursts of K progressive frames (atn_render_burst; --steps a multiple of K, one GPU); "
+                         "default 0: the serial loop is timed and an 8-frame regenerated burst is measured beside it (config.regeneration)")
     ap.add_argument("--mgpu", action="store_true",
                     help="one process, every GPU behind the C-ABI (atn_mgpu_*: worker thread per GPU, peer-copy gather into "
                          "GPU 0) instead of one process per GPU + RCCL all_gather")
@@ -725,6 +767,8 @@ def main():
         args.svgf = True
     if args.steps is None:
         args.steps = 200 if args.width * args.height * args.spp <= 4 * 1920 * 1080 else 20
+    if args.regen and (args.steps % args.regen or args.svgf or args.gpus > 1):
+        ap.error("--regen K needs --steps to be a multiple of K, one GPU, and not --svgf")
 
     if needs_self_launch(args.gpus, args.mgpu, os.environ):
         # `python bench.py --gpus N` on its own: become the launcher the contract describes (one rank per GPU)
@@ -756,7 +800,7 @@ def main():
     ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}
     cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
            "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
-           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump,
+           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "regen_timed": args.regen,
            "verify_film": args.verify_film or (world > 1 and not args.no_verify_film)}
     out = run_workload(args, cfg, ctx)
 

@@ -279,6 +279,10 @@ void* atn_mgpu_film_device(atn_mgpu* mg);
 int atn_mgpu_download_film(atn_mgpu* mg, atn_vec4* out_host);
 /* atn_set_frames_in_flight on every shard. */
 int atn_mgpu_set_frames_in_flight(atn_mgpu* mg, int32_t n);
+/* atn_set_regeneration on every shard; atn_render_burst on every shard followed by ONE exchange of the tiles (a progressive film is
+ * looked at after the burst: its tiles travel once per burst, not once per frame). */
+int atn_mgpu_set_regeneration(atn_mgpu* mg, int32_t mode);
+int atn_mgpu_render_burst(atn_mgpu* mg, const atn_destination* dst, int32_t n_frames, atn_vec4* out_host);
 
 /* ---- SVGF (next tier, BASELINE config 5) -------------------------------------------------------
  * ≙ aten::SVGFRenderer (src/libaten/renderer/svgf/svgf.{h,cpp}): the path pass with AOV outputs

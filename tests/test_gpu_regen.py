@@ -155,6 +155,31 @@ def test_regeneration_with_frames_in_flight_and_other_calls(sponza):
         r.close()
 
 
+def test_regeneration_on_the_node_wide_renderer(sponza):
+    """atn_mgpu_set_regeneration / atn_mgpu_render_burst: a regenerated pool per shard, one exchange per burst; the assembled film
+    equals the unsharded serial loop's."""
+    from aten_amd.renderer import MultiGpuPathTracing
+    fs, cam = sponza
+    w, h = 176, 100
+    r = _ctx(fs, cam, w, h)
+    try:
+        want, _, _ = _serial_frames(r, w, h, 5, 5, 2, False)
+    finally:
+        r.close()
+    m = MultiGpuPathTracing([0, 0, 0])
+    try:
+        m.UpdateSceneData(fs)
+        m.updateCamera(create_camera(cam["pos"], cam["at"], cam["vfov"], w, h))
+        m.initSampler(w, h, 0)
+        m.set_regeneration(True)
+        got = m.render_burst(w, h, 3, 5, 3, spp=2, frame=0, break_on_terminate=False)
+        assert got.tobytes() == want[2].tobytes()
+        got = m.render_burst(w, h, 2, 5, 3, spp=2, frame=3, break_on_terminate=False)
+        assert got.tobytes() == want[4].tobytes()
+    finally:
+        m.close()
+
+
 def _variant(name):
     from aten_amd import layout as L
     from aten_amd.scene import scenedefs

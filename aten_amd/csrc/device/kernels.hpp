@@ -771,10 +771,21 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     const bool nee = sc.n_lights > 0 && !invalid_mtrl;
                     const uint32_t nee_dim = smp.dim;
                     const f3 thr_in = throughput;
+                    // what the BSDF sample, the NEE evaluation and the light sample share at this vertex (shading.hpp, HitPre)
+                    HitPre hp;
+                    tangent_coordinate(orienting_normal, hp.t, hp.b);
+                    hp.rough = ggx_roughness(sc, m, rec.u, rec.v);
+                    hp.lambda_v = m.type == ATN_MTRL_GGX ? ggx_lambda(hp.rough, -ray_dir, orienting_normal) : 0.0F;
+                    int32_t nee_light = 0;      // the light NEE picked (kept: the draw that picked it is not repeated)
                     if (nee) {
-                        int32_t li = (int32_t)(cmj_next(smp) * (float)here(sc.n_lights));
-                        li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
-                        smp.dim += light_sample_draws(sc.lights[li], sc);
+                        // with ONE light the pick is 0 whatever the draw says ((int)(r * 1) with r < 1): the draw is skipped, its
+                        // dimension consumed
+                        if (here(sc.n_lights) > 1) {
+                            nee_light = (int32_t)(cmj_next(smp) * (float)here(sc.n_lights));
+                            nee_light = nee_light < sc.n_lights - 1 ? nee_light : sc.n_lights - 1;
+                        }
+                        else smp.dim++;
+                        smp.dim += light_sample_draws(sc.lights[nee_light], sc);
                     }
 
                     // ---- ComputeRussianProbability, pathtracing_impl.h:680-698
@@ -789,13 +800,13 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
 
                     // ---- sampleMaterial + PrepareForNextBounce, pathtracing_impl.h:700-743
                     MtrlSample ms;
-                    sample_material<MS>(ms, sc, m, orienting_normal, ray_dir, smp, rec.u, rec.v, mtrl_slot, pre_r);
+                    sample_material<MS>(ms, sc, m, orienting_normal, ray_dir, smp, rec.u, rec.v, mtrl_slot, pre_r, &hp);
                     const f3 next_dir = normalize(ms.dir);
                     const f3 ray_along_normal = dot(orienting_normal, next_dir) >= 0.0f ? orienting_normal : -orienting_normal;
                     const float c = dot(ray_along_normal, next_dir);
                     if (ms.pdf > 0 && c > 0) {
                         throughput = throughput * ((((albedo * ms.bsdf) * c) / ms.pdf));
-                        throughput = throughput / russian_prob;
+                        if (russian_prob != 1.0F) throughput = throughput / russian_prob;      // (x / 1 is x, bit for bit: three IEEE divisions on every vertex below the roulette depth)
                     }
                     else {
                         flags |= F_TERMINATED;
@@ -845,12 +856,11 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     }
                     // ---- the NEE evaluation (see above); HitShadowRay runs only for non-terminated paths (pathtracing_impl.h:362-368)
                     if (nee && !(flags & F_TERMINATED)) {
-                        Cmj sl; sl.idx = smp.idx; sl.dim = nee_dim; sl.scramble = smp.scramble;
-                        int32_t li = (int32_t)(cmj_next(sl) * (float)here(sc.n_lights));
-                        li = li < sc.n_lights - 1 ? li : sc.n_lights - 1;
+                        Cmj sl; sl.idx = smp.idx; sl.dim = nee_dim + 1u; sl.scramble = smp.scramble;     // (behind the light pick's dimension)
+                        const int32_t li = nee_light;
                         const float lightSelectPdf = sc.inv_n_lights;       // 1.0f / (float)n_lights, divided once at upload
                         LightSample ls;
-                        sample_light(ls, sc.lights[li], sc, rec.p, orienting_normal, sl);
+                        sample_light(ls, sc.lights[li], sc, rec.p, orienting_normal, sl, &hp);
                         push_shadow = radiance_nee_then<MS>(sc, ray_dir, orienting_normal, m, rec.u, rec.v, lightSelectPdf, ls, mtrl_slot, pre_r, nullptr,
                                                             [&](const f3& radiance) {
                             // (next to the light index: HitShadowRay's surface_mtrl.stencil_type == ALWAYS, pathtracing.cpp:59-66)
@@ -864,7 +874,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                             const f3 so = ray_offset(rec.p, orienting_normal);
                             pb.sh_o[slot] = make_float4(so.x, so.y, so.z, distToLight);
                             pb.sh_d[slot] = make_float4(dirToLight.x, dirToLight.y, dirToLight.z, lbits);
-                        });
+                        }, &hp);
                     }
                 }
             }

@@ -10,6 +10,12 @@ namespace atn {
 
 struct HitRec { f3 p; float area; f3 normal; float u, v; };
 struct MtrlSample { f3 dir; f3 bsdf; float pdf; };
+// What k_shade works out ONCE per hit for everything that follows at the same (normal, wi, material): the BSDF sample, the NEE
+// evaluation of the same BSDF, the light sample around the same normal.  Each value is the result of exactly the operations the
+// consumers would run themselves on the same operands (GetTangentCoordinate of the shading normal, the roughness lookup, GGX's
+// Smith lambda of the view direction): sharing them changes no bit, it takes ~90 + ~65 lane-instructions out of every NEE vertex.
+// A null pointer = compute on the spot (the stage kernels behind atn_material_table, the toon path).
+struct HitPre { f3 t, b; float rough, lambda_v; };
 
 ATN_DEV m4 load_m4(const DevScene& sc, int32_t elem) // element index of a mat4
 {
@@ -161,7 +167,7 @@ ATN_DEV f3 reflect_vector(const f3& wi, const f3& n)            // material.h:51
 
 // Diffuse, material/diffuse.h:86-137
 ATN_DEV float diffuse_pdf(const f3& n, const f3& wo) { return fabsf(dot(n, wo)) / kPi; }
-ATN_DEV f3 diffuse_dir(const f3& n, float r1, float r2)
+ATN_DEV f3 diffuse_dir(const f3& n, float r1, float r2, const HitPre* pre = nullptr)
 {
     const float costheta = sqrtf(1 - r1);
     const float sintheta = sqrtf(r1);
@@ -169,7 +175,7 @@ ATN_DEV f3 diffuse_dir(const f3& n, float r1, float r2)
     const float cosphi = cosf(phi);
     const float sinphi = sinf(phi);
     f3 t, b;
-    tangent_coordinate(n, t, b);
+    if (pre) { t = pre->t; b = pre->b; } else tangent_coordinate(n, t, b);
     const f3 dir = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + n * costheta;
     return normalize(dir);
 }
@@ -194,9 +200,9 @@ ATN_DEV float ggx_lambda(float roughness, const f3& w, const f3& n)
     const float a2 = 1.0f / ((roughness * roughness) * tan2);
     return (-1.0f + sqrtf(1.0f + 1.0f / a2)) / 2.0f;
 }
-ATN_DEV float ggx_G2(float roughness, const f3& view, const f3& light, const f3& n)
+ATN_DEV float ggx_G2(float roughness, const f3& view, const f3& light, const f3& n, const HitPre* pre = nullptr)
 {
-    const float lwi = ggx_lambda(roughness, view, n);
+    const float lwi = pre ? pre->lambda_v : ggx_lambda(roughness, view, n);
     const float lwo = ggx_lambda(roughness, light, n);
     return 1.0f / ((1.0f + lwi) + lwo);
 }
@@ -212,7 +218,7 @@ ATN_DEV float ggx_pdf(float roughness, const f3& n, const f3& wi, const f3& wo)
     const f3 wh = normalize((-wi) + wo);
     return ggx_pdf_h(roughness, n, wh, wo);
 }
-ATN_DEV f3 ggx_sample_m(float roughness, const f3& n, float r1, float r2)
+ATN_DEV f3 ggx_sample_m(float roughness, const f3& n, float r1, float r2, const HitPre* pre = nullptr)
 {
     float theta = atanf(roughness * sqrtf(r1 / (1 - r1)));
     theta = ((theta >= 0) ? theta : (theta + 2 * kPi));
@@ -222,29 +228,30 @@ ATN_DEV f3 ggx_sample_m(float roughness, const f3& n, float r1, float r2)
     const float cosphi = cosf(phi);
     const float sinphi = sinf(phi);
     f3 t, b;
-    tangent_coordinate(n, t, b);
+    if (pre) { t = pre->t; b = pre->b; } else tangent_coordinate(n, t, b);
     const f3 m = ((t * sintheta) * cosphi + (b * sintheta) * sinphi) + n * costheta;
     return normalize(m);
 }
-ATN_DEV f3 ggx_dir(float r1, float r2, float roughness, const f3& wi, const f3& n)
+ATN_DEV f3 ggx_dir(float r1, float r2, float roughness, const f3& wi, const f3& n, const HitPre* pre = nullptr)
 {
-    return reflect_vector(wi, ggx_sample_m(roughness, n, r1, r2));
+    return reflect_vector(wi, ggx_sample_m(roughness, n, r1, r2, pre));
 }
-ATN_DEV f3 ggx_brdf_h(float roughness, float ior, const f3& N, const f3& V, const f3& L, const f3& H)     // ComputeBRDFWithHalfVector
+// (pre: HitPre::lambda_v is the Smith lambda of V at this roughness and N -- the GGX material only)
+ATN_DEV f3 ggx_brdf_h(float roughness, float ior, const f3& N, const f3& V, const f3& L, const f3& H, const HitPre* pre = nullptr)     // ComputeBRDFWithHalfVector
 {
     const float NL = fabsf(dot(N, L));
     const float NV = fabsf(dot(N, V));
     const float D = ggx_D(H, N, roughness);
-    const float G = ggx_G2(roughness, V, L, N);
+    const float G = ggx_G2(roughness, V, L, N, pre);
     const float F = schlick_fresnel(1.0F, ior, L, H);
     const float denom = (4 * NL) * NV;
     const float bsdf = denom > kEps ? ((F * G) * D) / denom : 0.0f;
     return mk3(bsdf);
 }
-ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo)
+ATN_DEV f3 ggx_brdf(float roughness, float ior, const f3& N, const f3& wi, const f3& wo, const HitPre* pre = nullptr)
 {
     const f3 V = -wi, L = wo;
-    return ggx_brdf_h(roughness, ior, N, V, L, normalize(L + V));
+    return ggx_brdf_h(roughness, ior, N, V, L, normalize(L + V), pre);
 }
 
 // ToonSpecular (material/toon.cpp:288-367): GGX with the "stylized highlight" half vector; a material type that only
@@ -412,8 +419,11 @@ ATN_DEV MtrlSample disney_bsdf(const DevMaterial& m, const f3& n, const f3& wi, 
     r.dir = wo;
     return r;
 }
-ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp)  // :443-555
+ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, const f3& wi, Cmj& smp, const HitPre* pre = nullptr)  // :443-555
 {
+    HitPre frame;       // (the tangent frame only: Disney's lobes have their own roughnesses)
+    if (pre) { frame.t = pre->t; frame.b = pre->b; frame.rough = 0.0F; frame.lambda_v = 0.0F; }
+    const HitPre* fr = pre ? &frame : nullptr;
     const float r1 = cmj_next(smp), r2 = cmj_next(smp), r3 = cmj_next(smp);
     const f3 base = mk3(m.baseColor);
     DisW w = dis_weights(base, m.metallic, m.sheen, m.specular, m.clearcoat);
@@ -422,26 +432,26 @@ ATN_DEV void disney_sample(MtrlSample& res, const DevMaterial& m, const f3& n, c
     f3 wo; float p = 0;
     f3 d = mk3(0.0F), sh = mk3(0.0F), sp = mk3(0.0F), cc = mk3(0.0F);
     if (r3 < c0) {
-        wo = diffuse_dir(N, r1, r2);
+        wo = diffuse_dir(N, r1, r2, fr);
         d = dis_diffuse_brdf(base, m.roughness, m.subsurface, V, wo, N);
         p = diffuse_pdf(N, wo);
         p *= w.d; w.d = 0.0F;
     }
     else if (r3 < c1) {
-        wo = diffuse_dir(N, r1, r2);
+        wo = diffuse_dir(N, r1, r2, fr);
         sh = dis_sheen_brdf(base, m.sheen, m.sheenTint, V, wo);
         p = 1 / kPi;
         p *= w.sh; w.sh = 0.0F;
     }
     else if (r3 < c2) {
-        wo = ggx_dir(r1, r2, m.roughness, -V, N);
+        wo = ggx_dir(r1, r2, m.roughness, -V, N, fr);
         sp = dis_specular_brdf(base, m.roughness, m.metallic, m.specular, m.specularTint, V, wo, N);
         p = dis_specular_pdf(m.roughness, V, wo, N);
         p *= w.sp; w.sp = 0.0F;
     }
     else {
         const float a = mixf(0.1F, 0.001F, m.clearcoatGloss);
-        wo = reflect_vector(-V, ggx_sample_m(a, N, r1, r2));
+        wo = reflect_vector(-V, ggx_sample_m(a, N, r1, r2, fr));
         cc = dis_clearcoat_brdf(m.clearcoat, V, wo);
         p = dis_clearcoat_pdf(m.roughness, V, wo, N);
         p *= w.cc; w.cc = 0.0F;
@@ -1083,7 +1093,7 @@ ATN_DEV f3 carpaint_bsdf(const DevScene& sc, const DevMaterial& m, const CarPain
 // mtrl_id / pre_r: only CarPaint reads them (its parameter block and the random number material::applyNormal drew).
 template <int MS = kMsCarPaint>
 ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMaterial& m, const f3& normal,
-                             const f3& wi, Cmj& smp, float u, float v, int32_t mtrl_id = 0, float pre_r = 0.0F)
+                             const f3& wi, Cmj& smp, float u, float v, int32_t mtrl_id = 0, float pre_r = 0.0F, const HitPre* pre = nullptr)
 {
     if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) {       // CarPaint::sample, car_paint.cpp:178-193
         const CarPaintP p = carpaint_params(sc, mtrl_id);
@@ -1098,7 +1108,7 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
             refraction_sample(r, m, normal, wi, smp);
             return;
         case ATN_MTRL_BECKMAN: {
-            const float rough = ggx_roughness(sc, m, u, v);
+            const float rough = pre ? pre->rough : ggx_roughness(sc, m, u, v);
             const float r1 = cmj_next(smp), r2 = cmj_next(smp);
             r.dir = reflect_vector(wi, beckman_sample_m(rough, normal, r1, r2));
             r.pdf = beckman_pdf(rough, normal, wi, r.dir);
@@ -1107,9 +1117,9 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
         }
         case ATN_MTRL_VELVET: {
             const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-            r.dir = diffuse_dir(normal, r1, r2);
+            r.dir = diffuse_dir(normal, r1, r2, pre);
             r.pdf = diffuse_pdf(normal, r.dir);
-            r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+            r.bsdf = velvet_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, r.dir);
             return;
         }
         case ATN_MTRL_MICROFACET_REFRACTION:
@@ -1120,9 +1130,9 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
             return;
         case ATN_MTRL_OREN_NAYAR: {
             const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-            r.dir = diffuse_dir(normal, r1, r2);
+            r.dir = diffuse_dir(normal, r1, r2, pre);
             r.pdf = oren_nayar_pdf(normal, r.dir);
-            r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, r.dir);
+            r.bsdf = oren_nayar_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, r.dir);
             return;
         }
         default: break;
@@ -1137,19 +1147,19 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
         break;
     }
     case ATN_MTRL_GGX: {
-        const float rough = ggx_roughness(sc, m, u, v);
+        const float rough = pre ? pre->rough : ggx_roughness(sc, m, u, v);
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-        r.dir = ggx_dir(r1, r2, rough, wi, normal);
+        r.dir = ggx_dir(r1, r2, rough, wi, normal, pre);
         r.pdf = ggx_pdf(rough, normal, wi, r.dir);
-        r.bsdf = ggx_brdf(rough, m.ior, normal, wi, r.dir);
+        r.bsdf = ggx_brdf(rough, m.ior, normal, wi, r.dir, pre);
         break;
     }
     case ATN_MTRL_DISNEY:
-        if (MS >= kMsDisney) { disney_sample(r, m, normal, wi, smp); break; }
+        if (MS >= kMsDisney) { disney_sample(r, m, normal, wi, smp, pre); break; }
         [[fallthrough]];
     default: {  // Diffuse, Emissive (emissive.h:70-83) and the reference's fallback
         const float r1 = cmj_next(smp), r2 = cmj_next(smp);
-        r.dir = diffuse_dir(normal, r1, r2);
+        r.dir = diffuse_dir(normal, r1, r2, pre);
         r.pdf = diffuse_pdf(normal, r.dir);
         r.bsdf = diffuse_brdf();
         break;
@@ -1158,7 +1168,7 @@ ATN_DEV void sample_material(MtrlSample& r, const DevScene& sc, const DevMateria
 }
 template <int MS = kMsCarPaint>
 ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
-                           int32_t mtrl_id = 0)
+                           int32_t mtrl_id = 0, const HitPre* pre = nullptr)
 {
     if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) return carpaint_pdf(carpaint_params(sc, mtrl_id), normal, wi, wo);
     if (MS >= kMsToon && m.type == ATN_MTRL_TOON_SPECULAR) {       // ToonSpecular::ComputePDF, toon.cpp:288-301
@@ -1168,7 +1178,7 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
     if (MS >= kMsAnalytic) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: return 1.0F;
-        case ATN_MTRL_BECKMAN: return beckman_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
+        case ATN_MTRL_BECKMAN: return beckman_pdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, wo);
         case ATN_MTRL_OREN_NAYAR: return oren_nayar_pdf(normal, wo);
         case ATN_MTRL_VELVET: return diffuse_pdf(normal, wo);
         case ATN_MTRL_MICROFACET_REFRACTION: return 1.0F;
@@ -1178,14 +1188,14 @@ ATN_DEV float material_pdf(const DevScene& sc, const DevMaterial& m, const f3& n
     }
     switch (m.type) {
     case ATN_MTRL_SPECULAR: return 1.0F;
-    case ATN_MTRL_GGX: return ggx_pdf(ggx_roughness(sc, m, u, v), normal, wi, wo);
+    case ATN_MTRL_GGX: return ggx_pdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, wo);
     case ATN_MTRL_DISNEY: if (MS >= kMsDisney) return disney_pdf(m, normal, wi, wo); [[fallthrough]];
     default: return diffuse_pdf(normal, wo);
     }
 }
 template <int MS = kMsCarPaint>
 ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const f3& normal, const f3& wi, const f3& wo, float u, float v,
-                                 int32_t mtrl_id = 0, float pre_r = 0.0F)
+                                 int32_t mtrl_id = 0, float pre_r = 0.0F, const HitPre* pre = nullptr)
 {
     MtrlSample r; r.pdf = 0.0F; r.dir = wo; r.bsdf = mk3(0.0F);
     if (MS >= kMsCarPaint && m.type == ATN_MTRL_CARPAINT) { r.bsdf = carpaint_bsdf(sc, m, carpaint_params(sc, mtrl_id), normal, wi, wo, u, v, pre_r); return r; }
@@ -1197,9 +1207,9 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     if (MS >= kMsAnalytic) {
         switch (m.type) {
         case ATN_MTRL_REFRACTION: r.bsdf = mk3(0.0F); return r;
-        case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); return r;
-        case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
-        case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
+        case ATN_MTRL_BECKMAN: r.bsdf = beckman_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); return r;
+        case ATN_MTRL_OREN_NAYAR: r.bsdf = oren_nayar_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
+        case ATN_MTRL_VELVET: r.bsdf = velvet_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), normal, wi, wo); return r;
         case ATN_MTRL_MICROFACET_REFRACTION: r.bsdf = mk3(0.0F); return r;
         case ATN_MTRL_RETROREFLECTIVE: return retro_bsdf(m, normal, wi, wo);
         default: break;
@@ -1207,7 +1217,7 @@ ATN_DEV MtrlSample material_bsdf(const DevScene& sc, const DevMaterial& m, const
     }
     switch (m.type) {
     case ATN_MTRL_SPECULAR: { const float c = dot(normal, wo); r.bsdf = mk3(c == 0.0F ? 0.0F : 1.0F / c); break; }
-    case ATN_MTRL_GGX: r.bsdf = ggx_brdf(ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo); break;
+    case ATN_MTRL_GGX: r.bsdf = ggx_brdf(pre ? pre->rough : ggx_roughness(sc, m, u, v), m.ior, normal, wi, wo, pre); break;
     case ATN_MTRL_DISNEY: if (MS >= kMsDisney) { r = disney_bsdf(m, normal, wi, wo); break; } [[fallthrough]];
     default: r.bsdf = diffuse_brdf(); break;
     }
@@ -1299,7 +1309,8 @@ ATN_DEV float ibl_direction_pdf(const DevScene& sc, const f3& dir)
 }
 
 // Light::sample (light/light_impl.h:12-43) and the per-type samplers it dispatches to
-ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const DevScene& sc, const f3& org, const f3& nml, Cmj& smp)
+ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const DevScene& sc, const f3& org, const f3& nml, Cmj& smp,
+                          const HitPre* pre = nullptr)
 {
     res.pdf = 0.0F; res.dist = 0.0F; res.color = mk3(0.0F);
     res.pos = org; res.dir = mk3(0.0F, 1.0F, 0.0F); res.nml = mk3(0.0F, 1.0F, 0.0F);
@@ -1395,7 +1406,7 @@ ATN_DEV void sample_light(LightSample& res, const atn_light_param& lp, const Dev
             res.dist = 1.0F;
             break;
         }
-        res.dir = diffuse_dir(nml, r1, r2);
+        res.dir = diffuse_dir(nml, r1, r2, pre);
         float u, v;
         direction_to_uv(res.dir, u, v);
         res.pos = org + sc.ibl_scene_radius * res.dir;
@@ -1477,12 +1488,12 @@ ATN_DEV uint32_t light_sample_draws(const atn_light_param& lp, const DevScene& s
 template <int MS = kMsCarPaint, class Then>
 ATN_DEV bool radiance_nee_then(const DevScene& sc, const f3& wi, const f3& nml, const DevMaterial& m,
                                float hu, float hv, float light_select_prob, const LightSample& ls, int32_t mtrl_id, float pre_r,
-                               float* weight_ptr, Then&& then)
+                               float* weight_ptr, Then&& then, const HitPre* pre = nullptr)
 {
     if (weight_ptr) *weight_ptr = 0.0F;
     const float cosShadow = dot(nml, ls.dir);
-    float path_pdf = material_pdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id);
-    const MtrlSample ev = material_bsdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id, pre_r);
+    float path_pdf = material_pdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id, pre);
+    const MtrlSample ev = material_bsdf<MS>(sc, m, nml, wi, ls.dir, hu, hv, mtrl_id, pre_r, pre);
     if (ev.pdf > 0) path_pdf = ev.pdf;
     const float cosLight = dot(ls.nml, -ls.dir);
     float dist2 = sqr(ls.dist);

@@ -108,6 +108,7 @@ public:
     bool env_lds_nodes = true;  // small node images are walked from an LDS copy (ATEN_AMD_LDS_NODES=0: from global memory)
     int env_anyhit_twin = 1;    // ATEN_AMD_ANYHIT_TWIN: 0 = no any-hit twins, 1 = where the model says they pay (scene_upload.hpp, kTwinPays), 2 = wherever possible
     int env_anyhit_twin_dirs = 8;   // ATEN_AMD_ANYHIT_TWIN_DIRS: 8 = one twin per direction octant (default), 1 = the one direction-free twin
+    bool opt_node_layout = true, opt_planar_lights = true;      // ATEN_AMD_NODE_LAYOUT / ATEN_AMD_PLANAR_LIGHTS at creation; atn_set_upload_options
     bool env_atrous4 = true;    // SVGF a-trous levels with four pixels per thread (k_svgf_atrous4); ATEN_AMD_SVGF_ATROUS4=0: one pixel per thread
     uint32_t env_trace_blocks = 0;
     int env_shade_waves = 0;    // ATEN_AMD_SHADE_WAVES=4|5 forces the k_shade_wn flavour (default: 5 when frames are in flight, else 4)
@@ -593,6 +594,9 @@ public:
         if (const char* e = std::getenv("ATEN_AMD_SHADE_ITEMS")) { const int v = std::atoi(e); if (v >= 1 && v <= kChunkItems) env_shade_items = v; }
         if (const char* e = std::getenv("ATEN_AMD_LDS_NODES")) env_lds_nodes = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));
+        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN_DIRS")) env_anyhit_twin_dirs = std::atoi(e) == 1 ? 1 : 8;
+        if (const char* e = std::getenv("ATEN_AMD_NODE_LAYOUT")) opt_node_layout = std::atoi(e) != 0;     // 0: bottom-level records in walk order
+        if (const char* e = std::getenv("ATEN_AMD_PLANAR_LIGHTS")) opt_planar_lights = std::atoi(e) != 0; // 0: shadow rays towards area lights always walk to their closest hit
         if (const char* e = std::getenv("ATEN_AMD_PROBE_STREAMS")) env_probe_streams = std::atoi(e) != 0;
         if (const char* e = std::getenv("ATEN_AMD_TRACE")) { env_flavour = e[0] == 'r' ? 1 : 0; }   // 'r'efill / 's'imple
         if (const char* e = std::getenv("ATEN_AMD_SIMPLE_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) simple_block = (uint32_t)v; }
@@ -646,12 +650,10 @@ public:
         drop_alt_set(); cur_set = 0; scene_in_place = false; frame_since_update = true;
         HostSceneImage img;
         std::string err;
-        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN")) env_anyhit_twin = std::max(0, std::min(2, std::atoi(e)));   // (read per upload: tests switch it)
-        if (const char* e = std::getenv("ATEN_AMD_ANYHIT_TWIN_DIRS")) env_anyhit_twin_dirs = std::atoi(e) == 1 ? 1 : 8;
-        int layout_top = kLayoutTopLevels;     // ATEN_AMD_NODE_LAYOUT=0: bottom-level records in walk order (tests: films do not depend on it)
-        if (const char* e = std::getenv("ATEN_AMD_NODE_LAYOUT")) layout_top = std::atoi(e) == 0 ? 0 : kLayoutTopLevels;
-        bool planar_lights = true;             // ATEN_AMD_PLANAR_LIGHTS=0: shadow rays towards area lights always walk to their closest hit (tests)
-        if (const char* e = std::getenv("ATEN_AMD_PLANAR_LIGHTS")) planar_lights = std::atoi(e) != 0;
+        // (the upload options are context state: the environment was read ONCE, when the context was created; atn_set_upload_options
+        // changes them -- every shard of a node, every re-upload gets the same layout whatever happened to the process environment since)
+        const int layout_top = opt_node_layout ? kLayoutTopLevels : 0;
+        const bool planar_lights = opt_planar_lights;
         if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs, layout_top, planar_lights)) return fail(ATN_ERR_UNSUPPORTED, err);
         n_planar_lights = 0;
         for (const atn_light_param& l : img.lights) n_planar_lights += l._pad != 0 ? 1u : 0u;
@@ -821,7 +823,7 @@ public:
         if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; host_matrices.assign(mtxs, mtxs + n_mtxs); }
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
-        if (n_mtxs) scene.planar_lights = 0;    // (a light's instance may have a new matrix)
+        scene.planar_lights = 0;    // a light's instance may have a new matrix, or point at another object / matrix (an objs-only update too)
         tlas_refs.swap(new_refs);
         scene.root_link = root;
         fill_root_direct(scene, rec.data(), top_base, n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr), n_mtxs ? n_mtxs : n_host_matrices);
@@ -1958,6 +1960,16 @@ int atn_upload_scene(atn_ctx* ctx, const atn_scene_desc* scene)
     return guarded(ctx, [&] { return ctx->r.UpdateSceneData(scene); });
 }
 
+int atn_set_upload_options(atn_ctx* ctx, int32_t anyhit_twin, int32_t anyhit_twin_dirs, int32_t node_layout, int32_t planar_lights)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    if (anyhit_twin > 2 || (anyhit_twin_dirs >= 0 && anyhit_twin_dirs != 1 && anyhit_twin_dirs != 8)) return ctx->r.fail(ATN_ERR_INVALID_ARG, "upload option out of range");
+    if (anyhit_twin >= 0) ctx->r.env_anyhit_twin = anyhit_twin;
+    if (anyhit_twin_dirs >= 0) ctx->r.env_anyhit_twin_dirs = anyhit_twin_dirs;
+    if (node_layout >= 0) ctx->r.opt_node_layout = node_layout != 0;
+    if (planar_lights >= 0) ctx->r.opt_planar_lights = planar_lights != 0;
+    return ATN_OK;
+}
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera) { CTX_OR_FAIL(ctx); return guarded(ctx, [&] { return ctx->r.updateCamera(camera); }); }
 
 int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_objects, const atn_mat4* matrices, uint32_t n_matrices,
@@ -2603,6 +2615,7 @@ uint32_t atn_sizeof_destination(void) { return (uint32_t)sizeof(atn_destination)
 #define ATN_BUILD_ID "unknown"
 #endif
 const char* atn_build_id(void) { return ATN_BUILD_ID; }
-uint32_t atn_abi_version(void) { return 3; }     // 3: atn_material_table takes the starting dimension, atn_compact3 dropped (r04); 2: atn_scene_desc grew the NPR fields, atn_toon_param spelled out (r02)
+uint32_t atn_abi_version(void) { return 4; }     // 4: atn_bank_streams' *concurrent is a bit mask (bit 0 = banks overlap, bit 1 = the side stream does) since r05; r06 adds atn_set_regeneration / atn_render_burst / atn_regen_stage_counts / atn_set_upload_options / atn_mgpu_render_burst
+//     // 3: atn_material_table takes the starting dimension, atn_compact3 dropped (r04); 2: atn_scene_desc grew the NPR fields, atn_toon_param spelled out (r02)
 
 } // extern "C"

@@ -840,7 +840,15 @@ int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
                     atn_bvh_node** out_nodes, uint32_t* out_count,
                     float out_bbox_min[3], float out_bbox_max[3])
 {
-    try { return build_blas(vtx_pos, tris, tri_ids, n_tris, nullptr, out_nodes, out_count, out_bbox_min, out_bbox_max, nullptr); }
+    // The entry without options builds with OBJECT splits only: exactly one leaf per triangle, n - 1 inner nodes -- the shape
+    // atn_lbvh_rebuild_list requires of a list it rebuilds in place (a spatial split duplicates references: more leaves than triangles).
+    // Spatial splits are what atns_build_blas_opt's defaults add.
+    try {
+        atns_bvh_options o;
+        atns_bvh_default_options(&o);
+        o.spatial_splits = 0;
+        return build_blas(vtx_pos, tris, tri_ids, n_tris, &o, out_nodes, out_count, out_bbox_min, out_bbox_max, nullptr);
+    }
     catch (const std::bad_alloc&) { return -3; }
     catch (...) { return -5; }
 }

@@ -369,15 +369,22 @@ inline bool planar_area_light(const atn_scene_desc* s, const atn_light_param& l,
 // Measured on the headline scene: shadow-ray node visits 261.6 M per frame as given, 198.8 M with one twin, 134.6 M with eight;
 // 3.555 / 3.42 / 3.27 ms per frame.
 constexpr double kTwinPays = 0.95;
+// What the twins may cost in node memory: eight twins are nine times a list's records.  A list whose eight twins do not fit what is
+// left of the scene's budget gets the one direction-free twin (twice the records), or none; and a scene small enough to be walked
+// from an LDS copy (kLdsNodesMaxBytes of records) gets no twin that would push it out of that path.  (The 31-bit offset limit of the
+// links is a separate, later check.)
+constexpr uint64_t kTwinBudgetBytes = 512ull << 20;
 inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::string& err, int anyhit_twins = 0, int twin_dirs = 8,
-                             int node_layout_top_levels = kLayoutTopLevels, bool planar_lights = true)
+                             int node_layout_top_levels = kLayoutTopLevels, bool planar_lights = true, uint64_t twin_budget_bytes = kTwinBudgetBytes)
 {
     if (!s || s->n_bvh_lists == 0 || !s->bvh_lists) { err = "scene has no BVH lists"; return false; }
     const uint32_t nl = s->n_bvh_lists;
     std::string range_err;
     if (!validate_ranges(s->objects, s->n_objects, s->n_matrices, s, range_err)) { err = range_err; return false; }
 
-    const uint32_t n_dir = twin_dirs == 8 ? 8u : 1u;
+    const uint32_t n_dir_wanted = twin_dirs == 8 ? 8u : 1u;
+    uint64_t twin_bytes = 0, plain_bytes = 0;       // (48 bytes per record: an upper bound, inner records take 32)
+    for (uint32_t k = 0; k < nl; k++) plain_bytes += (uint64_t)s->bvh_lists[k].count * 48u;
     std::vector<std::vector<ListLayout>> twin_lay(nl);
     std::vector<ListLayout> lay(nl);
     std::vector<std::vector<std::vector<atn_bvh_node>>> twin(nl);    // the any-hit twin(s) of list k as threaded lists of their own (empty: none)
@@ -389,6 +396,15 @@ inline bool build_host_image(HostSceneImage& img, const atn_scene_desc* s, std::
         AnyhitTwin tw;
         if (!make_anyhit_twin(s->bvh_lists[k].nodes, s->bvh_lists[k].count, tw)) continue;
         if (anyhit_twins != 2 && !(tw.cost_twin <= kTwinPays * tw.cost_as_given)) continue;
+        const uint64_t one = (uint64_t)s->bvh_lists[k].count * 48u;
+        uint32_t n_dir = n_dir_wanted;
+        auto fits = [&](uint32_t nd) {
+            if (twin_bytes + one * nd > twin_budget_bytes) return false;
+            return !(plain_bytes <= kLdsNodesMaxBytes && plain_bytes + twin_bytes + one * nd > kLdsNodesMaxBytes);
+        };
+        if (!fits(n_dir)) n_dir = 1u;
+        if (!fits(n_dir)) continue;
+        twin_bytes += one * n_dir;
         twin[k].resize(n_dir); twin_lay[k].resize(n_dir);
         bool ok = true;
         for (uint32_t g = 0; g < n_dir && ok; g++) {

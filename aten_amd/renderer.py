@@ -48,12 +48,13 @@ class PathTracing:
     def UpdateSceneData(self, scene):
         self._check(self._l.atn_upload_scene(self._ctx, C.cast(scene.ref(), C.c_void_p)))
 
-    def updateBVH(self, scene):
+    def updateBVH(self, scene, with_matrices=True):
         """idaten::Renderer::updateBVH (renderer.cpp:133-153): objects, matrices and the top layer of `scene`
-        (a FlatScene whose bottom-level lists are the ones already uploaded)."""
+        (a FlatScene whose bottom-level lists are the ones already uploaded).  with_matrices=False: the reference's
+        `mtxs.empty()` form -- new objects and top layer, the uploaded matrices stay."""
         a = scene.arrays
         objs = np.ascontiguousarray(a["objects"])
-        mtx = np.ascontiguousarray(a["matrices"])
+        mtx = np.ascontiguousarray(a["matrices"]) if with_matrices else np.zeros((0, 4, 4), np.float32)
         top = np.ascontiguousarray(a["bvh_lists"][0])
         self._check(self._l.atn_update_tlas(self._ctx, objs.ctypes.data, len(objs), mtx.ctypes.data if len(mtx) else None,
                                             len(mtx), top.ctypes.data, len(top)))
@@ -122,6 +123,11 @@ class PathTracing:
         self._check(self._l.atn_render(self._ctx, C.byref(d), out.ctypes.data if download else None))
         self.width, self.height = width, height
         return out
+
+    def set_upload_options(self, anyhit_twin=None, anyhit_twin_dirs=None, node_layout=None, planar_lights=None):
+        """How the next UpdateSceneData lays the scene out (atn_set_upload_options); None leaves an option as it is."""
+        v = lambda x: -1 if x is None else int(x)
+        self._check(self._l.atn_set_upload_options(self._ctx, v(anyhit_twin), v(anyhit_twin_dirs), v(node_layout), v(planar_lights)))
 
     def set_regeneration(self, on):
         """Path regeneration (include/aten_amd.h): the samples of a frame / the frames of a burst share one pool of path slots."""

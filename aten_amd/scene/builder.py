@@ -372,9 +372,11 @@ class SceneBuilder:
         nm = self.load_image(os.path.join(base, m.bump_texname)) if m.bump_texname else -1
         return self.add_material(m.name, L.MTRL_DIFFUSE, m.diffuse, albedo_map=alb, normal_map=nm)
 
-    def add_mesh(self, name, positions, indices, mtrl, normals=None, uvs=None, need_normal=True, into=None):
+    def add_mesh(self, name, positions, indices, mtrl, normals=None, uvs=None, need_normal=True, into=None, deformable=False):
         """Programmatic PolygonObject (one TriangleGroupMesh).  positions [N,3], indices [M,3].  `into` appends
-        the mesh to an existing polygon object (several materials in one object, like a loaded OBJ)."""
+        the mesh to an existing polygon object (several materials in one object, like a loaded OBJ).
+        deformable: the object's tree will be rebuilt in place on the device (atn_lbvh_rebuild_list), which needs one leaf per
+        triangle: it is built with object splits only, whatever `bvh_options` say about spatial splits."""
         positions = np.asarray(positions, F32)
         indices = np.asarray(indices, np.int64)
         if into is None:
@@ -398,6 +400,8 @@ class SceneBuilder:
         mesh["tris"] = list(range(first, first + len(indices)))
         self.objects[oid]["meshes"].append(mesh)
         self.blas[oid] = None
+        if deformable:
+            self.objects[oid]["deformable"] = True
         return oid
 
     def set_mesh_vertices(self, obj_id, positions, indices, normals=None):
@@ -434,8 +438,10 @@ class SceneBuilder:
         self.objects.append(dict(type=L.OBJ_INSTANCE, object_id=obj_id, mtx_id=mid, light_id=-1))
         return len(self.objects) - 1
 
-    def _bvh_options(self):
+    def _bvh_options(self, deformable=False):
         kw = self.bvh_options if self.bvh_options is not None else DEFAULT_BVH_OPTIONS
+        if deformable:
+            kw = dict(kw or {}, spatial_splits=0)
         return C.byref(default_bvh_options(**kw)) if kw else None
 
     def import_sbvh(self, obj_id, path, optimize=False):
@@ -583,8 +589,8 @@ class SceneBuilder:
                 bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
                 ids = np.asarray(tri_ids, np.uint32)
                 st = BvhStats()
-                rc = lib.atns_build_blas_opt(L.ptr(pos), L.ptr(tris), L.ptr(ids), num, self._bvh_options(), C.byref(out), C.byref(cnt),
-                                             bmin, bmax, C.byref(st))
+                rc = lib.atns_build_blas_opt(L.ptr(pos), L.ptr(tris), L.ptr(ids), num, self._bvh_options(bool(o.get("deformable"))),
+                                             C.byref(out), C.byref(cnt), bmin, bmax, C.byref(st))
                 if rc != 0:
                     raise RuntimeError("atns_build_blas_opt failed: %d" % rc)
                 bvh_stats[oid] = dict(nodes=st.n_nodes, leaves=st.n_leaves, spatial_splits=st.n_spatial_splits, reinsertions=st.n_reinsertions, sah=st.sah_cost)

@@ -373,7 +373,7 @@ def deformable_room(t=0.0, asset_dir=None, **blob):
         b.create_instance(o)
     skin = b.add_material("skin", L.MTRL_GGX, (0.8, 0.45, 0.3), roughness=0.35, ior=1.4)
     pos, nml, idx = blob_mesh(t, **blob)
-    oid = b.add_mesh("blob", pos, idx, skin, normals=nml)
+    oid = b.add_mesh("blob", pos, idx, skin, normals=nml, deformable=True)
     b.create_instance(oid)
     b.set_background((0.0, 0.0, 0.0))
     cam = dict(pos=(0.0, 1.0, 3.0), at=(0.0, 1.0, 0.0), vfov=45.0)

@@ -67,6 +67,15 @@ int atn_update_tlas(atn_ctx* ctx, const atn_object_param* objects, uint32_t n_ob
                     const atn_mat4* matrices, uint32_t n_matrices,
                     const atn_bvh_node* top_nodes, uint32_t n_top_nodes);
 
+/* How atn_upload_scene lays the scene out.  Context state, initialised ONCE at atn_create from the environment variables of the same
+ * names (README.md) and changed only here -- not re-read from the process environment at every upload.  -1 leaves an option as it is.
+ *   anyhit_twin       0 / 1 / 2: no any-hit twins / where the surface-area model expects them to pay (default) / wherever possible
+ *   anyhit_twin_dirs  8 / 1: one twin per octant of the ray direction (default) / the one direction-free twin
+ *   node_layout       1 / 0: first levels of a list level by level (default) / walk order
+ *   planar_lights     1 / 0: shadow rays towards planar, rigidly placed area lights stop at the first nearer hit (default) / never
+ * Films do not depend on any of them (tests/test_gpu_anyhit_twin.py). */
+int atn_set_upload_options(atn_ctx* ctx, int32_t anyhit_twin, int32_t anyhit_twin_dirs, int32_t node_layout, int32_t planar_lights);
+
 /* ≙ idaten::Renderer::updateCamera (renderer.cpp:202-205). */
 int atn_update_camera(atn_ctx* ctx, const atn_camera_param* camera);
 

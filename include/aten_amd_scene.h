@@ -27,13 +27,17 @@ uint32_t atns_abi_version(void);
 /* Bottom-level tree over the triangles tri_ids[0..n_tris) of `tris` (global ids are written
  * into the leaves, like sbvh::convert's `ref.triid + m_offsetTriIdx`, sbvh.cpp:897).
  * Nodes come out in depth-first pre-order: an inner node's hit link is always index+1.
- * *out_nodes is malloc'ed; release with atns_free.  Returns 0 or a negative error code. */
+ * *out_nodes is malloc'ed; release with atns_free.  Returns 0 or a negative error code.
+ * This entry builds with OBJECT splits only -- exactly one leaf per triangle and n_tris - 1 inner nodes -- which is the shape
+ * atn_lbvh_rebuild_list requires of a list it rebuilds in place (deforming meshes).  Spatial splits (duplicated references, better
+ * trees for static meshes) come with atns_build_blas_opt, whose default options switch them on; a tree with duplicated references
+ * cannot be rebuilt in place (ATN_ERR_UNSUPPORTED): pass spatial_splits = 0 for meshes that deform. */
 int atns_build_blas(const atn_vec4* vtx_pos, const atn_triangle_param* tris,
                     const uint32_t* tri_ids, uint32_t n_tris,
                     atn_bvh_node** out_nodes, uint32_t* out_count,
                     float out_bbox_min[3], float out_bbox_max[3]);
 
-/* The knobs of the bottom-level builder.  atns_bvh_default_options fills in what atns_build_blas uses. */
+/* The knobs of the bottom-level builder.  atns_bvh_default_options fills in what atns_build_blas_opt(options = NULL) uses. */
 enum {
     ATNS_ORDER_AS_SPLIT = 0,      /* lower side of the split plane first (what sbvh::onBuild does, sbvh.cpp:386-404) */
     ATNS_ORDER_AREA = 1,          /* child with the larger surface area first */

@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """torch (device tensors for the tile / gather tests) bundles its own HIP runtime: when it initialises AFTER libaten_amd.so has
+    brought up the system one it can report "No HIP GPUs are available" -- so on a GPU box it comes up before any test creates a
+    context, whatever subset of the suite runs in whatever order (bench.py does the same)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import orc as o

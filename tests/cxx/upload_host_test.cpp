@@ -134,6 +134,13 @@ int main()
         }
         HostSceneImage none; std::string err;
         if (!build_host_image(none, &s.d, err, 0, 8, kLayoutTopLevels, true) || none.list_twin_delta[1] != 0 || none.params.root_twin != 0) return fail("twins off");
+        // the twins' memory budget (kTwinBudgetBytes): eight twins of this list are 8 x its records -- a budget of 3 x leaves room for the
+        // one direction-free twin only, a budget below 1 x for none
+        const uint64_t one = (uint64_t)s.blas.size() * 48u;
+        HostSceneImage b1, b0;
+        if (!build_host_image(b1, &s.d, err, 2, 8, kLayoutTopLevels, true, 3 * one) || b1.list_twin_delta[1] == 0 || (b1.list_twin_delta[1] & 1) != 0) return fail("budget: one twin");
+        if (b1.list_root[0] != b1.list_root[1] + 2u * b1.list_bytes[1]) return fail("budget: one twin's records");
+        if (!build_host_image(b0, &s.d, err, 2, 8, kLayoutTopLevels, true, one / 2) || b0.list_twin_delta[1] != 0) return fail("budget: no twin");
         // the model gives this bumpy sheet no twin by itself (nothing occludes anything)
         HostSceneImage adaptive;
         if (!build_host_image(adaptive, &s.d, err, 1, 8, kLayoutTopLevels, true)) return fail("adaptive: " + err);

@@ -82,6 +82,51 @@ def test_split_tree_structure(sponza_mesh):
     assert (capped["f0"] >= 0).sum() <= 1.1 * n + 64
 
 
+def test_trees_of_deforming_meshes_have_one_leaf_per_triangle(sponza_mesh):
+    """atn_lbvh_rebuild_list rebuilds a list in place only when it has one leaf per triangle and n - 1 inner nodes.  The entry
+    without options (atns_build_blas) builds exactly that -- on a mesh where the default options DO duplicate references -- and
+    so does SceneBuilder for a mesh added with deformable=True, whatever the builder's bvh_options say."""
+    from aten_amd import layout as L
+    from aten_amd._hostlib import hostlib
+    from aten_amd.scene.builder import SceneBuilder
+    _, _, pos, tris, ids = sponza_mesh
+    n = len(ids)
+    split, st, _, _ = _build(pos, tris, ids)
+    assert (split["f0"] >= 0).sum() > n and st.n_spatial_splits > 0          # the premise: this mesh gets spatial splits
+    lib = hostlib()
+    out = C.c_void_p(); cnt = C.c_uint32()
+    bmin = (C.c_float * 3)(); bmax = (C.c_float * 3)()
+    assert lib.atns_build_blas(L.ptr(pos), L.ptr(tris), L.ptr(ids), n, C.byref(out), C.byref(cnt), bmin, bmax) == 0
+    nodes = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(cnt.value * 48,)).view(L.BVH_NODE).copy()
+    lib.atns_free(out)
+    assert len(nodes) == 2 * n - 1 and (nodes["f0"] >= 0).sum() == n
+    assert set(nodes["f1"][nodes["f0"] >= 0].astype(np.int64).tolist()) == set(range(n))
+
+    # a deforming mesh whose rest pose invites spatial splits: long thin slats crossing a pile of small triangles
+    rng = np.random.default_rng(3)
+    P, I = [], []
+    for k in range(60):
+        y = 0.02 * k
+        P += [(-2.0, y, -0.01), (2.0, y, 0.01), (2.0, y + 0.005, 0.0)]
+        I.append((3 * k, 3 * k + 1, 3 * k + 2))
+    for k in range(400):
+        c = rng.uniform(-1.8, 1.8, 3) * (1, 0.3, 0.02)
+        P += [tuple(c), tuple(c + (0.03, 0, 0)), tuple(c + (0, 0.03, 0))]
+        I.append((180 + 3 * k, 180 + 3 * k + 1, 180 + 3 * k + 2))
+    for deformable in (False, True):
+        b = SceneBuilder()
+        m = b.add_material("m", L.MTRL_DIFFUSE, (0.7, 0.7, 0.7))
+        oid = b.add_mesh("slats", np.array(P, np.float32), np.array(I), m, deformable=deformable)
+        b.create_instance(oid)
+        fs = b.build()
+        lst = fs.arrays["bvh_lists"][1]
+        leaves = int((lst["f0"] >= 0).sum())
+        if deformable:
+            assert leaves == len(I) and len(lst) == 2 * len(I) - 1
+        else:
+            assert leaves > len(I)          # (the same mesh as a static one is split: the flag is what keeps it rebuildable)
+
+
 def test_split_tree_is_watertight(orc, sponza_mesh):
     """Clipped references must not lose a sliver of their triangle: 200 k incoherent rays (origins inside the building,
     random directions) find the same closest distance in the reference-built tree, in the split tree, and in the tree built

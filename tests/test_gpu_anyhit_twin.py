@@ -225,3 +225,95 @@ def test_shadow_rays_towards_planar_area_lights_stop_early(orc):
     a, _, _, _ = run(still, cam, 80, 80, 0, move=moved)
     b, _, n_before, n_after = run(still, cam, 80, 80, 1, move=moved)
     assert n_before == 1 and n_after == 0 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+def _hostile_lamp_scene(offset=(0.0, 0.0, 0.0)):
+    """A lamp quad on a ROTATED rigid instance (25 degrees about z), three thin blocker strips parallel to it a hair in front of it --
+    gaps of 4.5e-3 / 2.4e-3 / 3e-4, i.e. hits at ~0.9985 / 0.9992 / 0.9999 of the light distance for a point 3 units away: below, inside
+    and at the far end of the rule's 0.999 band --, a floor, and a wall that crosses the lamp's plane (points near the crossing see the
+    lamp at cosines around 0.005 - 0.02).  `offset` translates every vertex and the camera (1e4: the origin-offset bound of the rule is
+    then the binding term and the thinnest gaps are below the coordinates' resolution)."""
+    from aten_amd import layout as L
+    from aten_amd.scene.builder import SceneBuilder
+    off = np.asarray(offset, np.float32)
+    b = SceneBuilder()
+    white = b.add_material("white", L.MTRL_DIFFUSE, (0.7, 0.7, 0.7))
+    red = b.add_material("red", L.MTRL_DIFFUSE, (0.7, 0.2, 0.2))
+    emit = b.add_material("lamp", L.MTRL_EMISSIVE, (1.0, 1.0, 1.0))
+
+    def quad(name, p, mtrl, mtx=None, flip=False):
+        idx = [[0, 2, 1], [0, 3, 2]] if flip else [[0, 1, 2], [0, 2, 3]]
+        o = b.add_mesh(name, np.asarray(p, np.float32), idx, mtrl)
+        return b.create_instance(o, mtx)
+    a = np.deg2rad(25.0)
+    R = np.array([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    T = np.eye(4); T[:3, 3] = np.array([0.0, 3.0, 0.0]) + off.astype(np.float64)
+    M = (T @ R).astype(np.float32)
+    # (local frame: the lamp faces -y; the strips lie at local y = -gap, side by side along x)
+    lamp = quad("lamp", [[-1.0, 0, -0.6], [1.0, 0, -0.6], [1.0, 0, 0.6], [-1.0, 0, 0.6]], emit, M)
+    b.add_area_light(lamp, (1.0, 1.0, 1.0), 40.0)
+    for k, gap in enumerate((4.5e-3, 2.4e-3, 3e-4)):
+        x0 = -0.9 + 0.6 * k
+        quad("strip%d" % k, [[x0, -gap, -0.5], [x0 + 0.4, -gap, -0.5], [x0 + 0.4, -gap, 0.5], [x0, -gap, 0.5]], red, M)
+    fl = np.array([[-4, 0, -3], [4, 0, -3], [4, 0, 3], [-4, 0, 3]], np.float32) + off
+    quad("floor", fl, white, None, flip=True)
+    wl = np.array([[-1.6, 0, -3], [-1.6, 0, 3], [-1.6, 5, 3], [-1.6, 5, -3]], np.float32) + off
+    quad("wall", wl, white, None)
+    quad("wall_back", wl[[0, 3, 2, 1]], white, None)
+    b.set_background((0.0, 0.0, 0.0))
+    cam = dict(pos=tuple((np.array([1.0, 1.6, 6.0]) + off).tolist()), at=tuple((np.array([-0.3, 1.8, 0.0]) + off).tolist()), vfov=45.0)
+    return b.build(), cam
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (1e4, 1e4, 1e4)])
+def test_planar_light_rule_on_hostile_geometry(orc, offset):
+    """The three constants of the early stop towards planar lights (kernels.hpp ShadowJob::fetch_slot: 0.999 of the distance, cosine >=
+    0.01, the 300-ulp origin bound) against geometry chosen to sit on them: films byte-equal with the rule off, and inside the
+    tolerance of the oracle -- which walks every shadow ray to its closest hit."""
+    from aten_amd.renderer import PathTracing
+    fs, cam = _hostile_lamp_scene(offset)
+    w, h = 160, 120
+    c = make_camera(orc, cam, w, h)
+    films = {}
+    for on in (0, 1):
+        r = PathTracing(0)
+        try:
+            r.set_upload_options(planar_lights=on)
+            r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+            assert r.planar_area_lights() == on          # the rotated lamp IS recognised (rigid matrix, planar quad)
+            films[on] = [r.render(w, h, 3, 3, frame=f, count_stats=True).copy() for f in (0, 1, 5)]
+            films[(on, "stats")] = r.stats()
+        finally:
+            r.close()
+    for a, b in zip(films[0], films[1]):
+        assert a.tobytes() == b.tobytes()
+    for k in ("closest_rays", "shadow_rays", "hits"):
+        assert films[(0, "stats")][k] == films[(1, "stats")][k]
+    seeds = orc.init_sampler(w, h, 0)
+    want = orc.render(fs, c, seeds, w, h, 3, 3, frame=0)
+    got = films[1][0]
+    d = np.abs(got[..., :3] - want[..., :3])
+    inside = np.all(d <= 1e-3 * np.maximum(1.0, np.abs(want[..., :3])), axis=-1)
+    assert inside.mean() >= 0.99, inside.mean()
+    lit = want[..., :3].sum(-1) > 0
+    assert lit.mean() > 0.2             # (the lamp does light the scene: the comparison is not about black pixels)
+
+
+def test_an_objects_only_update_drops_the_planar_light_certificate(orc, cornell):
+    """atn_update_tlas with new objects but NO matrices (the reference's `mtxs.empty()` form) can still re-point the light's instance
+    at another matrix or object: the planar / rigid flags found at upload are dropped, the film is what a fresh upload renders."""
+    from aten_amd.renderer import PathTracing
+    fs, cam = cornell
+    w, h = 96, 96
+    c = make_camera(orc, cam, w, h)
+    r = PathTracing(0)
+    try:
+        r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
+        assert r.planar_area_lights() == 1
+        want = r.render(w, h, 5, 3, frame=0).copy()
+        r.updateBVH(fs, with_matrices=False)
+        assert r.planar_area_lights() == 0
+        r.reset()
+        assert r.render(w, h, 5, 3, frame=0).tobytes() == want.tobytes()
+    finally:
+        r.close()

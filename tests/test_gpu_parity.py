@@ -328,11 +328,19 @@ def test_sponza_disney_frame_vs_oracle(gpu, orc, sponza_disney):
     assert mean_err <= 5e-3, mean_err
 
 
-def test_counters_match_oracle(gpu, orc, cornell, monkeypatch):
+@pytest.fixture
+def no_planar_lights(gpu):
+    """Shadow rays walk to their closest hit like the reference's (the early stop towards planar area lights off) for the uploads of
+    one test: an upload option of the context (atn_set_upload_options), put back afterwards."""
+    gpu.set_upload_options(planar_lights=0)
+    yield
+    gpu.set_upload_options(planar_lights=1)
+
+
+def test_counters_match_oracle(gpu, orc, cornell, no_planar_lights):
     """Ray / hit counters of a whole frame: integer work, so equal unless a path diverged (allow 0.1 %
     slack for ulp-level transcendental flips).  (Node visits: with shadow rays walking as the reference's do -- the early stop towards
     planar area lights, r05, shortens them and is tested in test_gpu_anyhit_twin.py.)"""
-    monkeypatch.setenv("ATEN_AMD_PLANAR_LIGHTS", "0")       # read at upload
     fs, c, seeds = _setup(gpu, orc, cornell, 128, 128)
     gpu.render(128, 128, 5, 3, frame=0, count_stats=True)
     s = gpu.stats()
@@ -343,12 +351,11 @@ def test_counters_match_oracle(gpu, orc, cornell, monkeypatch):
     assert abs((s["closest_nodes"] + s["shadow_nodes"]) - int(cnt[3])) <= 2e-3 * int(cnt[3])
 
 
-def test_path_cost_map_matches_oracle(gpu, orc, cornell, monkeypatch):
+def test_path_cost_map_matches_oracle(gpu, orc, cornell, no_planar_lights):
     """atn_download_path_cost -- the per-pixel cost map (BVH node visits, triangle tests of all the pixel's walks) that
     stands in for the heat map of the reference's per-path GPU timer (path_time_profiler.h:15-60): integer work, equal
     to the oracle's per-pixel counters wherever the path did not diverge (Cornell: its shadow rays aim at an area
     light, so they walk to the closest hit on both sides -- with the early stop towards planar lights off)."""
-    monkeypatch.setenv("ATEN_AMD_PLANAR_LIGHTS", "0")       # read at upload
     fs, c, seeds = _setup(gpu, orc, cornell, 96, 96)
     gpu.reset()
     film = gpu.render(96, 96, 5, 3, frame=0, count_stats=True)

@@ -31,7 +31,7 @@ SYMBOLS = [
     "atn_mgpu_set_random", "atn_mgpu_render", "atn_mgpu_reset", "atn_mgpu_synchronize", "atn_mgpu_film_device",
     "atn_mgpu_download_film",
     "atn_set_regeneration", "atn_get_regeneration", "atn_render_burst", "atn_regen_stage_counts",
-    "atn_mgpu_set_regeneration", "atn_mgpu_render_burst", "atn_set_upload_options",
+    "atn_mgpu_set_regeneration", "atn_mgpu_render_burst", "atn_set_upload_options", "atn_libm_probe",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
         l.atn_cmj_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, vp]
         l.atn_cmj_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_int32, vp]
         l.atn_ray_offset.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        l.atn_libm_probe.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp]
         l.atn_material_table.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.atn_material_eval.argtypes = [vp, C.c_int32, C.c_uint32, vp, vp, vp, vp, vp]
         l.atn_compact.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]

@@ -2507,6 +2507,23 @@ int atn_ray_offset(atn_ctx* ctx, uint32_t n, const float* origins, const float* 
     return ATN_OK;
 }
 
+int atn_libm_probe(atn_ctx* ctx, int32_t kind, uint32_t n, const float* a, const float* b, float* out_host)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    PathTracing& r = ctx->r;
+    if (n == 0 || !a || !b || !out_host || kind < 0 || kind > 10) return r.fail(ATN_ERR_INVALID_ARG, "bad libm probe");
+    C_HIP(r, hipSetDevice(r.device));
+    atn::DevBuf<float> da, db, out;
+    C_HIP(r, da.resize(n)); C_HIP(r, db.resize(n)); C_HIP(r, out.resize(n));
+    C_HIP(r, hipMemcpyAsync(da.p, a, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    C_HIP(r, hipMemcpyAsync(db.p, b, 4 * (size_t)n, hipMemcpyHostToDevice, r.stream));
+    hipLaunchKernelGGL(atn::k_libm_probe, dim3((n + 255) / 256), dim3(256), 0, r.stream, kind, n, (const float*)da.p, (const float*)db.p, out.p);
+    C_HIP(r, hipGetLastError());
+    C_HIP(r, hipMemcpyAsync(out_host, out.p, 4 * (size_t)n, hipMemcpyDeviceToHost, r.stream));
+    C_HIP(r, hipStreamSynchronize(r.stream));
+    return ATN_OK;
+}
+
 int atn_material_table(atn_ctx* ctx, int32_t mtrl_id, uint32_t n, const float* nrm, const float* wi,
                        const uint32_t* index, const uint32_t* dimension, const uint32_t* scramble, const float* uv,
                        float* out_sample, float* out_eval)

@@ -1282,6 +1282,31 @@ __global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim
     }
 }
 
+// the math-library functions the float path calls, as this build answers them (atn_libm_probe; kinds as in oracle/aten_oracle.cpp,
+// orc_libm_probe)
+__global__ void __launch_bounds__(256) k_libm_probe(int32_t kind, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    float r = 0.0F;
+    switch (kind) {
+    case 0: r = sinf(x); break;
+    case 1: r = cosf(x); break;
+    case 2: r = atanf(x); break;
+    case 3: r = acosf(x); break;
+    case 4: r = atan2f(x, y); break;
+    case 5: r = logf(x); break;
+    case 6: r = expf(x); break;
+    case 7: r = powf(x, y); break;
+    case 8: r = sqrtf(x); break;
+    case 9: r = x / y; break;
+    case 10: r = 1.0F / sqrtf(x); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
 __global__ void __launch_bounds__(256) k_ray_offset(uint32_t n, const float* __restrict__ o, const float* __restrict__ nrm, float* __restrict__ out)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -322,6 +322,16 @@ class PathTracing:
                                           scramble.ctypes.data, draws, out.ctypes.data))
         return out
 
+    LIBM_KINDS = ["sinf", "cosf", "atanf", "acosf", "atan2f", "logf", "expf", "powf", "sqrtf", "div", "inversesqrt"]
+
+    def libm_probe(self, kind, a, b=None):
+        """The device build's math library on arrays (atn_libm_probe; kind: a name from LIBM_KINDS)."""
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ones_like(a) if b is None else np.ascontiguousarray(b, np.float32)
+        out = np.zeros_like(a)
+        self._check(self._l.atn_libm_probe(self._ctx, self.LIBM_KINDS.index(kind), len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out
+
     def ray_offset(self, origins, normals):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3); n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
         out = np.zeros_like(o)

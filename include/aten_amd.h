@@ -349,6 +349,11 @@ int atn_cmj_batch(atn_ctx* ctx, uint32_t n, const uint32_t* index, const uint32_
                   int32_t draws, float* out_host);
 /* ray::Offset (src/libaten/math/ray.h:26-74: "A Fast and Robust Method for Avoiding Self-Intersection", Ray Tracing Gems ch. 6)
  * as the kernels compute it for every next ray and shadow ray: n origins (xyz) and normals (xyz) -> n offset origins. */
+/* The math-library functions the float path calls, evaluated by THIS build on the device (ocml sinf / cosf / atanf / acosf / atan2f /
+ * logf / expf / powf, and the correctly rounded sqrtf, a / b, 1 / sqrtf): kind 0..10 in that order, b is the second argument where
+ * there is one.  What the float tolerance of the parity contract is made of: tools/ulp_study.py holds these against the CPU build's
+ * libm. */
+int atn_libm_probe(atn_ctx* ctx, int32_t kind, uint32_t n, const float* a, const float* b, float* out_host);
 int atn_ray_offset(atn_ctx* ctx, uint32_t n, const float* origins, const float* normals, float* out_host);
 /* material::sampleMaterial / samplePDF / sampleBSDF tables (src/libaten/material/material_impl.h:24-206).
  * Case i samples with CMJ::init(index[i], dimension[i], scramble[i]) (dimension == NULL: 0 -- note that CMJ's pattern seed is

@@ -69,6 +69,29 @@ void orc_math_kat(int32_t kind, int32_t n, const float* a, const float* b, const
     }
 }
 
+// The math-library functions the float path calls, as THIS build's libm answers them (the oracle's side of the ulp study,
+// tools/ulp_study.py: which function's last bit the GPU's ocml disagrees on).  kind: 0 sinf 1 cosf 2 atanf 3 acosf 4 atan2f(a, b)
+// 5 logf 6 expf 7 powf(a, b) 8 sqrtf 9 a / b 10 1 / sqrtf(a) as orc_math.h's inversesqrt writes it
+void orc_libm_probe(int32_t kind, int32_t n, const float* a, const float* b, float* out)
+{
+    for (int32_t i = 0; i < n; i++) {
+        switch (kind) {
+        case 0: out[i] = std::sin(a[i]); break;
+        case 1: out[i] = std::cos(a[i]); break;
+        case 2: out[i] = std::atan(a[i]); break;
+        case 3: out[i] = std::acos(a[i]); break;
+        case 4: out[i] = std::atan2(a[i], b[i]); break;
+        case 5: out[i] = std::log(a[i]); break;
+        case 6: out[i] = std::exp(a[i]); break;
+        case 7: out[i] = std::pow(a[i], b[i]); break;
+        case 8: out[i] = std::sqrt(a[i]); break;
+        case 9: out[i] = a[i] / b[i]; break;
+        case 10: out[i] = inversesqrt(a[i]); break;
+        default: out[i] = 0.0F;
+        }
+    }
+}
+
 void orc_create_camera(atn_camera_param* out, const float* origin, const float* lookat, const float* up,
     float vfov, float z_near, float z_far, int32_t width, int32_t height)
 {

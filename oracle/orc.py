@@ -67,6 +67,18 @@ def math_kat(kind, a, b=None, c=None):
     return out
 
 
+LIBM_KINDS = ["sinf", "cosf", "atanf", "acosf", "atan2f", "logf", "expf", "powf", "sqrtf", "div", "inversesqrt"]
+
+
+def libm_probe(kind, a, b=None):
+    """The oracle build's libm on arrays (kind: a name from LIBM_KINDS)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ones_like(a) if b is None else np.ascontiguousarray(b, np.float32)
+    out = np.zeros_like(a)
+    lib().orc_libm_probe(LIBM_KINDS.index(kind), len(a), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
 def create_camera(pos, at, vfov, width, height, up=(0, 1, 0), znear=0.1, zfar=10000.0):
     from aten_amd import layout as L
     cam = np.zeros((), L.CAMERA_PARAM)

@@ -129,7 +129,8 @@ def test_8spp_8bounce_vs_oracle_640x360(ctx, orc, atrium, brk):
                   got, want)
     # one depth-8 sample is inside the band for ~95-97 % of the pixels; a pixel that averages 8 independent samples is
     # inside only if all eight are (0.95^8 = 0.66), while with the break most pixels stop after their first sample
-    assert frac >= (0.90 if brk else 0.60), (brk, frac)
+    # measured (profiles/parity_r05.json, unchanged in r06): 0.9325 / 0.6701 -- the floors are those minus a margin for another box's ocml
+    assert frac >= (0.92 if brk else 0.65), (brk, frac)
     assert mean_err <= 1e-2, (brk, mean_err)
 
 
@@ -156,7 +157,7 @@ def test_companion_workload_1080p_vs_oracle(ctx, orc, atrium):
         got = ctx.render(w, h, 5, 3, frame=frame)
         want, cnt = orc.render(fs, c, seeds, w, h, 5, 3, frame=frame, counters=True)
         frac, mean_err = frame_tolerance_report(got, want)
-        assert frac >= 0.97, (frame, frac)
+        assert frac >= 0.975, (frame, frac)          # measured 0.9812 / 0.9813 (profiles/parity_r05.json)
         assert mean_err <= 5e-3, (frame, mean_err)
         ctx.reset()
         ctx.render(w, h, 5, 3, frame=frame, count_stats=True, download=False)

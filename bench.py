@@ -40,14 +40,15 @@ def algorithmic_bytes(nodes, tris, rays):
 L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, MI355X_MICROARCH.md (L2 section)
 
 
-def profile_counters(scene, w, h, spp, depth, svgf):
+def profile_counters(scene, w, h, spp, depth, svgf, brk_multi=False):
     """Per-launch PMC averages of this workload's kernels from the committed passes (profiles/*counters*.json, written by
     tools/pmc_to_json.py from `rocprofv3 --pmc` runs of this same command): bench.py cannot collect PMC counters itself
     (they need the profiler around the process), so the fractions below combine those counters with the launch
     durations measured live here.  None when no committed profile matches the workload."""
     import glob
     from aten_amd.build import kernel_sources_sha16, build_id, loaded_build_id
-    tag = "%s %dx%d %dspp %d-bounce%s" % (scene, w, h, spp, depth, " svgf" if svgf else "")
+    # (brk_multi: several samples per pixel with the CPU renderer's break-on-terminate sample loop -- its own work, its own counters)
+    tag = "%s %dx%d %dspp %d-bounce%s%s" % (scene, w, h, spp, depth, " svgf" if svgf else "", " break" if brk_multi else "")
     sha = kernel_sources_sha16()
     # the binary that is being timed (ATEN_AMD_LIB may point at a variant build): counters count only if they were taken on
     # THIS binary, and this binary is what the tree's sources build (hash + flags compiled into it: atn_build_id)
@@ -454,7 +455,7 @@ def run_workload(args, cfg, ctx):
     avg_launch_s = max(roof_ms * 1e-3, 1e-12)
     scene_tag = {"sponza": "sponza_lod", "sponza_own_tree": "sponza_lod own tree", "sponza_ref_tree_opt": "sponza_lod reference tree optimised",
                  "cornell": "cornell", "atrium": "atrium"}[scene]
-    prof, stale, sha = profile_counters(scene_tag, W, H, spp, depth, svgf)
+    prof, stale, sha = profile_counters(scene_tag, W, H, spp, depth, svgf, brk_multi=(spp > 1 and brk))
     pk = kernel_entry((prof,), dominant) if prof else None
     # The committed PMC record is of the UNSHARDED launch.  A rank of a world of N traces the rays of every N-th 8x8 tile: its
     # launch does 1/N of the record's accesses and bytes (interleaved tiles: equal shares within a per cent), in a duration that
@@ -726,6 +727,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=0.0, help="seconds of CPU-baseline sampling (default 16, + 8 for the 8-thread sample; below 12 the 8-thread sample is skipped)")
     ap.add_argument("--no-companion", action="store_true",
                     help="the default run (Sponza stand-in, 1 GPU) also times the 250 K-triangle procedural atrium at the same 1080p 1 spp "
                          "5-bounce protocol and reports it under `companion` (SURVEY 8(d): the stand-in AND a synthetic scale-up); this skips it")
@@ -801,6 +803,7 @@ def main():
     cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
            "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
            "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "regen_timed": args.regen,
+           **({"cpu_budget_s": args.cpu_budget, "cpu_8_threads": args.cpu_budget >= 12} if args.cpu_budget > 0 else {}),
            "verify_film": args.verify_film or (world > 1 and not args.no_verify_film)}
     out = run_workload(args, cfg, ctx)
 

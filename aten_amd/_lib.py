@@ -31,7 +31,7 @@ SYMBOLS = [
     "atn_mgpu_set_random", "atn_mgpu_render", "atn_mgpu_reset", "atn_mgpu_synchronize", "atn_mgpu_film_device",
     "atn_mgpu_download_film",
     "atn_set_regeneration", "atn_get_regeneration", "atn_render_burst", "atn_regen_stage_counts",
-    "atn_mgpu_set_regeneration", "atn_mgpu_render_burst", "atn_set_upload_options", "atn_libm_probe",
+    "atn_mgpu_set_regeneration", "atn_mgpu_render_burst", "atn_set_upload_options", "atn_libm_probe", "atn_set_shade_math",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
         l.atn_reset.argtypes = [vp]
         l.atn_set_upload_options.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         l.atn_set_regeneration.argtypes = [vp, C.c_int32]
+        l.atn_set_shade_math.argtypes = [vp, C.c_int32]
         l.atn_get_regeneration.argtypes = [vp]; l.atn_get_regeneration.restype = C.c_int32
         l.atn_render_burst.argtypes = [vp, C.POINTER(Destination), C.c_int32, vp]
         l.atn_regen_stage_counts.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -103,7 +103,10 @@ def build_host(force=False):
 #   aten_amd.hip      -fno-slp-vectorize  (no packed-fp32 pairing: the path-tracing kernels lose 15-25 % of their registers to it)
 #   svgf_atrous.hip   vectoriser on       (straight-line tap arithmetic, 22 % faster packed)
 #   regen.hip         -fno-slp-vectorize  (the path-regeneration kernels: same sources and flags as aten_amd.hip's, compiled beside them)
-HIP_UNITS = [("aten_amd.hip", ["-fno-slp-vectorize"]), ("regen.hip", ["-fno-slp-vectorize"]), ("svgf_atrous.hip", [])]
+#   shade_relaxed.hip  k_shade with the reference GPU build's --use_fast_math rules (opt-in, atn_set_shade_math): contraction, approximate
+#                      division / sqrt, flushed denormals (the unit itself redirects sinf / cosf / expf / logf / powf to the hardware forms)
+RELAXED_FLAGS = ["-fno-slp-vectorize", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"]
+HIP_UNITS = [("aten_amd.hip", ["-fno-slp-vectorize"]), ("regen.hip", ["-fno-slp-vectorize"]), ("shade_relaxed.hip", RELAXED_FLAGS), ("svgf_atrous.hip", [])]
 
 
 def hip_compile(out_lib, extra_flags=(), objdir=None, hipcc=None):

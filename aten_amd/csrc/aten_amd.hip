@@ -18,6 +18,7 @@
 #include "../../include/aten_amd.h"
 #include "device/kernels.hpp"
 #include "device/regen_launch.hpp"
+#include "device/relaxed_launch.hpp"
 #include "device/svgf.hpp"
 #include "device/lbvh.hpp"
 #include "host/scene_upload.hpp"
@@ -1195,6 +1196,10 @@ public:
         // (the SVGF flavour -- AOV writes, 25 registers spilled at 96 -- stays at 4: C5 4.66 vs 4.68 ms per frame)
         const int shade_waves = env_shade_waves ? env_shade_waves
                               : (!SVGF && frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
+        if (!SVGF && shade_math_relaxed) {      // atn_set_shade_math(1): the same kernel under --use_fast_math rules (shade_relaxed.hip); not the parity path
+            relaxed_launch_shade(scene.material_set, shade_waves, g_shade, st, pb, scene, fp, camera, b);
+            return;
+        }
         switch (scene.material_set) {       // BSDFs no uploaded material uses are compiled out of the instantiation launched
         // (small sets: 5 waves per SIMD when frames overlap -- they share the SIMDs with another frame's trace waves --, 4 otherwise:
         // kernels.hpp, k_shade_wn)
@@ -1465,6 +1470,7 @@ public:
     // Stages are launched up to the bound n_frames * spp * maxDepth (a pixel's worst case); the kernels read their counts from
     // device memory, and a stage whose queue is empty costs a kernel start.
     // ------------------------------------------------------------------------------------------------
+    bool shade_math_relaxed = false;    // atn_set_shade_math
     int regen_mode = 0;         // atn_set_regeneration: 0 = serial sample loop, 1 = regenerated pool wherever it applies
     uint64_t rg_host_totals[4] = {};
     static constexpr int32_t kRegenMaxStages = 1 << 16;
@@ -2030,6 +2036,13 @@ int atn_set_regeneration(atn_ctx* ctx, int32_t mode)
     CTX_QUIET_OR_FAIL(ctx);
     if (mode < 0 || mode > 1) return ctx->r.fail(ATN_ERR_INVALID_ARG, "regeneration mode out of range");
     ctx->r.regen_mode = mode;
+    return ATN_OK;
+}
+int atn_set_shade_math(atn_ctx* ctx, int32_t mode)
+{
+    CTX_QUIET_OR_FAIL(ctx);
+    if (mode < 0 || mode > 1) return ctx->r.fail(ATN_ERR_INVALID_ARG, "shade math mode out of range");
+    ctx->r.shade_math_relaxed = mode == 1;
     return ATN_OK;
 }
 int32_t atn_get_regeneration(atn_ctx* ctx) { return ctx ? ctx->r.regen_mode : 0; }

@@ -14,12 +14,18 @@
 #include "shading.hpp"
 #include "toon.hpp"
 
-// Two translation units include this file: aten_amd.hip (everything but the regeneration kernels) and regen.hip (ATN_REGEN_TU: the
-// regeneration kernels and the templates they instantiate).  Kernels that are not templates belong to exactly one of them.
-#ifdef ATN_REGEN_TU
+// Three translation units include this file: aten_amd.hip (everything but the regeneration kernels), regen.hip (ATN_REGEN_TU: the
+// regeneration kernels and the templates they instantiate) and shade_relaxed.hip (ATN_TEMPLATES_ONLY: k_shade under other compiler
+// flags).  Kernels that are not templates belong to exactly one of them.
+#if defined(ATN_REGEN_TU) || defined(ATN_TEMPLATES_ONLY)
 #define ATN_MAIN_TU 0
 #else
 #define ATN_MAIN_TU 1
+#endif
+#ifdef ATN_REGEN_TU
+#define ATN_REGEN_KERNELS 1
+#else
+#define ATN_REGEN_KERNELS 0
 #endif
 
 namespace atn {
@@ -293,7 +299,7 @@ ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const 
     ro.frames[(size_t)frame_k * (uint32_t)fp.n_slots + slot] = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
 }
 
-#if !ATN_MAIN_TU
+#if ATN_REGEN_KERNELS
 // The pool's first population: sample 0 of frame 0 for every pixel of this shard (= k_gen_path with the regeneration state words), as
 // regions for k_regen_compact(0) like a shade launch's output ("stage -1": q_count[-1] = the slots it worked on).
 __global__ void __launch_bounds__(256) k_regen_begin(PathBuffers pb, FrameParams fp, atn_camera_param cam)
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams f
     ro.film[pixel] = out;
     if (ro.tile_out) ro.tile_out[slot] = out;
 }
-#endif  // !ATN_MAIN_TU
+#endif  // ATN_REGEN_KERNELS
 
 // REFILL selects the persistent, lane-refilling walk (large trees) or the plain walk (small trees and small launches,
 // where the refill bookkeeping costs more than the idle lanes it removes).

@@ -129,6 +129,10 @@ class PathTracing:
         v = lambda x: -1 if x is None else int(x)
         self._check(self._l.atn_set_upload_options(self._ctx, v(anyhit_twin), v(anyhit_twin_dirs), v(node_layout), v(planar_lights)))
 
+    def set_shade_math(self, relaxed):
+        """False (default): the parity path; True: the shade kernel under the reference GPU build's --use_fast_math rules (opt-in)."""
+        self._check(self._l.atn_set_shade_math(self._ctx, int(relaxed)))
+
     def set_regeneration(self, on):
         """Path regeneration (include/aten_amd.h): the samples of a frame / the frames of a burst share one pool of path slots."""
         self._check(self._l.atn_set_regeneration(self._ctx, int(on)))

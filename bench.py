@@ -244,6 +244,8 @@ def run_workload(args, cfg, ctx):
     stage, gathered, ev_ready, ev_free = [None, None], [None, None], [None, None], [None, None]
     full = [None]
 
+    if cfg.get("shade_math") == "relaxed":
+        r.set_shade_math(True)      # --shade-math relaxed: NOT the parity path (atn_set_shade_math), named in config.shade_math
     regen_timed = int(cfg.get("regen_timed") or 0)      # --regen K: the timed steps ARE regenerated bursts of K frames
     if regen_timed:
         r.set_regeneration(True)
@@ -692,7 +694,7 @@ def run_workload(args, cfg, ctx):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp": spp, "max_depth": depth, "rr_depth": rr,
                        "sharding": "8x8 screen tiles, tile %% %d, RCCL all_gather of tile buffers" % world if world > 1 else "none",
-                       "frames_in_flight": in_flight,
+                       "frames_in_flight": in_flight, "shade_math": cfg.get("shade_math", "strict"),
                        "regeneration": ({"enabled_in_timed_region": True, "burst_frames": regen_timed} if regen_timed else regen_info),
                        "triangles": int(len(fs.arrays["triangles"])), "bvh_nodes": int(sum(len(n) for n in fs.arrays["bvh_lists"])),
                        "anyhit_twins": n_twins, "planar_area_lights": n_planar},
@@ -739,6 +741,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="consecutive frames enqueued on rotating banks of path state and streams (atn_set_frames_in_flight): "
                          "one frame's launch tails overlap the next frame's bulk; 1 = strictly one frame at a time")
+    ap.add_argument("--shade-math", default="strict", choices=["strict", "relaxed"],
+                    help="relaxed: k_shade under the reference GPU build's --use_fast_math rules (atn_set_shade_math 1) -- an opt-in that leaves the parity path; "
+                         "the line says so in config.shade_math")
     ap.add_argument("--regen", type=int, default=0,
                     help="K > 0: the timed steps are path-regenerated bursts of K progressive frames (atn_render_burst; --steps a multiple of K, one GPU); "
                          "default 0: the serial loop is timed and an 8-frame regenerated burst is measured beside it (config.regeneration)")
@@ -802,7 +807,7 @@ def main():
     ctx = {"torch": torch, "dist": dist, "rank": rank, "local_rank": local_rank, "world": world, "use_dist": use_dist}
     cfg = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth, "svgf": args.svgf,
            "all_samples": args.all_samples, "frames_in_flight": args.frames_in_flight, "experiment": args.experiment,
-           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "regen_timed": args.regen,
+           "cpu_baseline": not args.no_cpu_baseline, "dump": args.dump, "regen_timed": args.regen, "shade_math": args.shade_math,
            **({"cpu_budget_s": args.cpu_budget, "cpu_8_threads": args.cpu_budget >= 12} if args.cpu_budget > 0 else {}),
            "verify_film": args.verify_film or (world > 1 and not args.no_verify_film)}
     out = run_workload(args, cfg, ctx)

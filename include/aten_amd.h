@@ -158,6 +158,13 @@ int32_t atn_get_regeneration(atn_ctx* ctx);
 int atn_render_burst(atn_ctx* ctx, const atn_destination* dst, int32_t n_frames, atn_vec4* out_host);
 int atn_regen_stage_counts(atn_ctx* ctx, uint32_t* closest, uint32_t* shadow, uint32_t capacity, uint32_t* n_stages);
 
+/* Floating-point rules of the shade kernel.  0 (default): every operation rounds as the CPU renderer's SSE2 build does -- no fused
+ * multiply-add, correctly rounded division and square root, ocml's sinf / cosf / ...: the parity path, what every test and the
+ * headline number use.  1: the rules of the reference's own GPU build (src/libidaten/CMakeLists.txt:188, nvcc --use_fast_math): fused
+ * multiply-adds, approximate division / square root, the hardware's transcendentals, denormals flushed.  Frames then differ from the
+ * CPU renderer's beyond the parity tolerance (measured: DESIGN.md section 7f); serial loop only (not the regenerated pool, not SVGF). */
+int atn_set_shade_math(atn_ctx* ctx, int32_t mode);
+
 /* ≙ idaten::Renderer::reset (renderer.h:40-43): clears the progressive film. */
 int atn_reset(atn_ctx* ctx);
 

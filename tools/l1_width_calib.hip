@@ -26,6 +26,15 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool lane_on(int active)
 {
     const uint32_t ln = threadIdx.x & 63u;
+    if (active >= 10) {
+        // lane-packing study (r06): the same NUMBER of active lanes packed into the low lanes (whole quads where the count allows)
+        // against scattered over the wave.  10 + count: packed (lanes 0 .. count-1); 100 + count: scattered (a fixed pseudo-random subset)
+        const bool scattered = active >= 100;
+        const uint32_t count = (uint32_t)(scattered ? active - 100 : active - 10);
+        if (!scattered) return ln < count;
+        // rank of this lane in a fixed permutation of 0..63 (odd multiplier mod 64 is a bijection)
+        return ((ln * 37u + 11u) & 63u) < count;
+    }
     return active == 0 || (active == 1 && (ln & 3u) == 0u) || (active == 2 && ln < 16u) || (active == 3 && ((ln * 2654435761u) >> 16) % 64u < 27u);
 }
 
@@ -105,7 +114,26 @@ static void run(const char* table, uint32_t bytes, int* out)
     }
 }
 
-int main()
+// r06: does it matter WHERE in the wave the live lanes sit?  (if packed lanes cost the TCP >= 30 % less, keeping live
+// rays in the low lanes at refill time could pay; if not, the refill walk's lane occupancy is closed.)
+template <int W, int W2, bool BUF>
+static void run_packing(const char* table, uint32_t bytes, int* out)
+{
+    const int full = kCUs * 8, iters = 2000;
+    for (int count : { 64, 48, 32, 28, 27, 16, 8 }) {
+        for (int scattered = 0; scattered < 2; scattered++) {
+            if (count == 64 && scattered) continue;
+            const int active = (scattered ? 100 : 10) + count;
+            float ms = best_of([&] { hipLaunchKernelGGL((k_width<W, W2, BUF>), dim3(full), dim3(256), 0, 0, table, bytes, bytes / 32 - 1, out, iters, active); });
+            const double wave_insts_per_cu = (double)full * 4 * iters * 8 * (W2 ? 2 : 1) / kCUs;
+            printf("{\"study\": \"lane packing\", \"kind\": \"%s\", \"dwords\": \"%d%s\", \"active_lanes\": %d, \"placement\": \"%s\", \"ms\": %.4f, \"clocks_per_wave_load\": %.2f, \"clocks_per_record\": %.2f}\n",
+                   BUF ? "buffer" : "global", W, W2 == 0 ? "" : "+4", count, scattered ? "scattered over the wave" : "packed into the low lanes", ms,
+                   ms * 1e-3 * 2.4e9 / wave_insts_per_cu, ms * 1e-3 * 2.4e9 / (wave_insts_per_cu / (W2 ? 2 : 1)));
+        }
+    }
+}
+
+int main(int argc, char** argv)
 {
     int* out; CK(hipMalloc(&out, 64));
     const uint32_t bytes = 16384;
@@ -113,6 +141,12 @@ int main()
     for (size_t i = 0; i < h.size(); i++) h[i] = (int)(i * 2654435761u);
     char* table; CK(hipMalloc(&table, bytes));
     CK(hipMemcpy(table, h.data(), bytes, hipMemcpyHostToDevice));
+    if (argc > 1 && !strcmp(argv[1], "--packing")) {
+        run_packing<4, 0, true>(table, bytes, out);     // one 16-byte buffer load per lane
+        run_packing<4, 4, true>(table, bytes, out);     // the walk's inner step: both halves of one 32-byte record
+        CK(hipFree(table)); CK(hipFree(out));
+        return 0;
+    }
     run<1, 0, false>(table, bytes, out); run<2, 0, false>(table, bytes, out); run<3, 0, false>(table, bytes, out); run<4, 0, false>(table, bytes, out);
     run<1, 0, true>(table, bytes, out); run<2, 0, true>(table, bytes, out); run<3, 0, true>(table, bytes, out); run<4, 0, true>(table, bytes, out);
     run<4, 4, false>(table, bytes, out); run<4, 3, false>(table, bytes, out); run<4, 2, false>(table, bytes, out); run<4, 1, false>(table, bytes, out);

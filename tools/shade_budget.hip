@@ -3,7 +3,7 @@
 // the empty probe.  Not part of the library.
 #include <hip/hip_runtime.h>
 #include "../include/aten_amd.h"
-#define ATN_REGEN_TU 1          // (templates and helpers only: none of kernels.hpp's own __global__ functions)
+#define ATN_TEMPLATES_ONLY 1    // (templates and helpers only: none of kernels.hpp's own __global__ functions)
 #include "../aten_amd/csrc/device/kernels.hpp"
 using namespace atn;
 

@@ -141,6 +141,7 @@ public:
     // LBVH rebuild scratch (atn_lbvh_*), grown on demand
     struct LbvhScratch {
         DevBuf<uint32_t> codes[2], indices[2], counts, totals, arrived, offs;
+        DevBuf<uint8_t> flips;          // per inner node, bit g: twin g swaps the children (k_lbvh_twin_flips)
         DevBuf<int32_t> left, right, parent, first, last;
         DevBuf<atn_bvh_node> ref_nodes;
         DevBuf<LbvhBox> pre, suf, sup;
@@ -977,22 +978,12 @@ public:
         if (list_tri_leaves[list] != n || list_inner[list] != n - 1 || list_bytes[list] != (n - 1) * kInnerBytes + n * kTriLeafBytes)
             return fail(ATN_ERR_UNSUPPORTED, "the list was not uploaded as a binary tree with one leaf per triangle of this range");
         ATN_HIP(hipSetDevice(device));
-        // The list's any-hit twin (scene_upload.hpp) is a threading of the tree that is about to be replaced: it is switched off --
-        // the twin word of every TLAS leaf that enters this list becomes 0 -- and stays off until the next full upload.
-        const bool drop_twin = list < list_twin_delta.size() && list_twin_delta[list] != 0;
-        size_t n_patch = 0;
-        if (drop_twin) for (const auto& r : tlas_refs) n_patch += r.list == list ? 1 : 0;
-        { int r = begin_scene_update(64 * n_patch + 64); if (r) return r; }
-        if (drop_twin) {
-            const int32_t zero = 0;
-            for (const auto& ref : tlas_refs) {
-                if (ref.list != list) continue;
-                { int r = stage_copy(reinterpret_cast<char*>(nodes.p) + ref.offset + 28u, &zero, 4); if (r) return r; }
-                log_range(SB_NODES, ref.offset + 16u, 16);
-            }
-            list_twin_delta[list] = 0;
-            if (scene.root_direct && (scene.root_blas & (int32_t)kLinkOffsetMask) == (int32_t)list_base[list]) scene.root_twin = 0;
-        }
+        // The list's any-hit twins (scene_upload.hpp) are threadings of the tree that is about to be replaced: they are re-threaded on
+        // the device from the new tree (lbvh.hpp, k_lbvh_twin_*), into the region the upload gave them; the TLAS leaves' twin words stay.
+        const int32_t twin_word = list < list_twin_delta.size() ? list_twin_delta[list] : 0;
+        const uint32_t twin_delta = (uint32_t)(twin_word & ~15), twin_dirs = twin_word == 0 ? 0u : ((twin_word & 1) ? 8u : 1u);
+        if (twin_word != 0 && twin_delta != list_bytes[list]) return fail(ATN_ERR_UNSUPPORTED, "the list's twins do not lie at the list's own size apart");
+        { int r = begin_scene_update(64); if (r) return r; }
         // a caller may have written the scene arrays in place (atn_scene_device_arrays): refresh this mesh's shading records
         { int r = repack_shade_tris(tri_offset, n); if (r) return r; }
         { int r = lbvh_enqueue(tris.p + tri_offset, n, (int32_t)tri_offset, bmin, bmax, vtx_pos.p, 0, list_base[list], upd); if (r) return r; }
@@ -1001,7 +992,16 @@ public:
                            (const atn_triangle_param*)tris.p, (const float4*)vtx_pos.p, nodes.p);
         ATN_HIP(hipGetLastError());
         log_range(SB_NODES, list_base[list], list_bytes[list]);
-        // the root is node 0 = an inner record at the start of the region: the TLAS leaves' root link stays valid
+        if (twin_dirs) {
+            if (lb.flips.n < n) ATN_HIP(lb.flips.resize(n));
+            LbvhTopo t{ lb.left.p, lb.right.p, lb.parent.p, lb.first.p, lb.last.p };
+            hipLaunchKernelGGL(k_lbvh_twin_flips, dim3((n + 255) / 256), dim3(256), 0, upd, n, t, (const atn_bvh_node*)lb.ref_nodes.p, twin_dirs, lb.flips.p);
+            hipLaunchKernelGGL(k_lbvh_twin_emit, dim3((nn + 255) / 256, twin_dirs), dim3(256), 0, upd, n, t, (const atn_bvh_node*)lb.ref_nodes.p,
+                               (const uint32_t*)lb.offs.p, (const uint8_t*)lb.flips.p, twin_delta, (const atn_triangle_param*)tris.p, (const float4*)vtx_pos.p, nodes.p);
+            ATN_HIP(hipGetLastError());
+            log_range(SB_NODES, list_base[list] + twin_delta, (size_t)twin_dirs * twin_delta);
+        }
+        // the root is node 0 = an inner record at the start of the region: the TLAS leaves' root link (and twin word) stay valid
         { int r = end_scene_update(); if (r) return r; }
         if (sync) ATN_HIP(hipStreamSynchronize(upd));
         return ATN_OK;

@@ -389,4 +389,72 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(uint32_t n, const atn_bvh_nod
     }
 }
 
+// ---- the any-hit twins of a rebuilt list (host: csrc/host/anyhit_twin.hpp, scene_upload.hpp) ---------------------------------------
+// A twin is another THREADING of the same tree -- only the order of an inner node's two children may differ -- that the shadow rays of
+// infinite lights walk; any order gives the same answer, a good one finds the occluder sooner.  After a rebuild the list is a new
+// tree, so its twins are re-threaded here, on the device, from the tree that was just built: twin g (one per octant of the ray's
+// direction, bit a = dir[a] > 0) enters FIRST the child whose exit face along that octant's sign vector lies further out (back to
+// front: what blocks a ray that leaves a surface lies far along it) when the two exit faces are more than 5 % of the node's extent
+// apart -- the host rule's direction part; where they are not, the children stay in the list's own order (the host consults its
+// surface-area model there; the film does not depend on the choice, tests/test_gpu_anyhit_twin.py).
+// k_lbvh_twin_flips: one byte per inner node, bit g = "twin g swaps the children".
+__global__ __launch_bounds__(256) void k_lbvh_twin_flips(uint32_t n, LbvhTopo t, const atn_bvh_node* __restrict__ nodes, uint32_t n_dir, uint8_t* __restrict__ flips)
+{
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
+    if (idx >= num - 1) return;
+    uint32_t m = 0;
+    if (n_dir == 8u) {
+        const atn_bvh_node na = nodes[t.left[idx]], nb = nodes[t.right[idx]], nn = nodes[idx];
+        float ext = 0.0F;
+        for (int a = 0; a < 3; a++) ext += nn.boxmax[a] - nn.boxmin[a];
+        for (uint32_t g = 0; g < 8u; g++) {
+            float ea = 0.0F, eb = 0.0F;
+            for (int a = 0; a < 3; a++) {
+                if (g & (1u << a)) { ea += na.boxmax[a]; eb += nb.boxmax[a]; }
+                else { ea -= na.boxmin[a]; eb -= nb.boxmin[a]; }
+            }
+            if (eb - ea > 0.05F * ext) m |= 1u << g;
+        }
+    }
+    flips[idx] = (uint8_t)m;
+}
+
+// k_lbvh_twin_emit: the records of twin g (blockIdx.y) -- the list's records with the links of the other child order -- at the list's
+// own relative offsets, (1 + g) * delta bytes further on (the layout the upload gives a list's twins: anyhit_root, traverse.hpp).
+__global__ __launch_bounds__(256) void k_lbvh_twin_emit(uint32_t n, LbvhTopo t, const atn_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ offs,
+                                                        const uint8_t* __restrict__ flips, uint32_t delta,
+                                                        const atn_triangle_param* __restrict__ scene_tris, const float4* __restrict__ scene_vtx,
+                                                        float4* __restrict__ image)
+{
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x, num = (int32_t)n;
+    if (idx >= 2 * num - 1) return;
+    const uint32_t g = blockIdx.y, shift = (1u + g) * delta;
+    auto first_of = [&](int32_t p) { return ((flips[p] >> g) & 1u) ? t.right[p] : t.left[p]; };
+    auto second_of = [&](int32_t p) { return ((flips[p] >> g) & 1u) ? t.left[p] : t.right[p]; };
+    int32_t next = -1;      // where a walk goes when it is done with this node's subtree
+    for (int32_t cur = idx;;) {
+        const int32_t p = t.parent[cur];
+        if (p < 0) break;
+        if (first_of(p) == cur) { next = second_of(p); break; }
+        cur = p;
+    }
+    auto typed = [&](int32_t l) -> int32_t {
+        if (l < 0) return kLinkEnd;
+        return (int32_t)(offs[l] + shift) | (l >= num - 1 ? kLinkToLeaf : 0);
+    };
+    const atn_bvh_node nd = nodes[idx];
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<char*>(image) + offs[idx] + shift);
+    if (idx < num - 1) {
+        q[0] = make_float4(nd.boxmin[0], nd.boxmin[1], nd.boxmin[2], __int_as_float(typed(first_of(idx))));
+        q[1] = make_float4(nd.boxmax[0], nd.boxmax[1], nd.boxmax[2], __int_as_float(typed(next)));
+    }
+    else {
+        const int32_t tri = (int32_t)nd.f1;
+        const float4 a = scene_vtx[scene_tris[tri].idx[0]], b = scene_vtx[scene_tris[tri].idx[1]], c = scene_vtx[scene_tris[tri].idx[2]];
+        q[0] = make_float4(a.x, a.y, a.z, __int_as_float(tri));
+        q[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, __int_as_float(typed(next)));
+        q[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0F);
+    }
+}
+
 } // namespace atn

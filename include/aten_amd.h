@@ -174,7 +174,7 @@ void* atn_tile_device(atn_ctx* ctx);            /* float4[atn_tile_slots]: this 
 /* How many bottom-level lists of the uploaded scene have an any-hit twin right now (csrc/host/anyhit_twin.hpp: a second threading
  * of the same tree that the shadow rays of infinite lights walk; results do not depend on it).  ATEN_AMD_ANYHIT_TWIN = 0 / 1 / 2 at
  * upload: none / where the surface-area model expects it to pay (default) / wherever a list is a binary tree.  An LBVH rebuild of a
- * list drops its twin. */
+ * list re-threads its twins on the device from the new tree. */
 uint32_t atn_anyhit_twins(atn_ctx* ctx);
 /* How many area lights' shadow rays may stop at the first hit nearer than the light right now: lights whose object is planar and placed
  * by a rigid matrix, found at upload (csrc/host/scene_upload.hpp, planar_area_light; ATEN_AMD_PLANAR_LIGHTS=0 switches the rule off).

@@ -82,9 +82,10 @@ def test_every_light_kind_and_every_way_into_a_nested_tree(orc):
             assert s2["closest_nodes"] == s0["closest_nodes"] and s2["shadow_rays"] == s0["shadow_rays"]
 
 
-def test_a_rebuilt_list_loses_its_twin(orc):
-    """atn_lbvh_rebuild_list replaces the tree a twin was a threading of: the twin is switched off with it (every TLAS leaf that enters
-    the list), also with frames in flight, and the frames after the rebuild equal those of a context that never had twins."""
+def test_a_rebuilt_list_keeps_its_twins(orc):
+    """atn_lbvh_rebuild_list replaces the tree the twins were threadings of: they are re-threaded on the device from the new tree
+    (lbvh.hpp, k_lbvh_twin_*), also with frames in flight -- the list still has its twins afterwards, and the frames after the rebuild
+    equal those of a context that never had any, byte for byte."""
     from aten_amd.renderer import PathTracing
     from aten_amd.scene import scenedefs
     from aten_amd.scene.camera import create_camera
@@ -109,19 +110,27 @@ def test_a_rebuilt_list_loses_its_twin(orc):
                 fs, d = tick_data(b, oid, 1.3)
                 n_before = r.anyhit_twins()
                 push_tick(r, fs, d)
-                assert r.anyhit_twins() == (n_before - 1 if twin else 0)                 # the rebuilt list's twin is gone
+                assert r.anyhit_twins() == n_before and (n_before >= 1 if twin else n_before == 0)     # the rebuilt list has its twins still
                 r.reset()
                 out.append(r.render(W, H, frame=7).copy())
                 fs, d = tick_data(b, oid, 2.2)
                 push_tick(r, fs, d)
                 r.reset()
                 out.append(r.render(W, H, frame=8).copy())
+                r.set_frames_in_flight(1)
+                r.reset()
+                out.append(r.render(W, H, frame=9, count_stats=True).copy())
+                films[(twin, "stats")] = r.stats()
                 films[twin] = out
             finally:
                 r.close()
     for x, y in zip(films[0], films[2]):
         assert x.tobytes() == y.tobytes()
     assert films[0][0].tobytes() != films[0][1].tobytes()
+    s0, s2 = films[(0, "stats")], films[(2, "stats")]
+    for k in ("closest_rays", "shadow_rays", "hits", "closest_nodes", "closest_tris"):
+        assert s0[k] == s2[k]
+    assert s2["shadow_nodes"] != s0["shadow_nodes"]          # (the any-hit rays do walk other threadings after the rebuild)
 
 
 def test_top_layer_update_keeps_the_twins(orc):

@@ -1480,9 +1480,10 @@ public:
     bool regen_applies(const atn_destination& d, int32_t n_frames) const
     {
         if (regen_mode == 0 || d.count_stats) return false;        // (counted frames use the serial loop's counting kernels)
-        if (d.maxDepth > kRegenMaxDepth || (uint32_t)d.sample >= kRegenMaxSpp || (uint32_t)n_frames >= kRegenMaxFrames) return false;
+        if (d.maxDepth > kRegenMaxDepth || (uint32_t)d.sample >= kRegenMaxSpp) return false;
+        if ((uint64_t)n_frames * (uint64_t)d.width * (uint64_t)d.height >= kRegenMaxItems) return false;     // (items are 28-bit)
         if (n_frames > 1 && !d.progressive) return false;           // (a burst of overwriting frames is its last frame)
-        return (int64_t)n_frames * d.sample * d.maxDepth <= kRegenMaxStages;
+        return ((int64_t)n_frames + 1) * d.sample * d.maxDepth <= kRegenMaxStages;
     }
 
     // ≙ n_frames x (idaten::PathTracing::render, pathtracing.cpp:49-153) with frame = d->frame, d->frame + 1, ...
@@ -1529,27 +1530,33 @@ public:
         if (rc) return rc;
         rc = ensure_frame(d->width, d->height, d->maxDepth);
         if (rc) return rc;
-        const int32_t stages = n_frames * d->sample * d->maxDepth;
+        // Stages: while items are left every slot is busy, so the cursor passes the last item after at most (path-stages of all items) /
+        // (slots) <= n_frames * spp * maxDepth stages; the items then in flight need at most spp * maxDepth more.
+        const int32_t stages = (n_frames + 1) * d->sample * d->maxDepth;
+        rc = regen_valid_list(d->width, d->height);
+        if (rc) return rc;
         if (pend.n < n_slots) ATN_HIP(pend.resize(n_slots));
         const size_t cstride = (size_t)stages + 3;        // counters of stages -1 .. stages + 1
-        if (rg_counters.n < 3 * cstride) ATN_HIP(rg_counters.resize(3 * cstride));
+        if (rg_counters.n < 3 * cstride + 1) ATN_HIP(rg_counters.resize(3 * cstride + 1));
         if (rg_frames.n < (size_t)n_frames * n_slots) ATN_HIP(rg_frames.resize((size_t)n_frames * n_slots));
         rg_stages = stages;
         FrameParams fp = frame_params(*d);
         fp.burst_frames = n_frames; fp.spp = d->sample;
+        fp.n_valid = rg_n_valid; fp.n_valid_rcp = udiv_rcp(rg_n_valid); fp.n_items = rg_n_valid * (uint32_t)n_frames;
         PathBuffers pb = buffers(false);
         pb.pend = pend.p;
+        pb.valid_list = rg_valid.p; pb.next_item = rg_counters.p + 3 * cstride;
         pb.q_count = rg_counters.p + 1; pb.sh_count = rg_counters.p + cstride + 1; pb.fetch_closest = rg_counters.p + 2 * cstride + 1;
         pb.fetch_shadow = nullptr;
         const RegenOut ro{ rg_frames.p, film.p, tile_out.p };
 
         if (!flavour_forced) use_refill = tree_is_deep && n_slots >= kRefillMinPaths;
-        const uint32_t n = n_slots;
+        const uint32_t n = rg_n_valid;      // the pool: one slot per pixel of the shard (n_frames >= 1: never more slots than items)
         int items = n >= 400u * 1000u ? kChunkItems : 2;
         if (env_shade_items) items = env_shade_items;
         fp.chunk_items = items;
         const uint32_t g_shade = grid_for((n + (uint32_t)items - 1u) / (uint32_t)items);
-        const uint32_t g_all = (n + 255u) / 256u, g_fused = trace_grid(2u * n);
+        const uint32_t g_all = (n_slots + 255u) / 256u, g_fused = trace_grid(2u * n);
         // the regions a shade launch writes for the compaction in front of the next stage (kernels.hpp, k_regen_compact)
         const uint32_t chunk_size = 256u * (uint32_t)items, n_chunks = (n + chunk_size - 1u) / chunk_size, n_groups = (n_chunks + kRegenGroup - 1u) / kRegenGroup;
         const size_t region_words = (size_t)n_chunks * chunk_size;
@@ -1559,12 +1566,13 @@ public:
         uint32_t* const group_counts[2] = { pb.region_counts + 2 * (size_t)n_chunks, pb.region_counts + 2 * (size_t)n_chunks + 2 * (size_t)n_groups };
         const bool big = n >= 1500u * 1000u;
         const bool small_set = scene.material_set == kMsCore || scene.material_set == kMsDisney || scene.material_set == kMsAnalytic;
-        const int shade_waves = !small_set ? 0 : env_shade_waves ? env_shade_waves
-                              : (frames_in_flight > 1 && (scene.material_set != kMsCore || big) ? 5 : 4);
+        // (the regenerated shade kernel needs all 128 registers of the 4-wave budget: held to 96 for 5 waves it spills 21-44 of them)
+        const int shade_waves = !small_set ? 0 : env_shade_waves ? env_shade_waves : 4;
+        (void)big;
         const bool lds_nodes = lds_scene_bytes() != 0u;
         const uint32_t sb = (lds_nodes && lds_scene_bytes() > 8192u) ? 256u : simple_block;
 
-        ATN_HIP(hipMemsetAsync(rg_counters.p, 0, 3 * cstride * sizeof(uint32_t), stream));
+        ATN_HIP(hipMemsetAsync(rg_counters.p, 0, (3 * cstride + 1) * sizeof(uint32_t), stream));
         ATN_HIP(hipMemsetAsync(group_counts[0], 0, 4 * (size_t)n_groups * sizeof(uint32_t), stream));
         prof_begin(prof, ATN_K_GEN);
         pb.group_counts = group_counts[0];
@@ -1593,6 +1601,7 @@ public:
         }
         if (film_pending) ATN_HIP(hipStreamWaitEvent(stream, ev_film, 0));     // the film is a running mean: burst order
         prof_begin(prof, ATN_K_GATHER);
+        regen_launch_flush((n + 255u) / 256u, stream, pb, fp, ro);
         regen_launch_end(g_all, stream, pb, fp, ro);
         prof_end(prof);
         ATN_HIP(hipGetLastError());
@@ -1605,6 +1614,31 @@ public:
             ATN_HIP(hipMemcpyAsync(out_host, film.p, (size_t)d->width * d->height * sizeof(float4), hipMemcpyDeviceToHost, stream));
             ATN_HIP(hipStreamSynchronize(stream));
         }
+        return ATN_OK;
+    }
+
+    // The shard's pixel slots that lie inside the frame, ascending (kernels.hpp: the items of a burst index it).  Built on the host from
+    // the tile geometry once per (size, shard) and shared by every bank.
+    DevBuf<uint32_t> rg_valid;
+    uint32_t rg_n_valid = 0;
+    int32_t rg_valid_key[4] = { -1, -1, -1, -1 };
+    int regen_valid_list(int32_t w, int32_t h)
+    {
+        if (rg_valid_key[0] == w && rg_valid_key[1] == h && rg_valid_key[2] == rank && rg_valid_key[3] == world && rg_valid.p) return ATN_OK;
+        const int32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+        std::vector<uint32_t> v;
+        v.reserve(n_slots);
+        for (uint32_t slot = 0; slot < n_slots; slot++) {
+            const uint32_t tile = (slot >> 6) * (uint32_t)world + (uint32_t)rank;       // slot_to_pixel, kernels.hpp
+            if (tile >= (uint32_t)(tx * ty)) continue;
+            const int32_t x = (int32_t)(tile % (uint32_t)tx) * 8 + (int32_t)(slot & 7u), y = (int32_t)(tile / (uint32_t)tx) * 8 + (int32_t)((slot & 63u) >> 3);
+            if (x < w && y < h) v.push_back(slot);
+        }
+        { int q = quiesce(); if (q) return q; }        // (other banks' bursts may be reading the old list)
+        ATN_HIP(rg_valid.resize(v.size() ? v.size() : 1));
+        ATN_HIP(hipMemcpy(rg_valid.p, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        rg_n_valid = (uint32_t)v.size();
+        rg_valid_key[0] = w; rg_valid_key[1] = h; rg_valid_key[2] = rank; rg_valid_key[3] = world;
         return ATN_OK;
     }
 

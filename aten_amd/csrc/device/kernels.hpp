@@ -36,12 +36,17 @@ constexpr uint32_t kShadowStencilFlag = 0x40000000u;      // in sh_d.w next to t
 constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.last_hit_mtrl_idx names a Specular material
 
 // ---- path regeneration (the pool form of the sample loop, PathTracing::run_regen in aten_amd.hip) -------------------------
-// A slot is a PIXEL for a whole burst of `burst_frames` progressive frames x `spp` samples: the moment its path ends, k_regen_shade
-// runs the sample epilogue (and, after the frame's last sample, the film put) and writes the pixel's next primary ray into the
-// same slot, so every launch of the burst works on a full population instead of one that decays bounce by bounce and sample by
-// sample.  What the serial loop keeps in launch arguments becomes per-path state, packed into words that travel anyway:
-//   ray_d.w : flags (bits 0-4) | bounce (bits 5-12) | sample of the frame (bits 13-31)
-//   thr.w   : CMJ dimension (bits 0-11) | frame of the burst (bits 12-31)
+// The burst's work is a list of ITEMS -- (frame k of the burst, pixel p of this shard), frame-major, pixels in tile order: item =
+// k * n_valid + j, p = valid_list[j] -- and a slot of the pool is a CONTAINER: it traces an item's `spp` samples one after the other
+// (the accumulation order of the pixel's samples is the serial loop's), and the moment the item's last path ends k_regen_shade hands
+// the slot the next item nobody has taken yet (one atomic per 1024-entry chunk).  So every launch of the burst works on a full
+// population until the items run out -- not on one that decays bounce by bounce, and not on one in which a pixel whose paths are
+// short has run through its frames and idles while the long ones finish (the Cornell box: a third of the pixels see the background).
+// Frames of one pixel may be in flight in different slots at once: they meet again in the burst's staging planes (RegenOut::frames),
+// which k_regen_end folds into the film in frame order.  What the serial loop keeps in launch arguments becomes per-path state, packed
+// into words that travel anyway:
+//   ray_d.w : flags (bits 0-4) | bounce (bits 5-12) | sample of the item (bits 13-23) | item, high 8 bits (bits 24-31)
+//   thr.w   : CMJ dimension (bits 0-11) | item, low 20 bits (bits 12-31)
 // Two things a pool that lives for tens of stages needs, and the serial loop's five bounces do not:
 //  * QUEUES THAT STAY IN SLOT ORDER.  The serial loop's append reserves room for a block's entries with one atomic, so the blocks' runs
 //    land in the order the blocks finish -- harmless for five bounces after a freshly generated, sorted queue.  In a pool every
@@ -56,9 +61,10 @@ constexpr uint32_t F_LAST_SPECULAR = 8u;     // SVGF shade only: paths.attrib.la
 constexpr uint32_t F_PENDING = 16u;         // the pixel's PREVIOUS sample still waits for its last shadow ray: its epilogue runs at the next shade
 constexpr uint32_t kRegenFlagMask = 31u;
 constexpr uint32_t kRegenBounceShift = 5u, kRegenBounceMask = 255u;
-constexpr uint32_t kRegenSampleShift = 13u;
-constexpr uint32_t kRegenDimMask = 4095u, kRegenFrameShift = 12u;
-constexpr uint32_t kRegenMaxSpp = 1u << 19, kRegenMaxFrames = 1u << 20;
+constexpr uint32_t kRegenSampleShift = 13u, kRegenSampleMask = 2047u;
+constexpr uint32_t kRegenItemHiShift = 24u;
+constexpr uint32_t kRegenDimMask = 4095u, kRegenItemLoShift = 12u, kRegenItemLoMask = (1u << 20) - 1u;
+constexpr uint32_t kRegenMaxSpp = 1u << 11, kRegenMaxItems = 1u << 28;
 constexpr uint32_t kShadowFinalFlag = 0x20000000u;        // in sh_c.w / sh_d.w: the shadow ray of a path's LAST vertex -- its light goes to `pend`, not `contrib`
 
 struct PathBuffers {
@@ -90,6 +96,8 @@ struct PathBuffers {
     uint32_t* sh_regions;
     uint32_t* region_counts;
     uint32_t* group_counts;
+    const uint32_t* valid_list;     // regeneration only: [n_valid] the shard's pixel slots that lie inside the frame, ascending (items index it)
+    uint32_t* next_item;            // regeneration only: the first item no slot has taken yet
 };
 
 struct FrameParams {
@@ -108,6 +116,7 @@ struct FrameParams {
     int32_t break_on_terminate;
     int32_t progressive;
     int32_t burst_frames, spp;  // regeneration only: progressive frames frame .. frame + burst_frames - 1, spp samples each
+    uint32_t n_valid, n_valid_rcp, n_items;     // regeneration only: pixels of this shard inside the frame (udiv_rcp of it), items of the burst
 };
 
 // slot -> pixel.  Slots are grouped in 8x8 pixel tiles (one tile per wave64): a wave's primary
@@ -243,12 +252,27 @@ __global__ void __launch_bounds__(256) k_gen_path(PathBuffers pb, FrameParams fp
 #endif  // ATN_MAIN_TU
 
 // ---- path regeneration: the pieces k_regen_begin / k_regen_shade / k_regen_end share ---------------------------------------
-// GeneratePath (pathtracing_impl.h:65-110) for pixel (ix, iy), sampler frame `fs` = frame + sample: the same operations on the
-// same operands as k_gen_path, so the same bits.
 struct RegenState { float4 o, d, t; };     // what a slot's ray_o / ray_d / thr hold
-ATN_DEV RegenState regen_primary_state(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, int32_t ix, int32_t iy,
-                                       uint32_t frame_k, uint32_t sample_s, uint32_t flags)
+// item -> (frame of the burst, pixel slot of the shard)
+ATN_DEV void regen_item(const PathBuffers& pb, const FrameParams& fp, uint32_t item, uint32_t& frame_k, uint32_t& pixel_slot)
 {
+    uint32_t j;
+    udivmod(item, fp.n_valid, fp.n_valid_rcp, frame_k, j);
+    pixel_slot = pb.valid_list[j];
+}
+ATN_DEV uint32_t regen_pack_d(uint32_t flags, uint32_t bounce, uint32_t sample_s, uint32_t item)
+{
+    return flags | (bounce << kRegenBounceShift) | (sample_s << kRegenSampleShift) | ((item >> 20) << kRegenItemHiShift);
+}
+ATN_DEV uint32_t regen_pack_t(uint32_t dim, uint32_t item) { return dim | ((item & kRegenItemLoMask) << kRegenItemLoShift); }
+// GeneratePath (pathtracing_impl.h:65-110) for sample `sample_s` of item `item`, sampler frame fs = frame + k + sample: the same
+// operations on the same operands as k_gen_path, so the same bits.
+ATN_DEV RegenState regen_primary_state(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, uint32_t item, uint32_t sample_s, uint32_t flags)
+{
+    uint32_t frame_k, p;
+    regen_item(pb, fp, item, frame_k, p);
+    int32_t ix = 0, iy = 0;
+    slot_to_pixel(fp, p, ix, iy);
     const uint32_t idx = (uint32_t)(iy * fp.width + ix);
     const uint32_t rnd = pb.seeds[idx % fp.n_seeds];
     const uint32_t fs = fp.frame + frame_k + sample_s;
@@ -262,61 +286,56 @@ ATN_DEV RegenState regen_primary_state(const PathBuffers& pb, const FrameParams&
     pinhole_sample(cam, s, t, org, dir);
     RegenState st;
     st.o = make_float4(org.x, org.y, org.z, 1.0F);                    // pdfb = 1
-    st.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(flags | (sample_s << kRegenSampleShift)));    // bounce 0
-    st.t = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(smp.dim | (frame_k << kRegenFrameShift)));
+    st.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(regen_pack_d(flags, 0u, sample_s, item)));
+    st.t = make_float4(1.0F, 1.0F, 1.0F, __uint_as_float(regen_pack_t(smp.dim, item)));
     return st;
-}
-ATN_DEV void regen_primary(const PathBuffers& pb, const FrameParams& fp, const atn_camera_param& cam, uint32_t slot, int32_t ix, int32_t iy,
-                           uint32_t frame_k, uint32_t sample_s, uint32_t flags)
-{
-    const RegenState st = regen_primary_state(pb, fp, cam, ix, iy, frame_k, sample_s, flags);
-    pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
-    pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
 }
 
 struct RegenOut {
-    float4* frames;     // [burst_frames][n_slots]: the pixel value (col / cnt, 1) every frame of the burst hands to Film::put
+    float4* frames;     // [burst_frames][n_slots]: the pixel value (col / cnt, 1) every frame of the burst hands to Film::put, by PIXEL slot
     float4* film;       // full-frame vec4[w*h] (k_regen_end only)
     float4* tile_out;   // this GPU's pixels in slot order (k_regen_end only; may be null)
 };
 constexpr uint32_t kRegenGroup = 64u;       // chunks per group of k_regen_compact's two-level prefix sum
 
-// One sample's epilogue -- OnRender's inner loop, pathtracing.cpp:339-352 = k_accumulate_sample -- and, when it was the pixel's last
-// sample of the frame, the value k_gather hands to Film::put / FilmProgressive::put (film.cpp:33-45,61-71), stored for k_regen_end.
-// `c`: the sample's contribution; `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path);
-// `frame_k`: the frame of the burst.  Per pixel the operations and their order are the serial loop's: the pixel's samples and frames
-// pass through its slot one after the other.
+// One sample's epilogue -- OnRender's inner loop, pathtracing.cpp:339-352 = k_accumulate_sample -- and, when it was the item's last
+// sample, the value k_gather hands to Film::put / FilmProgressive::put (film.cpp:33-45,61-71), stored for k_regen_end.
+// `c`: the sample's contribution; `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path).
+// The samples of an item pass through ONE slot one after the other: the operations and their order are the serial loop's.
 ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro, uint32_t slot,
-                            const f3& c, uint32_t sample_s, uint32_t frame_k, bool frame_last)
+                            const f3& c, uint32_t sample_s, uint32_t item, bool item_last)
 {
     float4 a = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
     if (sample_s != 0u) a = pb.accum[slot];
     const bool invalid = isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z)
         || c.x < 0 || c.y < 0 || c.z < 0;                     // Renderer::isInvalidColor, renderer.h:58-68
     if (!invalid) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0F; }
-    if (!frame_last) { pb.accum[slot] = a; return; }
+    if (!item_last) { pb.accum[slot] = a; return; }
     const float cnt = a.w;
-    ro.frames[(size_t)frame_k * (uint32_t)fp.n_slots + slot] = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
+    uint32_t frame_k, p;
+    regen_item(pb, fp, item, frame_k, p);
+    ro.frames[(size_t)frame_k * (uint32_t)fp.n_slots + p] = make_float4(a.x / cnt, a.y / cnt, a.z / cnt, 1.0F);
 }
 
 #if ATN_REGEN_KERNELS
-// The pool's first population: sample 0 of frame 0 for every pixel of this shard (= k_gen_path with the regeneration state words), as
-// regions for k_regen_compact(0) like a shade launch's output ("stage -1": q_count[-1] = the slots it worked on).
+// The pool's first population: slot j takes item j (sample 0), for the n_slots_pool = min(n_valid, n_items) slots of the pool; written
+// as regions for k_regen_compact(0) like a shade launch's output ("stage -1": q_count[-1] = the slots it worked on).
 __global__ void __launch_bounds__(256) k_regen_begin(PathBuffers pb, FrameParams fp, atn_camera_param cam)
 {
     __shared__ BlockAppendShared sh;
-    const uint32_t n = (uint32_t)fp.n_slots;
+    const uint32_t n = fp.n_valid < fp.n_items ? fp.n_valid : fp.n_items;
     const int items = fp.chunk_items;
     const uint32_t chunk_size = 256u * (uint32_t)items;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) pb.q_count[-1] = n;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) { pb.q_count[-1] = n; *pb.next_item = n; }
     for (uint32_t chunk = blockIdx.x * chunk_size; chunk < n; chunk += gridDim.x * chunk_size) {
         uint32_t flags = 0;
 #pragma unroll 1
         for (int k = 0; k < items; k++) {
             const uint32_t slot = chunk + (uint32_t)k * 256u + threadIdx.x;
-            int32_t ix = 0, iy = 0;
-            if (!(slot < n && slot_to_pixel(fp, slot, ix, iy))) continue;
-            regen_primary(pb, fp, cam, slot, ix, iy, 0u, 0u, 0u);
+            if (slot >= n) continue;
+            const RegenState st = regen_primary_state(pb, fp, cam, slot, 0u, 0u);
+            pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
+            pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
             flags |= 1u << k;
         }
         auto entry_of = [&](int k) { return chunk + (uint32_t)k * 256u + threadIdx.x; };
@@ -356,9 +375,21 @@ __global__ void __launch_bounds__(256) k_regen_compact(PathBuffers pb, int32_t s
     if (c == n_chunks - 1u && threadIdx.x == 0u) { pb.q_count[stage] = base_q + nq; pb.sh_count[stage - 1] = base_s + ns; }
 }
 
-// After the last stage: the epilogue of pixels whose very last sample ended with a shadow ray in flight, then the burst's frames into
-// the film -- Film::put / FilmProgressive::put (film.cpp:33-45,61-71) = k_gather, frame after frame for every pixel -- and the zero
-// k_gather writes into the tile buffer for slots outside the frame.
+// After the last stage, per SLOT: the epilogue of an item whose last sample ended with a shadow ray in flight and whose slot found no
+// further item to take (the F_PENDING marker k_regen_shade leaves in a retired slot).
+__global__ void __launch_bounds__(256) k_regen_flush(PathBuffers pb, FrameParams fp, RegenOut ro)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (fp.n_valid < fp.n_items ? fp.n_valid : fp.n_items)) return;
+    const uint32_t w = __float_as_uint(pb.ray_d[slot].w);
+    if (w & F_PENDING) {
+        const float4 pd = pb.pend[slot];
+        regen_epilogue(pb, fp, ro, slot, mk3(pd), (uint32_t)fp.spp - 1u, __float_as_uint(pd.w), true);
+    }
+}
+
+// Then, per PIXEL slot: the burst's frames into the film -- Film::put / FilmProgressive::put (film.cpp:33-45,61-71) = k_gather, frame
+// after frame for every pixel -- and the zero k_gather writes into the tile buffer for slots outside the frame.
 __global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams fp, RegenOut ro)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,8 +399,6 @@ __global__ void __launch_bounds__(256) k_regen_end(PathBuffers pb, FrameParams f
         if (ro.tile_out) ro.tile_out[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
         return;
     }
-    const uint32_t w = __float_as_uint(pb.ray_d[slot].w);
-    if (w & F_PENDING) regen_epilogue(pb, fp, ro, slot, mk3(pb.pend[slot]), (uint32_t)fp.spp - 1u, (uint32_t)fp.burst_frames - 1u, true);
     const uint32_t pixel = (uint32_t)(y * fp.width + x);
     float4 out = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
     if (fp.progressive) out = ro.film[pixel];
@@ -556,6 +585,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
         const bool valid = j < count;
 #endif
         bool push_next = false, push_shadow = false;
+        uint32_t rg_need_bits = 0u;     // REGEN: bit 2 = the slot needs a new item, bit 3 = ... and its last path's epilogue is pending
         uint32_t slot = 0;
 
         if (valid) {
@@ -568,10 +598,11 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             const f3 ray_org = mk3(ro4), ray_dir = mk3(rd4);
             float pdfb = ro4.w;
             uint32_t flags = __float_as_uint(rd4.w);
-            uint32_t rg_sample = 0u, rg_frame = 0u;     // REGEN: the path's sample of the frame, frame of the burst
+            uint32_t rg_sample = 0u, rg_item = 0u;      // REGEN: the path's sample of its item, the item (frame of the burst, pixel)
             int32_t bounce = bounce_arg;
             if constexpr (REGEN) {
-                rg_sample = flags >> kRegenSampleShift;
+                rg_sample = (flags >> kRegenSampleShift) & kRegenSampleMask;
+                rg_item = (flags >> kRegenItemHiShift) << 20;
                 bounce = (int32_t)((flags >> kRegenBounceShift) & kRegenBounceMask);
                 flags &= kRegenFlagMask;
             }
@@ -584,18 +615,21 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             bool contrib_changed = false;
             // sampler state: GeneratePath's scramble (pathtracing_impl.h:75-81) from the pixel's seed
             uint4 s4;
+            uint32_t pixel_slot = slot;         // the slot of the serial layout that IS this path's pixel (REGEN: the item's)
             {
-                int32_t px = 0, py = 0;
-                slot_to_pixel(fp, slot, px, py);
-                s4.w = (uint32_t)(py * fp.width + px);
-                const uint32_t rnd = pb.seeds[s4.w < fp.n_seeds ? s4.w : s4.w % here(fp.n_seeds)];    // (one seed per pixel is the rule)
                 uint32_t fs = fp.frame + (uint32_t)fp.sample;
                 s4.y = __float_as_uint(thr4.w);
                 if constexpr (REGEN) {
-                    rg_frame = s4.y >> kRegenFrameShift;
+                    rg_item |= s4.y >> kRegenItemLoShift;
                     s4.y &= kRegenDimMask;
+                    uint32_t rg_frame;
+                    regen_item(pb, fp, rg_item, rg_frame, pixel_slot);
                     fs = fp.frame + rg_frame + rg_sample;
                 }
+                int32_t px = 0, py = 0;
+                slot_to_pixel(fp, pixel_slot, px, py);
+                s4.w = (uint32_t)(py * fp.width + px);
+                const uint32_t rnd = pb.seeds[s4.w < fp.n_seeds ? s4.w : s4.w % here(fp.n_seeds)];    // (one seed per pixel is the rule)
                 s4.x = fs % 256u;
                 s4.z = rnd * 0x1fe3434fu * ((fs + 133u * rnd) / 256u);
             }
@@ -606,37 +640,29 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 if (flags & F_PENDING) {
                     flags &= ~F_PENDING;
                     const bool prev_last = rg_sample == 0u;     // (such a sample was not terminated: no break, the next index is the next sample)
-                    regen_epilogue(pb, fp, ro, slot, mk3(pb.pend[slot]), prev_last ? (uint32_t)fp.spp - 1u : rg_sample - 1u,
-                                   prev_last ? rg_frame - 1u : rg_frame, prev_last);
+                    const float4 pd = pb.pend[slot];            // (w: the item it belongs to -- another one when it was that item's last sample)
+                    regen_epilogue(pb, fp, ro, slot, mk3(pd), prev_last ? (uint32_t)fp.spp - 1u : rg_sample - 1u, __float_as_uint(pd.w), prev_last);
                 }
             }
             // REGEN: where the path ends.  The sample epilogue -- at once, or handed over (`pend`, F_PENDING) when the path ran out of
-            // depth without being terminated: the shadow ray of its last vertex, if NEE casts one, is yet to be traced -- and the state of
-            // the pixel's next sample (or next frame) for the slot.  The caller stores that state for ALL lanes of the wave together with
-            // the continued paths' (one full-line store per array: an array written by two groups of lanes at two places of the kernel
-            // costs the L2 and the HBM a read-modify-write per line -- measured).
+            // depth without being terminated: the shadow ray of its last vertex, if NEE casts one, is yet to be traced.  Then either the
+            // item's next sample (its state is returned: the caller stores it with the continued paths' state, all lanes together), or,
+            // when that was the item's last sample, a NEW ITEM for the slot -- taken after the chunk's entries are all shaded, one atomic
+            // for the whole chunk (need_item; the slot's state is written there).
             bool rg_stored = false;
-            auto regen_end = [&](bool out_of_depth) -> RegenState {
+            uint32_t rg_end = 0u;       // how the path ended: 0 = it did not; 1 = the item goes on (next sample: state stored); 4 / 12 = the slot needs a new item (12: with a pending epilogue)
+            auto regen_end = [&](bool out_of_depth) -> uint32_t {
                 f3 ctot = mk3(pb.contrib[slot]);
-                if (contrib_changed) { ctot = ctot + contrib_add; contrib_changed = false; }
+                if (contrib_changed) ctot = ctot + contrib_add;
                 const bool pending = out_of_depth;      // (not terminated)
-                const bool frame_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && !out_of_depth);    // pathtracing.cpp:350-352
-                if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, 0.0F);
-                else regen_epilogue(pb, fp, ro, slot, ctot, rg_sample, rg_frame, frame_last);
-                const uint32_t nk = frame_last ? rg_frame + 1u : rg_frame, ns = frame_last ? 0u : rg_sample + 1u;
-                RegenState st;
-                if (nk < (uint32_t)fp.burst_frames) {
-                    int32_t px = 0, py = 0;
-                    slot_to_pixel(fp, slot, px, py);
-                    st = regen_primary_state(pb, fp, cam, px, py, nk, ns, pending ? F_PENDING : 0u);
-                    pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
-                    push_next = true;
-                }
-                else {
-                    st.o = ro4; st.t = thr4;
-                    st.d = make_float4(rd4.x, rd4.y, rd4.z, __uint_as_float(pending ? F_PENDING : 0u));     // (k_regen_end looks for it)
-                }
-                return st;
+                const bool item_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && !out_of_depth);    // pathtracing.cpp:350-352
+                if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, __uint_as_float(rg_item));
+                else regen_epilogue(pb, fp, ro, slot, ctot, rg_sample, rg_item, item_last);
+                if (item_last) return pending ? 12u : 4u;
+                const RegenState st = regen_primary_state(pb, fp, cam, rg_item, rg_sample + 1u, pending ? F_PENDING : 0u);
+                pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
+                pb.contrib[slot] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+                return 1u;
             };
 
             flags &= ~F_HIT;
@@ -648,7 +674,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     f3 dir = ray_dir;
                     if (bounce == 0) {
                         int32_t ix = 0, iy = 0;
-                        slot_to_pixel(fp, slot, ix, iy);
+                        slot_to_pixel(fp, pixel_slot, ix, iy);
                         const float s = (float)ix / (float)here(fp.width);
                         const float t = (float)iy / (float)here(fp.height);
                         f3 o;
@@ -731,7 +757,7 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     // path's contribution and the path ends (what PathTracing::shade still computes after it --
                     // pathtracing.cpp:174-184 -- is never observed: HitShadowRay and the next bounce skip terminated paths)
                     int32_t px = 0, py = 0;
-                    slot_to_pixel(fp, slot, px, py);
+                    slot_to_pixel(fp, pixel_slot, px, py);
                     const f3 toon = toon_bsdf(sc, m, mtrlid >= 0 ? mtrlid : sc.n_materials, smp, rec.p, rec.normal, ray_dir, rec.u, rec.v, px, py);
                     contrib_add = (throughput * toon) * albedo; contrib_changed = true;
                     flags |= F_TERMINATED;
@@ -820,7 +846,6 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                     // (the path's throughput and sampler position are final here: stored now, not carried across the NEE block)
                     bool nee_final = false;     // REGEN: the vertex is the path's last and NEE's shadow ray adds to `pend`
                     if constexpr (REGEN) {
-                        RegenState st;
                         bool cont = false;
                         if (!(flags & F_TERMINATED)) {
                             pdfb = ms.pdf;
@@ -831,15 +856,16 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                         if (cont) {
                             const f3 no = ray_offset(rec.p, ray_along_normal);
                             const f3 nd = normalize(next_dir);     // ray(o, d, n) constructor re-normalises (ray.h:17-24)
-                            st.o = make_float4(no.x, no.y, no.z, pdfb);
-                            st.d = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags | ((uint32_t)(bounce + 1) << kRegenBounceShift) | (rg_sample << kRegenSampleShift)));
-                            st.t = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(smp.dim | (rg_frame << kRegenFrameShift)));
+                            pb.ray_o[slot] = make_float4(no.x, no.y, no.z, pdfb);
+                            pb.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(regen_pack_d(flags, (uint32_t)(bounce + 1), rg_sample, rg_item)));
+                            pb.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(regen_pack_t(smp.dim, rg_item)));
                             push_next = true;
                         }
                         else {
-                            st = regen_end(nee_final);
+                            rg_end = regen_end(nee_final);
+                            contrib_changed = false;
+                            push_next = rg_end == 1u;
                         }
-                        pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
                         rg_stored = true; thr_stored = true; wrote_ray = true;
                     }
                     else {
@@ -886,8 +912,9 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
             }
             if constexpr (REGEN) {
                 if (!rg_stored) {       // a miss, an emissive or first-hit toon surface: the path ended without reaching the block above
-                    const RegenState st = regen_end(false);
-                    pb.ray_o[slot] = st.o; pb.ray_d[slot] = st.d; pb.thr[slot] = st.t;
+                    rg_end = regen_end(false);
+                    contrib_changed = false;
+                    push_next = rg_end == 1u;
                     thr_stored = true;
                 }
             }
@@ -901,8 +928,12 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 const f3 contrib = mk3(pb.contrib[slot]) + contrib_add;
                 pb.contrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, 0.0F);
             }
+            if constexpr (REGEN) rg_need_bits = rg_end & 12u;
         }
-        if constexpr (REGEN) { if (valid) order[0].oflag[order[0].inv[e]] = (uint8_t)((push_next ? 1u : 0u) | (push_shadow ? 2u : 0u)); }
+        if constexpr (REGEN) {
+            // (declared inside `if (valid)`: carried out through the flag byte)
+            if (valid) order[0].oflag[order[0].inv[e]] = (uint8_t)((push_next ? 1u : 0u) | (push_shadow ? 2u : 0u) | rg_need_bits);
+        }
         else push_bits |= (push_next ? 1u << k : 0u) | (push_shadow ? 0x10000u << k : 0u);
       }
 #if ATN_SHADE_PARTITION
@@ -914,10 +945,51 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
           // into this chunk's own regions, in the order of the chunk's queue entries, no atomic on a queue cursor (k_regen_compact makes
           // the dense queues of them)
           __syncthreads();
-          for (int k = 0; k < items; k++) {
-              const uint32_t jl = (uint32_t)k * 256u + threadIdx.x;
-              const uint32_t f = jl < n_valid ? (uint32_t)order[0].oflag[jl] : 0u;
-              push_bits |= ((f & 1u) << k) | (((f >> 1) & 1u) << (16 + k));
+          // ---- new items for the slots whose item is finished: one atomic on the burst's item cursor for the whole chunk, consecutive
+          // items (= neighbouring pixels of one frame) to the entries in queue order, GeneratePath for each into its slot
+          {
+              const uint32_t tid2 = here_v(threadIdx.x);
+              const uint32_t lane2 = tid2 & 63u, wave2 = tid2 >> 6;
+              uint32_t tot = 0;
+#pragma unroll 1
+              for (int k = 0; k < items; k++) {
+                  const uint32_t jl = (uint32_t)k * 256u + threadIdx.x;
+                  const bool need = jl < n_valid && (order[0].oflag[jl] & 4u) != 0u;
+                  tot += (uint32_t)__popcll(__ballot(need));
+              }
+              if (lane2 == 0u) sh.wave_total[0][wave2] = tot;
+              __syncthreads();
+              if (threadIdx.x == 0u) {
+                  const uint32_t a = sh.wave_total[0][0] + sh.wave_total[0][1] + sh.wave_total[0][2] + sh.wave_total[0][3];
+                  sh.base[0] = a ? atomicAdd(pb.next_item, a) : 0u;
+              }
+              __syncthreads();
+              uint32_t off = sh.base[0];
+              for (uint32_t w = 0; w < wave2; w++) off += sh.wave_total[0][w];
+#pragma unroll 1
+              for (int k = 0; k < items; k++) {
+                  const uint32_t jl = (uint32_t)k * 256u + threadIdx.x;
+                  uint32_t f = jl < n_valid ? (uint32_t)order[0].oflag[jl] : 0u;
+                  const bool need = (f & 4u) != 0u;
+                  const unsigned long long m = __ballot(need);
+                  if (need) {
+                      const uint32_t item = off + bits_below_lane(m);
+                      const uint32_t slot2 = q[chunk + jl];
+                      const uint32_t pend_flag = (f & 8u) ? F_PENDING : 0u;
+                      if (item < fp.n_items) {
+                          const RegenState st = regen_primary_state(pb, fp, cam, item, 0u, pend_flag);
+                          pb.ray_o[slot2] = st.o; pb.ray_d[slot2] = st.d; pb.thr[slot2] = st.t;
+                          pb.contrib[slot2] = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+                          f |= 1u;
+                      }
+                      else {
+                          pb.ray_d[slot2] = make_float4(0.0F, 0.0F, 0.0F, __uint_as_float(pend_flag));       // retired (k_regen_flush looks for the flag)
+                      }
+                  }
+                  off += (uint32_t)__popcll(m);
+                  push_bits |= ((f & 1u) << k) | (((f >> 1) & 1u) << (16 + k));
+              }
+              __syncthreads();        // (sh is block_append2's next)
           }
           auto entry_in_order = [&](int k) { return q[chunk + (uint32_t)k * 256u + threadIdx.x]; };
           const uint32_t c = chunk / chunk_size;
@@ -1071,7 +1143,7 @@ struct ShadowJob {
             float4* dst = pb.contrib;
             if constexpr (REGEN) { if (lbits & kShadowFinalFlag) dst = pb.pend; }
             const float4 c = dst[slot];
-            dst[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, 0.0F);
+            dst[slot] = make_float4(c.x + lc.x, c.y + lc.y, c.z + lc.z, REGEN ? c.w : 0.0F);       // (pend.w: the item the sample belongs to)
         }
         return false;
     }

@@ -21,6 +21,8 @@ void regen_launch_shade(int material_set, int waves, uint32_t grid, hipStream_t 
                         const atn_camera_param& cam, int32_t stage, const RegenOut& ro);
 // the stable compaction in front of trace(stage): regions written by shade(stage - 1) (by regen_launch_begin for stage 0) -> dense queues
 void regen_launch_compact(uint32_t grid, hipStream_t st, const PathBuffers& pb, int32_t stage, uint32_t chunk_size, uint32_t* group_counts_next, uint32_t n_groups);
+// the pending epilogues of retired slots (per slot), in front of regen_launch_end (per pixel)
+void regen_launch_flush(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro);
 void regen_launch_end(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro);
 
 } // namespace atn

@@ -22,6 +22,11 @@ void regen_launch_compact(uint32_t grid, hipStream_t st, const PathBuffers& pb, 
     hipLaunchKernelGGL(k_regen_compact, dim3(grid), dim3(256), 0, st, pb, stage, chunk_size, group_counts_next, n_groups);
 }
 
+void regen_launch_flush(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro)
+{
+    hipLaunchKernelGGL(k_regen_flush, dim3(grid), dim3(256), 0, st, pb, fp, ro);
+}
+
 void regen_launch_end(uint32_t grid, hipStream_t st, const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro)
 {
     hipLaunchKernelGGL(k_regen_end, dim3(grid), dim3(256), 0, st, pb, fp, ro);

@@ -1360,8 +1360,7 @@ __global__ void __launch_bounds__(64) k_cmj_samples(uint32_t index, uint32_t dim
     }
 }
 
-// the math-library functions the float path calls, as this build answers them (atn_libm_probe; kinds as in oracle/aten_oracle.cpp,
-// orc_libm_probe)
+// the math-library functions the float path calls, as this build answers them (atn_libm_probe; kinds: include/aten_amd.h)
 __global__ void __launch_bounds__(256) k_libm_probe(int32_t kind, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -16,7 +16,9 @@ cell() {    # name  workload-tag  bench-args...
   echo "$NAME" | grep -Eq "$ONLY" || return 0
   bash tools/pmc_collect.sh "$OUT/$NAME/pmc" "1 2 3 4 5 6 7" "$@" --no-companion --no-own-tree > "$OUT/$NAME.pmc.log" 2>&1
   python tools/pmc_to_json.py "$OUT/$NAME/pmc" "$WL" > "profiles/${TAG}_counters_matrix_${NAME}.json"
+  cp "profiles/${TAG}_counters_matrix_${NAME}.json" "$OUT/"      # (gpurun brings back gpurun_out/ only: copy from there into profiles/)
   rm -rf "$OUT/$NAME/pmc"
+  [ "${MATRIX_PMC_ONLY:-0}" = "1" ] && return 0
   timeout 900 python bench.py "$@" --no-companion --no-own-tree --cpu-budget 8 --repeats 3 --min-timed-seconds 1 > "$OUT/$NAME.json" 2> "$OUT/$NAME.err"
   python - <<PY
 import json
@@ -36,4 +38,4 @@ for RES in "1920 1080 1080p" "3840 2160 4k"; do
     cell ${SCENE}_${R}_8spp_all  "$ST ${W}x${H} 8spp 5-bounce"        --scene $SCENE --width $W --height $H --spp 8 --depth 5 --steps 24 --all-samples
   done
 done
-python tools/results_matrix.py "$OUT" "$TAG"
+[ "${MATRIX_PMC_ONLY:-0}" = "1" ] || python tools/results_matrix.py "$OUT" "$TAG"

@@ -302,13 +302,16 @@ constexpr uint32_t kRegenGroup = 64u;       // chunks per group of k_regen_compa
 // sample, the value k_gather hands to Film::put / FilmProgressive::put (film.cpp:33-45,61-71), stored for k_regen_end.
 // `c`: the sample's contribution; `sample_s`: its index in the frame (0 starts the sum: the serial loop clears accum in k_gen_path).
 // The samples of an item pass through ONE slot one after the other: the operations and their order are the serial loop's.
+ATN_DEV bool regen_invalid_color(const f3& c)     // Renderer::isInvalidColor, renderer.h:58-68
+{
+    return isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z) || c.x < 0 || c.y < 0 || c.z < 0;
+}
 ATN_DEV void regen_epilogue(const PathBuffers& pb, const FrameParams& fp, const RegenOut& ro, uint32_t slot,
                             const f3& c, uint32_t sample_s, uint32_t item, bool item_last)
 {
     float4 a = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
     if (sample_s != 0u) a = pb.accum[slot];
-    const bool invalid = isnan(c.x) || isinf(c.x) || isnan(c.y) || isinf(c.y) || isnan(c.z) || isinf(c.z)
-        || c.x < 0 || c.y < 0 || c.z < 0;                     // Renderer::isInvalidColor, renderer.h:58-68
+    const bool invalid = regen_invalid_color(c);
     if (!invalid) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0F; }
     if (!item_last) { pb.accum[slot] = a; return; }
     const float cnt = a.w;
@@ -655,7 +658,9 @@ ATN_DEV void shade_body(const PathBuffers& pb, const DevScene& sc, const FramePa
                 f3 ctot = mk3(pb.contrib[slot]);
                 if (contrib_changed) ctot = ctot + contrib_add;
                 const bool pending = out_of_depth;      // (not terminated)
-                const bool item_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && !out_of_depth);    // pathtracing.cpp:350-352
+                // pathtracing.cpp:339-352: an INVALID sample `continue`s past the break -- a terminated path whose colour is NaN / negative does
+                // not stop the pixel's sample loop (k_accumulate_sample returns before it sets `done`)
+                const bool item_last = rg_sample + 1u >= (uint32_t)fp.spp || (fp.break_on_terminate && !out_of_depth && !regen_invalid_color(ctot));
                 if (pending) pb.pend[slot] = make_float4(ctot.x, ctot.y, ctot.z, __uint_as_float(rg_item));
                 else regen_epilogue(pb, fp, ro, slot, ctot, rg_sample, rg_item, item_last);
                 if (item_last) return pending ? 12u : 4u;

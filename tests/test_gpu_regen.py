@@ -218,6 +218,32 @@ def test_every_material_set_and_light_kind_regenerates(name):
         r.close()
 
 
+def test_an_invalid_sample_does_not_break_the_sample_loop():
+    """pathtracing.cpp:339-352: `if (isInvalidColor(c)) continue;` comes BEFORE `if (is_terminated) break;` -- a terminated path whose
+    colour is NaN / negative does not stop the pixel.  The Disney atrium produces such samples (0.3 % of its pixels); r06's first
+    regenerated epilogue broke on them (found by bench.py's own film check, config.regeneration.film_equals_serial).  Break mode, 8 spp,
+    bursts on rotating banks, at a size where hundreds of pixels have an invalid sample."""
+    from aten_amd.scene import scenedefs
+    fs, cam = scenedefs.atrium(detail=0.25)
+    w, h = 320, 180
+    r = _ctx(fs, cam, w, h)
+    try:
+        want, _, _ = _serial_frames(r, w, h, 4, 8, 8, True)
+        # the premise: frames of this scene do contain invalid samples (a frame with one sample per pixel shows them as NaN pixels)
+        r.reset()
+        one = r.render(w, h, 8, 3, spp=1, frame=0)
+        assert np.isnan(one[..., :3]).any(axis=-1).sum() >= 20
+        r.reset()
+        r.set_regeneration(True)
+        r.set_frames_in_flight(3)
+        r.render_burst(w, h, 2, 8, 3, spp=8, frame=0, break_on_terminate=True, download=False)
+        got = r.render_burst(w, h, 2, 8, 3, spp=8, frame=2, break_on_terminate=True)
+        assert got.tobytes() == want[3].tobytes()
+        r.set_frames_in_flight(1)
+    finally:
+        r.close()
+
+
 def test_regeneration_edge_cases(cornell):
     from aten_amd.renderer import AtenAmdError
     fs, cam = cornell

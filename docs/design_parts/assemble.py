@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""DESIGN.md from docs/design_parts/*.md (+ the matrix table from profiles/r06_matrix.md when it exists)."""
+"""DESIGN.md from docs/design_parts/*.md; every measured number in section 0's table, section 6's result sentence and the matrix /
+regeneration tables is read from profiles/r06_z_bench_*.json and profiles/r06_matrix.json.  --out FILE writes elsewhere
+(tests/test_docs_cpu.py holds DESIGN.md against it)."""
 import os
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(os.path.dirname(here))
@@ -117,5 +119,7 @@ else:
     regen_break = regen_gain = "(not collected)"
 txt = txt.replace("@@REGEN_MS_TABLE@@", regen_ms).replace("@@REGEN_BREAK_SENTENCE@@", regen_break).replace("@@REGEN_GAIN@@", regen_gain)
 txt = txt.replace("@@NUMBERS_TABLE@@", numbers).replace("@@ROOFLINE_SENTENCE@@", roofline).replace("@@MATRIX_TABLE@@", matrix)
-open(os.path.join(root, "DESIGN.md"), "w").write(txt)
+import sys
+out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(root, "DESIGN.md")
+open(out, "w").write(txt)
 print(len(txt.encode()), "bytes")

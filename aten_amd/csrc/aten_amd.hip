@@ -131,6 +131,65 @@ public:
     bool has_scene = false, has_camera = false;
     std::vector<int32_t> list_root_link;    // typed root link of every BVH list (top layer = list 0, stored last)
     uint32_t n_planar_lights = 0;           // area lights flagged planar + rigid at upload (scene.planar_lights says whether the flags still hold)
+    // What a planar light's flag was derived from (scene_upload.hpp: planar_area_light): the instance's and the mesh's object records,
+    // the instance's two matrices, the mesh's triangles and the vertices they name.  An update that leaves ALL of it byte for byte
+    // as it was leaves the flag true; any other update drops every flag until the next full upload (never re-derived: the host
+    // keeps no copy of the vertices).  r06: a deformation tick (new blob vertices, rebuilt list, same lamp) used to drop them --
+    // deformable room 1.97 -> 2.04 ms per frame after the first tick (profiles/r06_rebuilt_layout_bound.jsonl).
+    struct PlanarCert {
+        int32_t inst_obj = -1, mesh_obj = -1, mtx_id = -1;
+        atn_object_param inst{}, mesh{};
+        atn_mat4 l2w{}, w2l{};
+        uint32_t tri_first = 0, tri_count = 0, vtx_lo = 0, vtx_hi = 0;     // [tri_first, tri_first + tri_count), [vtx_lo, vtx_hi]
+    };
+    std::vector<PlanarCert> planar_certs;
+    void collect_planar_certs(const atn_scene_desc* s, const std::vector<atn_light_param>& lights)
+    {
+        planar_certs.clear();
+        for (size_t i = 0; i < lights.size() && i < s->n_lights; i++) {
+            if (!lights[i]._pad) continue;
+            PlanarCert c;                                          // (planar_area_light accepted this light: every index below is in range)
+            c.inst_obj = s->lights[i].arealight_objid;
+            c.inst = s->objects[c.inst_obj];
+            const atn_object_param* o = &s->objects[c.inst_obj];
+            if (o->type == ATN_OBJ_INSTANCE) {
+                c.mtx_id = o->mtx_id;
+                if (c.mtx_id >= 0) { c.l2w = s->matrices[c.mtx_id]; c.w2l = s->matrices[c.mtx_id + 1]; }
+                c.mesh_obj = o->object_id;
+                c.mesh = s->objects[c.mesh_obj];
+                o = &s->objects[c.mesh_obj];
+            }
+            c.tri_first = (uint32_t)o->triangle_id; c.tri_count = (uint32_t)o->triangle_num;
+            c.vtx_lo = 0xFFFFFFFFu; c.vtx_hi = 0;
+            for (uint32_t t = c.tri_first; t < c.tri_first + c.tri_count; t++)
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t v = (uint32_t)s->triangles[t].idx[k];
+                    c.vtx_lo = std::min(c.vtx_lo, v); c.vtx_hi = std::max(c.vtx_hi, v);
+                }
+            planar_certs.push_back(c);
+        }
+    }
+    // the objects (and, when given, the matrices) of an atn_update_tlas leave every planar light's instance as it was uploaded
+    bool planar_certs_survive_objects(const atn_object_param* objs, uint32_t n_objs, const atn_mat4* mtxs, uint32_t n_mtxs) const
+    {
+        for (const PlanarCert& c : planar_certs) {
+            if ((uint32_t)c.inst_obj >= n_objs || std::memcmp(&objs[c.inst_obj], &c.inst, sizeof(atn_object_param)) != 0) return false;
+            if (c.mesh_obj >= 0 && ((uint32_t)c.mesh_obj >= n_objs || std::memcmp(&objs[c.mesh_obj], &c.mesh, sizeof(atn_object_param)) != 0)) return false;
+            if (c.mtx_id >= 0 && n_mtxs
+                && ((uint32_t)c.mtx_id + 1 >= n_mtxs || std::memcmp(&mtxs[c.mtx_id], &c.l2w, sizeof(atn_mat4)) != 0
+                    || std::memcmp(&mtxs[c.mtx_id + 1], &c.w2l, sizeof(atn_mat4)) != 0)) return false;
+        }
+        return true;
+    }
+    // an atn_update_geometry over these vertex / triangle ranges touches none of a planar light's triangles or vertices
+    bool planar_certs_survive_geometry(uint32_t vtx_offset, uint32_t n_vtx, uint32_t tri_offset, uint32_t n_tr) const
+    {
+        for (const PlanarCert& c : planar_certs) {
+            if (n_vtx && vtx_offset <= c.vtx_hi && (uint64_t)vtx_offset + n_vtx > c.vtx_lo) return false;
+            if (n_tr && tri_offset < c.tri_first + c.tri_count && (uint64_t)tri_offset + n_tr > c.tri_first) return false;
+        }
+        return true;
+    }
     std::vector<int32_t> list_twin_delta;   // HostSceneImage::list_twin_delta: where each list's any-hit twin starts (0 = none)
     std::vector<HostSceneImage::TlasRef> tlas_refs;     // the top layer's TLAS-leaf records and the lists they enter
     uint32_t top_base = 0, n_host_matrices = 0;
@@ -659,6 +718,7 @@ public:
         if (!build_host_image(img, s, err, env_anyhit_twin, env_anyhit_twin_dirs, layout_top, planar_lights)) return fail(ATN_ERR_UNSUPPORTED, err);
         n_planar_lights = 0;
         for (const atn_light_param& l : img.lights) n_planar_lights += l._pad != 0 ? 1u : 0u;
+        collect_planar_certs(s, img.lights);
         ATN_HIP(nodes.upload(img.nodes, stream));
         ATN_HIP(tris.upload(img.tris, stream));
         ATN_HIP(vtx_pos.upload(img.vtx_pos, stream));
@@ -825,7 +885,9 @@ public:
         if (n_mtxs) { int r = stage_copy(matrices.p, mv.data(), mtx_bytes); if (r) return r; log_range(SB_MATRICES, 0, mtx_bytes); n_host_matrices = n_mtxs; host_matrices.assign(mtxs, mtxs + n_mtxs); }
         { int r = end_scene_update(); if (r) return r; }
         list_root_link[0] = root;
-        scene.planar_lights = 0;    // a light's instance may have a new matrix, or point at another object / matrix (an objs-only update too)
+        // a light's instance may have a new matrix, or point at another object / matrix (an objs-only update too): the flags hold only
+        // if every planar light's records came back byte for byte
+        if (scene.planar_lights && !planar_certs_survive_objects(objs, n_objs, mtxs, n_mtxs)) scene.planar_lights = 0;
         tlas_refs.swap(new_refs);
         scene.root_link = root;
         fill_root_direct(scene, rec.data(), top_base, n_mtxs ? mtxs : (host_matrices.size() == n_host_matrices ? host_matrices.data() : nullptr), n_mtxs ? n_mtxs : n_host_matrices);
@@ -857,7 +919,8 @@ public:
                 if (tr[i].idx[v] < 0 || (uint32_t)tr[i].idx[v] >= n_scene_vtx) return fail(ATN_ERR_UNSUPPORTED, "triangle vertex index out of range");
         }
         ATN_HIP(hipSetDevice(device));
-        scene.planar_lights = 0;        // a light's vertices may be among these: its shadow rays walk to their closest hit from here on
+        // a light's vertices or triangles may be among these: then its shadow rays walk to their closest hit from here on
+        if (scene.planar_lights && !planar_certs_survive_geometry(vtx_offset, n_vtx, tri_offset, n_tr)) scene.planar_lights = 0;
         const size_t vb = (size_t)n_vtx * sizeof(float4), tb = (size_t)n_tr * sizeof(atn_triangle_param);
         { int r = begin_scene_update((pos ? vb : 0) + (nml ? vb : 0) + tb + 256); if (r) return r; }
         if (n_vtx && pos) { int r = stage_copy(vtx_pos.p + vtx_offset, pos, vb); if (r) return r; log_range(SB_VTX_POS, (size_t)vtx_offset * sizeof(float4), vb); }

@@ -179,7 +179,9 @@ uint32_t atn_anyhit_twins(atn_ctx* ctx);
 /* How many area lights' shadow rays may stop at the first hit nearer than the light right now: lights whose object is planar and placed
  * by a rigid matrix, found at upload (csrc/host/scene_upload.hpp, planar_area_light; ATEN_AMD_PLANAR_LIGHTS=0 switches the rule off).
  * Such a ray meets the light's object at distToLight and nowhere else, so a nearer hit is on another object and scene::hitLight's answer
- * is "blocked" whatever else the walk would find.  0 after any update that may move vertices or instance matrices. */
+ * is "blocked" whatever else the walk would find.  An update keeps the flags when it hands back every such light's object records
+ * (and, if it carries matrices, the instance's two matrices) byte for byte and writes none of the light's vertices or triangles -- a
+ * deformation tick of another mesh, other instances moving; 0 after any other update, until the next atn_upload_scene. */
 uint32_t atn_planar_area_lights(atn_ctx* ctx);
 uint32_t atn_tile_slots(atn_ctx* ctx);          /* identical on every rank: ceil(n_tiles / world) * 64 */
 void* atn_stream(atn_ctx* ctx);                 /* hipStream_t all work is enqueued on */

@@ -190,7 +190,7 @@ def test_shadow_rays_towards_planar_area_lights_stop_early(orc):
     """An area light's shadow ray needs the closest hit's OBJECT -- but when the light's object is planar and rigidly placed the ray meets
     it at distToLight and nowhere else, so a hit nearer than that is on another object and settles "blocked" (scene_upload.hpp,
     planar_area_light).  Films byte-equal with the rule off (ATEN_AMD_PLANAR_LIGHTS=0); shadow walks shorter where lights are occluded;
-    a sphere light or a light moved through atn_update_tlas is not (or no longer) treated so."""
+    a sphere light is not treated so; boxes moving through atn_update_tlas leave the lamp's flag alone."""
     from aten_amd.renderer import PathTracing
     from aten_amd.scene import scenedefs
 
@@ -228,12 +228,14 @@ def test_shadow_rays_towards_planar_area_lights_stop_early(orc):
     a, _, _, _ = run(mixed, cam, 96, 96, 0)
     b, _, nb, _ = run(mixed, cam, 96, 96, 1)
     assert nb == 1 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
-    # new instance matrices through atn_update_tlas: the flags no longer hold (the lamp's instance may have moved), results as ever
+    # new instance matrices through atn_update_tlas that move the BOXES: the lamp's records and matrices come back byte for byte, the
+    # flags hold (r06; until then any update dropped them), results as ever
     still, cam = scenedefs.cornell_box_variant(lights="area", move_boxes=False)
     moved, _ = scenedefs.cornell_box_variant(lights="area", move_boxes=True)
-    a, _, _, _ = run(still, cam, 80, 80, 0, move=moved)
-    b, _, n_before, n_after = run(still, cam, 80, 80, 1, move=moved)
-    assert n_before == 1 and n_after == 0 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    a, sa, _, _ = run(still, cam, 80, 80, 0, move=moved)
+    b, sb, n_before, n_after = run(still, cam, 80, 80, 1, move=moved)
+    assert n_before == 1 and n_after == 1 and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    assert sb["shadow_nodes"] <= sa["shadow_nodes"]
 
 
 def _hostile_lamp_scene(offset=(0.0, 0.0, 0.0)):
@@ -308,21 +310,124 @@ def test_planar_light_rule_on_hostile_geometry(orc, offset):
     assert lit.mean() > 0.2             # (the lamp does light the scene: the comparison is not about black pixels)
 
 
-def test_an_objects_only_update_drops_the_planar_light_certificate(orc, cornell):
-    """atn_update_tlas with new objects but NO matrices (the reference's `mtxs.empty()` form) can still re-point the light's instance
-    at another matrix or object: the planar / rigid flags found at upload are dropped, the film is what a fresh upload renders."""
+def test_an_update_keeps_the_planar_light_certificate_only_if_the_lamp_comes_back_unchanged(orc, cornell):
+    """atn_update_tlas (with or without matrices) and atn_update_geometry keep the planar / rigid flags found at upload exactly when
+    every flagged light's object records, matrices, triangles and vertices come back byte for byte; an update that re-points the
+    lamp's instance, gives it another matrix or writes one of its vertices drops them.  The film is what a fresh upload renders
+    either way."""
+    import copy
+    from aten_amd import layout as L
     from aten_amd.renderer import PathTracing
     fs, cam = cornell
     w, h = 96, 96
     c = make_camera(orc, cam, w, h)
-    r = PathTracing(0)
-    try:
+    a = fs.arrays
+    lamp = int(a["lights"][0]["arealight_objid"])
+    o = a["objects"][lamp]
+    mesh = int(o["object_id"]) if int(o["type"]) == L.OBJ_INSTANCE else lamp
+    t0, tn = int(a["objects"][mesh]["triangle_id"]), int(a["objects"][mesh]["triangle_num"])
+    v = int(a["triangles"][t0]["idx"][0])
+
+    def fresh():
+        r = PathTracing(0)
         r.UpdateSceneData(fs); r.updateCamera(c); r.initSampler(w, h, 0)
         assert r.planar_area_lights() == 1
+        return r
+
+    r = fresh()
+    try:
         want = r.render(w, h, 5, 3, frame=0).copy()
-        r.updateBVH(fs, with_matrices=False)
+        r.updateBVH(fs, with_matrices=False)                        # the same objects: the flags hold
+        assert r.planar_area_lights() == 1
+        r.updateBVH(fs)                                             # the same objects and matrices
+        assert r.planar_area_lights() == 1
+        lo = min(int(a["triangles"][t]["idx"].min()) for t in range(t0, t0 + tn))
+        hi = max(int(a["triangles"][t]["idx"].max()) for t in range(t0, t0 + tn))
+        other = hi + 1 if hi + 1 < len(a["vtx_pos"]) else lo - 1     # a vertex that is not the lamp's
+        assert 0 <= other < len(a["vtx_pos"]) and not (lo <= other <= hi) and lo <= v <= hi
+        r.updateGeometry(vtx_pos=a["vtx_pos"][other:other + 1], vtx_nml=a["vtx_nml"][other:other + 1], vtx_offset=other)
+        assert r.planar_area_lights() == 1
+        r.reset()
+        assert r.render(w, h, 5, 3, frame=0).tobytes() == want.tobytes()
+        r.updateGeometry(vtx_pos=a["vtx_pos"][v:v + 1], vtx_nml=a["vtx_nml"][v:v + 1], vtx_offset=v)      # one of the lamp's vertices (same value)
+        assert r.planar_area_lights() == 0
+        r.updateBVH(fs)                                             # never re-derived
         assert r.planar_area_lights() == 0
         r.reset()
         assert r.render(w, h, 5, 3, frame=0).tobytes() == want.tobytes()
     finally:
         r.close()
+    r = fresh()
+    try:
+        r.updateGeometry(triangles=a["triangles"][t0:t0 + 1], tri_offset=t0)                               # one of the lamp's triangles
+        assert r.planar_area_lights() == 0
+    finally:
+        r.close()
+    assert int(o["type"]) == L.OBJ_INSTANCE and int(o["mtx_id"]) >= 0        # (the Cornell lamp is an instance with a matrix pair)
+    moved = copy.copy(fs)
+    moved.arrays = dict(a)
+    m = a["matrices"].copy()
+    m[int(o["mtx_id"])][0][3] += np.float32(0.25)                   # the lamp moved (both matrices, consistently)
+    m[int(o["mtx_id"]) + 1][0][3] -= np.float32(0.25)
+    moved.arrays["matrices"] = m
+    r = fresh()
+    try:
+        r.updateBVH(moved)
+        assert r.planar_area_lights() == 0
+    finally:
+        r.close()
+    repointed = copy.copy(fs)
+    repointed.arrays = dict(a)
+    objs = a["objects"].copy()
+    objs[lamp]["mtx_id"] = 2 if int(o["mtx_id"]) != 2 else 4          # another instance's matrix pair
+    assert int(objs[lamp]["mtx_id"]) != int(o["mtx_id"])
+    repointed.arrays["objects"] = objs
+    r = fresh()
+    try:
+        r.updateBVH(repointed, with_matrices=False)
+        assert r.planar_area_lights() == 0
+    finally:
+        r.close()
+
+
+def test_a_deformation_tick_keeps_the_planar_light_rule(orc):
+    """The deforming-mesh room: a tick writes the blob's vertices, rebuilds its list and hands the objects back -- the lamp is not
+    touched, so its shadow rays keep stopping early (r06: they used not to, +4 % per frame after the first tick); the frames equal
+    those of a context that never had the rule, byte for byte, and shadow rays visit fewer nodes."""
+    from aten_amd.renderer import PathTracing
+    from aten_amd.scene import scenedefs
+    from aten_amd.scene.camera import create_camera
+    from test_gpu_lbvh import tick_data, push_tick
+    W, H = 160, 120
+    b, oid, cam = scenedefs.deformable_room(0.0)
+    c = create_camera(cam["pos"], cam["at"], cam["vfov"], W, H)
+    out = {}
+    for rule in (0, 1):
+        r = PathTracing(0)
+        try:
+            r.set_upload_options(planar_lights=rule)
+            fs0, d0 = tick_data(b, oid, 0.0)
+            r.UpdateSceneData(fs0); r.updateCamera(c); r.initSampler(W, H, 0)
+            assert r.planar_area_lights() == rule
+            r.set_frames_in_flight(3)
+            films = []
+            for k, t in enumerate((1.3, 2.2)):
+                for f in range(3):
+                    r.render(W, H, frame=f, download=False)                      # frames of the old tree still in flight
+                fs, d = tick_data(b, oid, t)
+                push_tick(r, fs, d)
+                assert r.planar_area_lights() == rule
+                r.reset()
+                films.append(r.render(W, H, frame=7 + k).copy())
+            r.set_frames_in_flight(1)
+            r.reset()
+            films.append(r.render(W, H, frame=9, count_stats=True).copy())
+            out[rule] = (films, r.stats())
+        finally:
+            r.close()
+    for x, y in zip(out[0][0], out[1][0]):
+        assert x.tobytes() == y.tobytes()
+    s0, s1 = out[0][1], out[1][1]
+    for k in ("closest_rays", "shadow_rays", "hits", "closest_nodes", "closest_tris"):
+        assert s0[k] == s1[k]
+    assert s1["shadow_nodes"] < s0["shadow_nodes"]

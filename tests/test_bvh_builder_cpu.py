@@ -335,7 +335,6 @@ def test_anyhit_twin_is_the_same_tree_in_another_child_order():
 
     def shape(a):
         """The tree up to the order of siblings: hash(node) = hash(box, payload, {hash(child), hash(child)}), from the root"""
-        import sys
         is_leaf = (a["f0"] >= 0) | (a["f1"] >= 0)
         hit = a["hit"].astype(np.int64); miss = a["miss"].astype(np.int64)
         raw = [a["boxmin"][j].tobytes() + a["boxmax"][j].tobytes() + np.float32([a["f0"][j], a["f1"][j], a["f2"][j], a["f3"][j]]).tobytes() for j in range(len(a))]

@@ -4,7 +4,6 @@ atn_update_camera / atn_init_sampler / atn_render (the call sequence of INTEGRAT
 The same arrays go to the CPU oracle; the films must agree.  The program then checks by itself: three atn_mgpu shards on one
 device give the same film byte for byte, atn_svgf_render gives a finite non-black image, and after a deformation tick
 (atn_update_geometry + atn_lbvh_rebuild_list + atn_update_tlas) a ray finds the moved panel."""
-import ctypes as C
 import glob
 import os
 import subprocess

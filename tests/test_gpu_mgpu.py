@@ -87,7 +87,6 @@ def test_multi_sample_frames_and_all_samples(cornell):
 
 
 def test_errors(cornell):
-    import ctypes as C
     from aten_amd._lib import lib
     from aten_amd.renderer import AtenAmdError, MultiGpuPathTracing
     with pytest.raises(AtenAmdError):

@@ -3,7 +3,6 @@ multiply-adds, approximate division / square root, hardware transcendentals) is 
 switching it on and off again leaves the parity path's films untouched (byte-equal), and the relaxed frames are the same picture --
 image mean within 1 % of the CPU oracle's, most pixels still inside the parity band -- with the measured numbers written into the
 parity report (they are what DESIGN.md section 7f quotes)."""
-import numpy as np
 import pytest
 
 from conftest import make_camera, parity_record

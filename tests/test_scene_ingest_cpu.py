@@ -143,7 +143,6 @@ def test_second_mtllib_appends_and_array_sizes_are_checked(tmp_path):
     """a second `mtllib` APPENDS to the material list (tinyobj's reader does; clearing it left earlier faces with
     ids into the old list and atns_obj_register reading mtl_is_emissive out of bounds); atns_obj_register / atns_obj_copy
     take the sizes of the caller's arrays and refuse short ones."""
-    import ctypes as C
     from aten_amd.scene import native_obj
     (tmp_path / "a.mtl").write_text("newmtl red\nKd 1 0 0\nnewmtl lamp\nKe 5 5 5\n")
     (tmp_path / "b.mtl").write_text("newmtl blue\nKd 0 0 1\n")

@@ -16,11 +16,8 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch                                                   # noqa: E402,F401  (the HIP runtime torch ships comes first)
 from aten_amd.renderer import PathTracing                      # noqa: E402
 from aten_amd.scene import scenedefs                           # noqa: E402
